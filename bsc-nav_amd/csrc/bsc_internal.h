@@ -1,0 +1,135 @@
+// bsc_internal.h — shared declarations of libbscnav.so (gfx950 only; no CPU path).
+#pragma once
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bscnav.h"
+
+typedef unsigned long long u64;
+
+// device scalar block indices (int64 each)
+enum {
+    DS_MAX_ID = 0,      // number of voxel ids assigned so far (memory_2.py max_id)
+    DS_MAX_ID_PREV = 1, // max_id before the batch in flight (voxels >= this are new in the batch)
+    DS_NPASS_TOTAL = 2, // points that passed all checks since creation
+    DS_NSEEN_TOTAL = 3,
+    DS_POOL_N = 4,      // rows used in the token pool (exact mode)
+    DS_ERROR = 5,       // sticky device-side error flag (capacity)
+    DS_B_NPASS = 6,     // batch: passing points
+    DS_B_NFIRST = 7,    // batch: first-touch points (= new voxels)
+    DS_N_HITS = 8,      // flush: rows that met a full voxel
+    DS_B_NSEG = 9,      // batch: voxel segments in the sorted point list
+    DS_RMW_TOTAL = 10,  // dense: voxel rows read-modify-written since creation
+    DS_COUNT = 16
+};
+
+struct bsc_ctx {
+    bsc_config c;
+    int device;
+    hipStream_t stream;
+    int nh;
+    int64_t ncell;
+    int g2;
+    // ---- persistent state in HBM ----
+    int32_t *occ;      // (gs,gs,nh) voxel id or -1 (memory_2.py occupied_ids)
+    int32_t *rgb_pos;  // (vcap+1,3)
+    uint8_t *rgb;      // (vcap,3)
+    float *weight;     // (vcap)
+    u64 *hmap;         // (gs,gs) packed (h+1)<<40 | order  (max_height + tie order)
+    uint8_t *cv_map;   // (gs,gs,3)
+    int64_t *dscal;    // DS_COUNT device scalars
+    int64_t *hscal;    // pinned host mirror for readbacks
+    // exact mode
+    float *cache_f;     // (iter_size,D)
+    int32_t *cache_pos; // (iter_size,3)
+    float *cache_d;     // (iter_size)
+    int64_t iter_id;    // host mirror of the cache fill
+    float *pool;        // (token_capacity,D)
+    float *pool_d;      // (token_capacity)
+    int32_t *store_rows; // (vcap+1,cache_size) pool rows; entry vcap is the grid_0_0_0 group
+    int32_t *store_cnt;  // (vcap+1)
+    int64_t n_flush;
+    // dense modes
+    float *acc;   // (vcap,D)
+    int32_t *acnt; // (vcap)
+    // ---- per-batch scratch (max_points) ----
+    int32_t *p_cell;
+    uint32_t *p_patf;
+    uint32_t *p_rgbv;
+    float *p_r2f;
+    double *p_alpha;
+    int64_t *p_scan_in, *p_scan_out;
+    u64 *keys_a, *keys_b;
+    int32_t *pass_list;
+    int32_t *seg_start;
+    double *d_transforms; // (max_frames,16)
+    int64_t *d_offsets;   // (max_frames+1)
+    int max_frames;
+    // flush scratch (iter_size)
+    int32_t *f_rowdst, *f_hit, *f_hidx, *f_rowseg, *f_rowe, *f_headpos, *f_win;
+    uint32_t *f_draws;
+    int64_t draws_cap;
+    // localize scratch
+    float *l_sims;       // per token row / voxel row
+    int64_t l_sims_cap, l_out_pos_cap, l_out_sim_cap;   // bytes
+    u64 *l_key_a, *l_key_b;
+    uint32_t *l_val_a, *l_val_b;
+    uint32_t *l_name_rank;
+    float *l_q;          // normalised queries
+    int32_t *l_out_pos;
+    float *l_out_sim;
+    bool names_dirty;
+    // primitives workspace
+    void *prim_tmp;
+    size_t prim_tmp_bytes;
+    // bookkeeping
+    int64_t order_base; // global point counter (top-down map tie order)
+    hipEvent_t ev0, ev1;
+    double last_ms[2], last_bytes[2];
+    bool timing;
+};
+
+void bsc_set_error(const char *fmt, ...);
+#define BSC_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            bsc_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return BSC_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+#define BSC_TRY(expr)                 \
+    do {                              \
+        bsc_status _s = (expr);       \
+        if (_s != BSC_OK) return _s;  \
+    } while (0)
+
+// ---- primitives (prims.hip; rocPRIM device-wide sort and scans) ----
+size_t prim_workspace_bytes(size_t max_items);
+bsc_status prim_sort_keys(bsc_ctx *x, const u64 *in, u64 *out, size_t n, int begin_bit, int end_bit);
+bsc_status prim_sort_pairs(bsc_ctx *x, const u64 *kin, u64 *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                           int begin_bit, int end_bit);
+bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
+bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
+bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
+
+// ---- kernels launchers ----
+bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *idx, int64_t P, uint8_t *flags,
+                                 double *pc, double *pg, int32_t *vox, int32_t *pix, int32_t *pat, double *r2,
+                                 double *alpha);
+bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
+                        const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
+                        bsc_draw_fn draw, void *user);
+bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
+bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, double radius, const int32_t *curr,
+                         int32_t floor_lo, int32_t floor_hi, int32_t *out_pos, float *out_sim, int32_t *out_count);
+bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out);
+bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the stream)
+
+static inline int ceil_log2_u64(uint64_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}

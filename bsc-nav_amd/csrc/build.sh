@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libbscnav.so (gfx950 only) next to the Python package.  -ffp-contract=off: every fma in the
+# geometry chain is explicit (__fma_rn); nothing else may be fused (bit-exact parity with the reference).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../libbscnav.so"
+OBJ="$HERE/_obj"
+mkdir -p "$OBJ"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+pids=()
+for f in prims ingest flush localize capi; do
+  src="$HERE/$f.hip"; obj="$OBJ/$f.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/bsc_internal.h" -nt "$obj" ] || [ "$HERE/geometry_dev.h" -nt "$obj" ] || [ "$HERE/../../include/bscnav.h" -nt "$obj" ]; then
+    ( hipcc $FLAGS -c "$src" -o "$obj" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/prims.o "$OBJ"/ingest.o "$OBJ"/flush.o "$OBJ"/localize.o "$OBJ"/capi.o
+echo "built $OUT"

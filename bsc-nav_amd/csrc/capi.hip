@@ -1,0 +1,663 @@
+// capi.hip — the extern "C" surface of libbscnav.so (include/bscnav.h): context lifetime, HBM state layout,
+// import/export of the reference's on-disk arrays, and dispatch into the kernel pipelines.
+#include "bsc_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define TPB 256
+
+static thread_local char g_err[512] = "";
+
+void bsc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *bsc_last_error(void) { return g_err; }
+extern "C" const char *bsc_version(void) { return "bscnav 0.1 (gfx950)"; }
+
+bsc_status read_scalars(bsc_ctx *x)
+{
+    BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->stream));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    return BSC_OK;
+}
+
+template <typename T>
+__global__ void k_fill(T *p, int64_t n, T v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+template <typename T>
+static void fill(bsc_ctx *x, T *p, int64_t n, T v)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + TPB - 1) / TPB;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((k_fill<T>), dim3((unsigned)blocks), dim3(TPB), 0, x->stream, p, n, v);
+}
+
+#define ALLOC(ptr, count)                                                               \
+    do {                                                                                \
+        size_t _b = sizeof(*(ptr)) * (size_t)(count);                                   \
+        hipError_t _e = hipMalloc((void **)&(ptr), _b ? _b : 16);                       \
+        if (_e != hipSuccess) {                                                         \
+            bsc_set_error("hipMalloc(%zu bytes) for %s: %s", _b, #ptr, hipGetErrorString(_e)); \
+            bsc_destroy(x);                                                             \
+            return BSC_E_HIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+static bsc_status reset_state(bsc_ctx *x)
+{
+    hipStream_t s = x->stream;
+    const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
+    const int64_t vcap = x->c.voxel_capacity;
+    fill<int32_t>(x, x->occ, x->ncell, -1);                                     // memory_2.py:717
+    BSC_HIP(hipMemsetAsync(x->rgb_pos, 0, sizeof(int32_t) * 3 * (vcap + 1), s));
+    BSC_HIP(hipMemsetAsync(x->rgb, 0, 3 * vcap, s));
+    BSC_HIP(hipMemsetAsync(x->weight, 0, sizeof(float) * vcap, s));
+    BSC_HIP(hipMemsetAsync(x->hmap, 0, sizeof(u64) * gs2, s));                  // 0 == -inf (memory_2.py:99)
+    BSC_HIP(hipMemsetAsync(x->cv_map, 0, 3 * gs2, s));
+    BSC_HIP(hipMemsetAsync(x->dscal, 0, sizeof(int64_t) * DS_COUNT, s));
+    if (x->c.mode == BSC_MODE_EXACT) {
+        BSC_HIP(hipMemsetAsync(x->cache_f, 0, sizeof(float) * (size_t)x->c.iter_size * x->c.token_dim, s));
+        BSC_HIP(hipMemsetAsync(x->cache_pos, 0, sizeof(int32_t) * 3 * (size_t)x->c.iter_size, s));
+        BSC_HIP(hipMemsetAsync(x->cache_d, 0, sizeof(float) * (size_t)x->c.iter_size, s));
+        BSC_HIP(hipMemsetAsync(x->store_cnt, 0, sizeof(int32_t) * (vcap + 1), s));
+    } else {
+        BSC_HIP(hipMemsetAsync(x->acnt, 0, sizeof(int32_t) * (vcap + 1), s));
+    }
+    BSC_HIP(hipGetLastError());
+    x->iter_id = 0;
+    x->n_flush = 0;
+    x->order_base = 0;
+    x->names_dirty = true;
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hip_stream, bsc_ctx **out)
+{
+    if (!cfg || !out) { bsc_set_error("bsc_create: null argument"); return BSC_E_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        bsc_set_error("bsc_create: no HIP device visible (libbscnav has no CPU path)");
+        return BSC_E_HIP;
+    }
+    if (device < 0 || device >= ndev) { bsc_set_error("bsc_create: device %d of %d", device, ndev); return BSC_E_INVALID; }
+    const bsc_config &c = *cfg;
+    const int64_t nh = (int64_t)c.max_h - c.min_h;
+    const int64_t ncell = (int64_t)c.grid_size * c.grid_size * nh;
+    if (c.height <= 0 || c.width <= 0 || c.grid_size <= 0 || nh <= 0 || c.patch_grid <= 0 || c.patch_grid > 255 ||
+        c.token_dim <= 0 || (c.token_dim & 3) || c.token_dim > 2048 || c.cache_size <= 0 || c.cache_size > 64 ||
+        c.iter_size <= 0 || c.iter_size > (1 << 20) || c.voxel_capacity <= 0 || c.max_points <= 0 ||
+        c.mode < 0 || c.mode > 2 || ncell >= (1ll << 31) || !(c.cell_size > 0)) {
+        bsc_set_error("bsc_create: invalid configuration (need token_dim %% 4 == 0 <= 2048, patch_grid <= 255, "
+                      "iter_size <= 2^20, gs*gs*(max_h-min_h) < 2^31)");
+        return BSC_E_INVALID;
+    }
+    BSC_HIP(hipSetDevice(device));
+    bsc_ctx *x = (bsc_ctx *)calloc(1, sizeof(bsc_ctx));
+    x->c = c;
+    x->device = device;
+    x->stream = (hipStream_t)hip_stream;
+    x->nh = (int)nh;
+    x->ncell = ncell;
+    x->g2 = c.patch_grid * c.patch_grid;
+    x->max_frames = 65535;
+    const int64_t vcap = c.voxel_capacity, gs2 = (int64_t)c.grid_size * c.grid_size;
+    const int64_t D = c.token_dim;
+    const int64_t np = c.max_points > c.iter_size ? c.max_points : c.iter_size;
+    ALLOC(x->occ, ncell);
+    ALLOC(x->rgb_pos, 3 * (vcap + 1));
+    ALLOC(x->rgb, 3 * vcap);
+    ALLOC(x->weight, vcap);
+    ALLOC(x->hmap, gs2);
+    ALLOC(x->cv_map, 3 * gs2);
+    ALLOC(x->dscal, DS_COUNT);
+    BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * DS_COUNT));
+    if (c.mode == BSC_MODE_EXACT) {
+        if (c.token_capacity <= 0) { bsc_set_error("bsc_create: token_capacity"); bsc_destroy(x); return BSC_E_INVALID; }
+        ALLOC(x->cache_f, (int64_t)c.iter_size * D);
+        ALLOC(x->cache_pos, 3 * (int64_t)c.iter_size);
+        ALLOC(x->cache_d, c.iter_size);
+        ALLOC(x->pool, c.token_capacity * D);
+        ALLOC(x->pool_d, c.token_capacity);
+        ALLOC(x->store_rows, (vcap + 1) * c.cache_size);
+        ALLOC(x->store_cnt, vcap + 1);
+        ALLOC(x->f_rowdst, c.iter_size); ALLOC(x->f_hit, c.iter_size); ALLOC(x->f_hidx, c.iter_size);
+        ALLOC(x->f_rowseg, c.iter_size); ALLOC(x->f_rowe, c.iter_size); ALLOC(x->f_headpos, c.iter_size);
+        ALLOC(x->f_win, (int64_t)c.iter_size * c.cache_size);
+        ALLOC(x->f_draws, c.iter_size);
+    } else {
+        ALLOC(x->acc, vcap * D);
+        ALLOC(x->acnt, vcap + 1);
+    }
+    ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_rgbv, np); ALLOC(x->p_r2f, np); ALLOC(x->p_alpha, np);
+    ALLOC(x->p_scan_in, np); ALLOC(x->p_scan_out, np);
+    ALLOC(x->keys_a, np); ALLOC(x->keys_b, np);
+    ALLOC(x->pass_list, np); ALLOC(x->seg_start, np);
+    ALLOC(x->d_transforms, (int64_t)x->max_frames * 16);
+    ALLOC(x->d_offsets, x->max_frames + 1);
+    ALLOC(x->l_key_a, vcap + 1); ALLOC(x->l_key_b, vcap + 1);
+    ALLOC(x->l_val_a, vcap + 1); ALLOC(x->l_val_b, vcap + 1);
+    ALLOC(x->l_name_rank, vcap + 1);
+    ALLOC(x->l_q, 1024 * D);
+    const int64_t prim_items = (np > vcap + 1) ? np : vcap + 1;
+    x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
+    hipError_t e = hipMalloc(&x->prim_tmp, x->prim_tmp_bytes);
+    if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
+    BSC_HIP(hipEventCreate(&x->ev0));
+    BSC_HIP(hipEventCreate(&x->ev1));
+    x->timing = true;
+    bsc_status st = reset_state(x);
+    if (st != BSC_OK) { bsc_destroy(x); return st; }
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    *out = x;
+    return BSC_OK;
+}
+
+extern "C" void bsc_destroy(bsc_ctx *x)
+{
+    if (!x) return;
+    hipSetDevice(x->device);
+    void *ptrs[] = {x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
+                    x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
+                    x->p_rgbv, x->p_r2f, x->p_alpha, x->p_scan_in, x->p_scan_out, x->keys_a, x->keys_b, x->pass_list,
+                    x->seg_start, x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
+                    x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
+                    x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->prim_tmp};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (x->hscal) hipHostFree(x->hscal);
+    if (x->ev0) hipEventDestroy(x->ev0);
+    if (x->ev1) hipEventDestroy(x->ev1);
+    free(x);
+}
+
+extern "C" bsc_status bsc_reset(bsc_ctx *x)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(reset_state(x));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_ingest(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
+                                 int32_t rgb_channels, const float *tokens_dev, const double *transforms_host,
+                                 const int32_t *sample_idx_dev, const int64_t *offsets_host, const double *alpha_dev,
+                                 bsc_draw_fn draw, void *user)
+{
+    if (!x || !depth_dev || !rgb_dev || !tokens_dev || !transforms_host || n_frames < 1 || n_frames > x->max_frames ||
+        rgb_channels < 3 || (sample_idx_dev && !offsets_host)) {
+        bsc_set_error("bsc_ingest: invalid argument");
+        return BSC_E_INVALID;
+    }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipMemcpyAsync(x->d_transforms, transforms_host, sizeof(double) * 16 * n_frames, hipMemcpyHostToDevice,
+                           x->stream));
+    x->names_dirty = true;
+    bsc_status st = ingest_batch(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, sample_idx_dev, offsets_host,
+                                 alpha_dev, draw, user);
+    return st;
+}
+
+extern "C" bsc_status bsc_flush(bsc_ctx *x, bsc_draw_fn draw, void *user)
+{
+    if (!x) return BSC_E_INVALID;
+    if (x->c.mode != BSC_MODE_EXACT) { bsc_set_error("bsc_flush: only the exact mode has a token cache"); return BSC_E_STATE; }
+    BSC_HIP(hipSetDevice(x->device));
+    return flush_cache(x, draw, user);
+}
+
+__global__ void k_store_totals(int n, const int32_t *cnt, int64_t *out2)
+{
+    __shared__ long long sv[TPB], st[TPB];
+    long long v = 0, t = 0;
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        const int c = cnt[i];
+        v += c > 0;
+        t += c;
+    }
+    sv[threadIdx.x] = v; st[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sv[threadIdx.x] += sv[threadIdx.x + o]; st[threadIdx.x] += st[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = sv[0]; out2[1] = st[0]; }
+}
+
+extern "C" bsc_status bsc_counters(bsc_ctx *x, int64_t *out)
+{
+    if (!x || !out) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    const int32_t *cnt = x->c.mode == BSC_MODE_EXACT ? x->store_cnt : x->acnt;
+    hipLaunchKernelGGL(k_store_totals, dim3(1), dim3(TPB), 0, x->stream, x->c.voxel_capacity + 1, cnt, x->dscal + 12);
+    BSC_TRY(read_scalars(x));
+    out[0] = x->hscal[DS_MAX_ID];
+    out[1] = x->iter_id;
+    out[2] = x->hscal[12];
+    out[3] = x->hscal[13];
+    out[4] = x->n_flush;
+    out[5] = x->hscal[DS_NPASS_TOTAL];
+    out[6] = x->hscal[DS_NSEEN_TOTAL];
+    out[7] = x->hscal[DS_RMW_TOTAL];
+    if (x->hscal[DS_ERROR]) {
+        bsc_set_error("device capacity error flag %lld (1 voxel_capacity, 2 token_capacity)", (long long)x->hscal[DS_ERROR]);
+        return BSC_E_CAPACITY;
+    }
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_geometry(bsc_ctx *x, const float *depth_dev, const double *transform_host,
+                                   const int32_t *sample_idx_dev, int64_t P, uint8_t *flags_host, double *pc_host,
+                                   double *pg_host, int32_t *vox_host, int32_t *pix_host, int32_t *pat_host,
+                                   double *r2_host, double *alpha_host)
+{
+    if (!x || !depth_dev || !transform_host || P < 1) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    hipStream_t s = x->stream;
+    BSC_HIP(hipMemcpyAsync(x->d_transforms, transform_host, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+    uint8_t *flags; double *pc, *pg, *r2, *al; int32_t *vox, *pix, *pat;
+    BSC_HIP(hipMalloc((void **)&flags, P)); BSC_HIP(hipMalloc((void **)&pc, 24 * P)); BSC_HIP(hipMalloc((void **)&pg, 24 * P));
+    BSC_HIP(hipMalloc((void **)&vox, 12 * P)); BSC_HIP(hipMalloc((void **)&pix, 8 * P)); BSC_HIP(hipMalloc((void **)&pat, 8 * P));
+    BSC_HIP(hipMalloc((void **)&r2, 8 * P)); BSC_HIP(hipMalloc((void **)&al, 8 * P));
+    BSC_HIP(hipMemsetAsync(pg, 0, 24 * P, s)); BSC_HIP(hipMemsetAsync(vox, 0, 12 * P, s));
+    BSC_HIP(hipMemsetAsync(pix, 0, 8 * P, s)); BSC_HIP(hipMemsetAsync(pat, 0, 8 * P, s));
+    BSC_HIP(hipMemsetAsync(r2, 0, 8 * P, s)); BSC_HIP(hipMemsetAsync(al, 0, 8 * P, s));
+    bsc_status st = launch_geometry_debug(x, depth_dev, sample_idx_dev, P, flags, pc, pg, vox, pix, pat, r2, al);
+    if (st == BSC_OK) {
+        hipStreamSynchronize(s);
+        if (flags_host) hipMemcpy(flags_host, flags, P, hipMemcpyDeviceToHost);
+        if (pc_host) hipMemcpy(pc_host, pc, 24 * P, hipMemcpyDeviceToHost);
+        if (pg_host) hipMemcpy(pg_host, pg, 24 * P, hipMemcpyDeviceToHost);
+        if (vox_host) hipMemcpy(vox_host, vox, 12 * P, hipMemcpyDeviceToHost);
+        if (pix_host) hipMemcpy(pix_host, pix, 8 * P, hipMemcpyDeviceToHost);
+        if (pat_host) hipMemcpy(pat_host, pat, 8 * P, hipMemcpyDeviceToHost);
+        if (r2_host) hipMemcpy(r2_host, r2, 8 * P, hipMemcpyDeviceToHost);
+        if (alpha_host) hipMemcpy(alpha_host, al, 8 * P, hipMemcpyDeviceToHost);
+    }
+    hipFree(flags); hipFree(pc); hipFree(pg); hipFree(vox); hipFree(pix); hipFree(pat); hipFree(r2); hipFree(al);
+    return st;
+}
+
+// ---- exports ---------------------------------------------------------------------------------------
+extern "C" bsc_status bsc_export_rgb(bsc_ctx *x, int32_t *pos, uint8_t *rgb, float *weight)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    const int64_t n = x->hscal[DS_MAX_ID];
+    if (n == 0) return BSC_OK;
+    if (pos) BSC_HIP(hipMemcpy(pos, x->rgb_pos, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+    if (rgb) BSC_HIP(hipMemcpy(rgb, x->rgb, 3 * n, hipMemcpyDeviceToHost));
+    if (weight) BSC_HIP(hipMemcpy(weight, x->weight, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_export_occupied(bsc_ctx *x, int32_t *occ)
+{
+    if (!x || !occ) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    BSC_HIP(hipMemcpy(occ, x->occ, sizeof(int32_t) * x->ncell, hipMemcpyDeviceToHost));
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_export_heightmap(bsc_ctx *x, double *max_height, uint8_t *cv_map)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
+    if (max_height) {
+        u64 *h = (u64 *)malloc(sizeof(u64) * gs2);
+        hipError_t e = hipMemcpy(h, x->hmap, sizeof(u64) * gs2, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (int64_t i = 0; i < gs2; ++i) max_height[i] = h[i] ? (double)((int64_t)(h[i] >> 40) - 1) : -INFINITY;
+        free(h);
+        BSC_HIP(e);
+    }
+    if (cv_map) BSC_HIP(hipMemcpy(cv_map, x->cv_map, 3 * gs2, hipMemcpyDeviceToHost));
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_export_cache(bsc_ctx *x, float *feat, int32_t *pos, float *dis)
+{
+    if (!x || x->c.mode != BSC_MODE_EXACT) return BSC_E_STATE;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    const int64_t n = x->iter_id;
+    if (n == 0) return BSC_OK;
+    if (feat) BSC_HIP(hipMemcpy(feat, x->cache_f, sizeof(float) * n * x->c.token_dim, hipMemcpyDeviceToHost));
+    if (pos) BSC_HIP(hipMemcpy(pos, x->cache_pos, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+    if (dis) BSC_HIP(hipMemcpy(dis, x->cache_d, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return BSC_OK;
+}
+
+// name key on the host (same encoding as localize.hip)
+static u64 host_name_field(int32_t v, bool last)
+{
+    int dig[12], n = 0;
+    if (v == 0) dig[n++] = 0;
+    while (v > 0) { dig[n++] = v % 10; v /= 10; }
+    u64 k = 0;
+    for (int i = 0; i < 6; ++i) {
+        int sym = (i < n) ? dig[n - 1 - i] + (last ? 1 : 0) : (last ? 0 : 10);
+        k = k * 11 + (u64)sym;
+    }
+    return k;
+}
+static u64 host_name_key(int32_t r, int32_t c, int32_t h)
+{
+    const u64 B = 1771561ull;
+    return (host_name_field(r, false) * B + host_name_field(c, false)) * B + host_name_field(h, true);
+}
+struct name_ent { u64 key; int32_t e; };
+static int cmp_name_ent(const void *a, const void *b)
+{
+    const u64 x = ((const name_ent *)a)->key, y = ((const name_ent *)b)->key;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+// gather pool rows into name-ordered contiguous output: one wavefront per output token
+__global__ __launch_bounds__(TPB) void k_gather_rows(int64_t n, const int32_t *__restrict__ src_rows,
+                                                     const float *__restrict__ pool, const float *__restrict__ pool_d,
+                                                     int D, float *__restrict__ out, float *__restrict__ out_d)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (t >= n) return;
+    const int64_t r = src_rows[t];
+    const float4 *src = (const float4 *)(pool + r * D);
+    float4 *dst = (float4 *)(out + t * D);
+    for (int v = lane; v < (D >> 2); v += 64) dst[v] = src[v];
+    if (lane == 0) out_d[t] = pool_d[r];
+}
+
+extern "C" bsc_status bsc_export_store(bsc_ctx *x, int32_t *pos_host, int32_t *cnt_host, float *feats_host,
+                                       float *dists_host)
+{
+    if (!x || x->c.mode != BSC_MODE_EXACT) { bsc_set_error("bsc_export_store: exact mode only"); return BSC_E_STATE; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    const int64_t max_id = x->hscal[DS_MAX_ID], vcap = x->c.voxel_capacity, cs = x->c.cache_size, D = x->c.token_dim;
+    // host copies of the small tables, name order on the host, feature gather on the device
+    int32_t *cnt = (int32_t *)malloc(sizeof(int32_t) * (vcap + 1));
+    int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * 3 * (max_id + 1));
+    int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * (vcap + 1) * cs);
+    hipError_t e = hipMemcpy(cnt, x->store_cnt, sizeof(int32_t) * (vcap + 1), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && max_id) e = hipMemcpy(pos, x->rgb_pos, sizeof(int32_t) * 3 * max_id, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(rows, x->store_rows, sizeof(int32_t) * (vcap + 1) * cs, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(cnt); free(pos); free(rows); BSC_HIP(e); }
+    name_ent *ents = (name_ent *)malloc(sizeof(name_ent) * (max_id + 1));
+    int64_t nv = 0, nt = 0;
+    for (int64_t c = 0; c <= max_id; ++c) {
+        const int64_t en = (c == max_id) ? vcap : c;
+        if (cnt[en] <= 0) continue;
+        ents[nv].e = (int32_t)en;
+        ents[nv].key = (c == max_id) ? host_name_key(0, 0, 0) : host_name_key(pos[3 * c], pos[3 * c + 1], pos[3 * c + 2]);
+        ++nv;
+        nt += cnt[en];
+    }
+    qsort(ents, nv, sizeof(name_ent), cmp_name_ent);
+    int32_t *src = (int32_t *)malloc(sizeof(int32_t) * (nt ? nt : 1));
+    int64_t t = 0;
+    for (int64_t i = 0; i < nv; ++i) {
+        const int32_t en = ents[i].e;
+        if (pos_host) {
+            if (en == vcap) { pos_host[3 * i] = pos_host[3 * i + 1] = pos_host[3 * i + 2] = 0; }
+            else memcpy(pos_host + 3 * i, pos + 3 * (int64_t)en, sizeof(int32_t) * 3);
+        }
+        if (cnt_host) cnt_host[i] = cnt[en];
+        for (int k = 0; k < cnt[en]; ++k) src[t++] = rows[(int64_t)en * cs + k];
+    }
+    bsc_status st = BSC_OK;
+    if (nt > 0 && (feats_host || dists_host)) {
+        int32_t *d_src = nullptr; float *d_out = nullptr, *d_outd = nullptr;
+        e = hipMalloc((void **)&d_src, sizeof(int32_t) * nt);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(float) * nt * D);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_outd, sizeof(float) * nt);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_src, src, sizeof(int32_t) * nt, hipMemcpyHostToDevice, x->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((nt * 64 + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, nt, d_src,
+                               x->pool, x->pool_d, (int)D, d_out, d_outd);
+            e = hipStreamSynchronize(x->stream);
+        }
+        if (e == hipSuccess && feats_host) e = hipMemcpy(feats_host, d_out, sizeof(float) * nt * D, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && dists_host) e = hipMemcpy(dists_host, d_outd, sizeof(float) * nt, hipMemcpyDeviceToHost);
+        if (d_src) hipFree(d_src);
+        if (d_out) hipFree(d_out);
+        if (d_outd) hipFree(d_outd);
+        if (e != hipSuccess) { bsc_set_error("bsc_export_store: %s", hipGetErrorString(e)); st = BSC_E_HIP; }
+    }
+    free(cnt); free(pos); free(rows); free(ents); free(src);
+    return st;
+}
+
+extern "C" bsc_status bsc_export_dense(bsc_ctx *x, float *acc_host, int32_t *cnt_host)
+{
+    if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_export_dense: dense modes only"); return BSC_E_STATE; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    const int64_t n = x->hscal[DS_MAX_ID];
+    if (n == 0) return BSC_OK;
+    if (acc_host) BSC_HIP(hipMemcpy(acc_host, x->acc, sizeof(float) * n * x->c.token_dim, hipMemcpyDeviceToHost));
+    if (cnt_host) BSC_HIP(hipMemcpy(cnt_host, x->acnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return BSC_OK;
+}
+
+// ---- imports (load_memory, memory_2.py:189-200) ---------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_import_occ(int64_t n, const int32_t *__restrict__ pos, int gs, int nh, int32_t *occ,
+                                                    int64_t *dscal)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = pos[3 * i], c = pos[3 * i + 1], h = pos[3 * i + 2];
+    if (r < 0 || c < 0 || h < 0 || r >= gs || c >= gs || h >= nh) { dscal[DS_ERROR] = 3; return; }
+    occ[((int64_t)r * gs + c) * nh + h] = (int32_t)i;
+}
+
+extern "C" bsc_status bsc_import_rgb(bsc_ctx *x, int64_t max_id, const int32_t *pos, const uint8_t *rgb, const float *weight)
+{
+    if (!x || max_id < 0 || max_id > x->c.voxel_capacity) { bsc_set_error("bsc_import_rgb: max_id vs capacity"); return BSC_E_CAPACITY; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(reset_state(x));
+    if (max_id == 0) return BSC_OK;
+    hipStream_t s = x->stream;
+    BSC_HIP(hipMemcpyAsync(x->rgb_pos, pos, sizeof(int32_t) * 3 * max_id, hipMemcpyHostToDevice, s));
+    BSC_HIP(hipMemcpyAsync(x->rgb, rgb, 3 * max_id, hipMemcpyHostToDevice, s));
+    BSC_HIP(hipMemcpyAsync(x->weight, weight, sizeof(float) * max_id, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_import_occ, dim3((unsigned)((max_id + TPB - 1) / TPB)), dim3(TPB), 0, s, max_id, x->rgb_pos,
+                       x->c.grid_size, x->nh, x->occ, x->dscal);
+    int64_t m[2] = {max_id, max_id};
+    BSC_HIP(hipMemcpyAsync(x->dscal + DS_MAX_ID, m, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
+    BSC_HIP(hipStreamSynchronize(s));
+    BSC_TRY(read_scalars(x));
+    if (x->hscal[DS_ERROR]) { bsc_set_error("bsc_import_rgb: position outside the grid"); return BSC_E_INVALID; }
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const int32_t *pos, const int32_t *cnt,
+                                       const float *feats, const float *dists)
+{
+    if (!x || x->c.mode != BSC_MODE_EXACT) { bsc_set_error("bsc_import_store: exact mode only"); return BSC_E_STATE; }
+    if (nt > x->c.token_capacity) { bsc_set_error("bsc_import_store: %lld tokens > token_capacity", (long long)nt); return BSC_E_CAPACITY; }
+    BSC_HIP(hipSetDevice(x->device));
+    const int64_t vcap = x->c.voxel_capacity, cs = x->c.cache_size, D = x->c.token_dim;
+    // voxel ids come from the occupied map imported before (bsc_import_rgb)
+    int32_t *occ = (int32_t *)malloc(sizeof(int32_t) * x->ncell);
+    hipError_t e = hipMemcpy(occ, x->occ, sizeof(int32_t) * x->ncell, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(occ); BSC_HIP(e); }
+    int32_t *h_cnt = (int32_t *)calloc(vcap + 1, sizeof(int32_t));
+    int32_t *h_rows = (int32_t *)calloc((vcap + 1) * cs, sizeof(int32_t));
+    int64_t t = 0;
+    bsc_status st = BSC_OK;
+    for (int64_t i = 0; i < nv && st == BSC_OK; ++i) {
+        const int32_t r = pos[3 * i], c = pos[3 * i + 1], h = pos[3 * i + 2];
+        int64_t en = -1;
+        if (r == 0 && c == 0 && h == 0) en = vcap;
+        else if (r >= 0 && c >= 0 && h >= 0 && r < x->c.grid_size && c < x->c.grid_size && h < x->nh)
+            en = occ[((int64_t)r * x->c.grid_size + c) * x->nh + h];
+        if (en < 0 || cnt[i] > cs) {
+            bsc_set_error("bsc_import_store: group grid_%d_%d_%d has no voxel id (or more than cache_size tokens)", r, c, h);
+            st = BSC_E_INVALID;
+            break;
+        }
+        h_cnt[en] = cnt[i];
+        for (int k = 0; k < cnt[i]; ++k) h_rows[en * cs + k] = (int32_t)(t++);
+    }
+    if (st == BSC_OK && t != nt) { bsc_set_error("bsc_import_store: token count mismatch"); st = BSC_E_INVALID; }
+    if (st == BSC_OK) {
+        e = hipMemcpy(x->store_cnt, h_cnt, sizeof(int32_t) * (vcap + 1), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(x->store_rows, h_rows, sizeof(int32_t) * (vcap + 1) * cs, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nt) e = hipMemcpy(x->pool, feats, sizeof(float) * nt * D, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nt) e = hipMemcpy(x->pool_d, dists, sizeof(float) * nt, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(x->dscal + DS_POOL_N, &nt, sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { bsc_set_error("bsc_import_store: %s", hipGetErrorString(e)); st = BSC_E_HIP; }
+    }
+    free(occ); free(h_cnt); free(h_rows);
+    x->names_dirty = true;
+    return st;
+}
+
+extern "C" bsc_status bsc_import_dense(bsc_ctx *x, int64_t max_id, const float *acc, const int32_t *cnt)
+{
+    if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_import_dense: dense modes only"); return BSC_E_STATE; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    if (max_id != x->hscal[DS_MAX_ID]) { bsc_set_error("bsc_import_dense: call bsc_import_rgb first (max_id mismatch)"); return BSC_E_INVALID; }
+    if (max_id == 0) return BSC_OK;
+    BSC_HIP(hipMemcpy(x->acc, acc, sizeof(float) * max_id * x->c.token_dim, hipMemcpyHostToDevice));
+    BSC_HIP(hipMemcpy(x->acnt, cnt, sizeof(int32_t) * max_id, hipMemcpyHostToDevice));
+    x->names_dirty = true;
+    return BSC_OK;
+}
+
+// ---- query ----------------------------------------------------------------------------------------------
+extern "C" bsc_status bsc_pool_query(bsc_ctx *x, const float *tokens_dev, int32_t B, int32_t T, int32_t D, float *out_dev)
+{
+    if (!x || !tokens_dev || !out_dev || B < 1 || T < 1 || D < 1) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    return pool_query_impl(x, tokens_dev, B, T, D, out_dev);
+}
+
+extern "C" bsc_status bsc_localize(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, double radius,
+                                   const int32_t *curr_host, int32_t floor_lo, int32_t floor_hi, int32_t *out_pos_host,
+                                   float *out_sim_host, int32_t *out_count_host)
+{
+    if (!x || !q_dev || !out_pos_host || !out_sim_host || !out_count_host) return BSC_E_INVALID;
+    if (radius >= 0 && !curr_host) { bsc_set_error("bsc_localize: region filter needs curr"); return BSC_E_INVALID; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    const int64_t n_rows = x->c.mode == BSC_MODE_EXACT ? x->hscal[DS_POOL_N] : x->hscal[DS_MAX_ID];
+    const int64_t need = (int64_t)nq * (n_rows > 0 ? n_rows : 1);
+    // scratch grows on demand (similarities for every query x row, top-K staging)
+    struct grow { static bsc_status run(void **p, int64_t *cap, int64_t need_bytes) {
+        if (*cap >= need_bytes) return BSC_OK;
+        if (*p) hipFree(*p);
+        *p = nullptr; *cap = 0;
+        hipError_t e = hipMalloc(p, (size_t)need_bytes);
+        if (e != hipSuccess) { bsc_set_error("bsc_localize scratch: %s", hipGetErrorString(e)); return BSC_E_HIP; }
+        *cap = need_bytes;
+        return BSC_OK;
+    } };
+    BSC_TRY(grow::run((void **)&x->l_sims, &x->l_sims_cap, need * 4));
+    BSC_TRY(grow::run((void **)&x->l_out_pos, &x->l_out_pos_cap, (int64_t)nq * K * 12));
+    BSC_TRY(grow::run((void **)&x->l_out_sim, &x->l_out_sim_cap, (int64_t)nq * K * 4));
+    return localize_impl(x, q_dev, nq, K, radius, curr_host, floor_lo, floor_hi, out_pos_host, out_sim_host, out_count_host);
+}
+
+// ---- multi-GPU merge helpers (dense modes) ---------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_dense_gather(int64_t n, const int32_t *__restrict__ keys, int gs, int nh,
+                                                      const int32_t *__restrict__ occ, const float *__restrict__ acc,
+                                                      const int32_t *__restrict__ acnt, int D, int mode,
+                                                      float *__restrict__ out, int32_t *__restrict__ out_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (i >= n) return;
+    const int32_t r = keys[3 * i], c = keys[3 * i + 1], h = keys[3 * i + 2];
+    int32_t vid = -1;
+    if (r >= 0 && c >= 0 && h >= 0 && r < gs && c < gs && h < nh) vid = occ[((int64_t)r * gs + c) * nh + h];
+    const int32_t m = vid >= 0 ? acnt[vid] : 0;
+    float4 *dst = (float4 *)(out + i * D);
+    const float fillv = (mode == BSC_MODE_MAX) ? -INFINITY : 0.f;
+    for (int v = lane; v < (D >> 2); v += 64)
+        dst[v] = (m > 0) ? ((const float4 *)(acc + (int64_t)vid * D))[v] : make_float4(fillv, fillv, fillv, fillv);
+    if (lane == 0) out_cnt[i] = m;
+}
+
+extern "C" bsc_status bsc_dense_gather(bsc_ctx *x, int64_t n, const int32_t *keys_dev, float *acc_dev, int32_t *cnt_dev)
+{
+    if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_dense_gather: dense modes only"); return BSC_E_STATE; }
+    if (n <= 0) return BSC_OK;
+    BSC_HIP(hipSetDevice(x->device));
+    hipLaunchKernelGGL(k_dense_gather, dim3((unsigned)((n * 64 + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, n, keys_dev,
+                       x->c.grid_size, x->nh, x->occ, x->acc, x->acnt, x->c.token_dim, x->c.mode, acc_dev, cnt_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_dense_replace(bsc_ctx *x, int64_t n, const int32_t *keys_dev, const float *acc_dev,
+                                        const int32_t *cnt_dev)
+{
+    if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_dense_replace: dense modes only"); return BSC_E_STATE; }
+    if (n > x->c.voxel_capacity) { bsc_set_error("bsc_dense_replace: %lld voxels > capacity", (long long)n); return BSC_E_CAPACITY; }
+    BSC_HIP(hipSetDevice(x->device));
+    hipStream_t s = x->stream;
+    // the feature map is replaced; rgb / weight / top-down map stay rank-local (multi-GPU)
+    fill<int32_t>(x, x->occ, x->ncell, -1);
+    BSC_HIP(hipMemsetAsync(x->acnt, 0, sizeof(int32_t) * (x->c.voxel_capacity + 1), s));
+    if (n > 0) {
+        BSC_HIP(hipMemcpyAsync(x->rgb_pos, keys_dev, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToDevice, s));
+        BSC_HIP(hipMemcpyAsync(x->acc, acc_dev, sizeof(float) * n * x->c.token_dim, hipMemcpyDeviceToDevice, s));
+        BSC_HIP(hipMemcpyAsync(x->acnt, cnt_dev, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_import_occ, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, n, x->rgb_pos, x->c.grid_size,
+                           x->nh, x->occ, x->dscal);
+    }
+    int64_t m[2] = {n, n};
+    BSC_HIP(hipMemcpyAsync(x->dscal + DS_MAX_ID, m, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
+    BSC_HIP(hipStreamSynchronize(s));
+    x->names_dirty = true;
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_keys_dev(bsc_ctx *x, const int32_t **keys_dev, int64_t *max_id)
+{
+    if (!x || !keys_dev || !max_id) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(read_scalars(x));
+    *keys_dev = x->rgb_pos;
+    *max_id = x->hscal[DS_MAX_ID];
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_last_kernel_stats(bsc_ctx *x, int32_t which, double *out)
+{
+    if (!x || !out || which < 0 || which > 1) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    float ms = 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, x->ev0, x->ev1);
+    out[0] = (e == hipSuccess) ? (double)ms : -1.0;
+    if (which == 0) {
+        // algorithmic bytes of the last dense reduce: U voxel rows read+written, plus counts and the token tile
+        BSC_TRY(read_scalars(x));
+        const double U = (double)x->hscal[DS_B_NSEG], D = x->c.token_dim;
+        out[1] = U * (2.0 * D * 4.0 + 8.0);
+    } else {
+        out[1] = x->last_bytes[1];
+    }
+    return BSC_OK;
+}

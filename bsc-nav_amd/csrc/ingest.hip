@@ -1,0 +1,463 @@
+// ingest.hip — obs2voxeltoken's per-point loop (memory_2.py:859-903) as a batch pipeline on gfx950.
+//
+// The reference walks the sampled points of a frame sequentially; ids, the rgb running mean, the
+// top-down map and the token cache are all defined by that order.  Here every point j of a batch
+// (frames in call order, points in the reference's shuffled order) carries its order implicitly:
+//
+//   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
+//               first toucher of every still-empty cell                         (1 thread / point)
+//   k_flags + exclusive scan + k_assign      first-touch points get ids max_id + rank in order
+//   k_keys      sort key (voxel id << 32 | j) and top-down map atomicMax on (h, order)
+//   radix sort  groups the points of a voxel, in order
+//   k_chain     per voxel: sequential truncating weighted rgb mean            (1 thread / voxel)
+//   k_dense_reduce  per voxel: run-length (frame,patch) pairs x token rows -> one RMW of the
+//               D-float accumulator row                                       (1 wavefront / voxel)
+//   k_append    exact mode: token rows into the cache in order                (1 wavefront / row)
+#include "bsc_internal.h"
+#include "geometry_dev.h"
+
+#include <limits.h>
+#include <math.h>
+
+#define TPB 256
+
+static GeomConst make_geom_const(const bsc_ctx *x)
+{
+    GeomConst g;
+    memcpy(g.K, x->c.K, sizeof g.K);
+    memcpy(g.Kinv, x->c.Kinv, sizeof g.Kinv);
+    memcpy(g.Kp, x->c.Kpatch, sizeof g.Kp);
+    g.cs = x->c.cell_size;
+    g.half_gs = (double)x->c.grid_size / 2.0;   // utils.py:202 `gs / 2` is float division
+    g.min_depth = x->c.min_depth;
+    g.max_depth = x->c.max_depth;
+    g.H = x->c.height; g.W = x->c.width; g.gs = x->c.grid_size;
+    g.min_h = x->c.min_h; g.max_h = x->c.max_h; g.nh = x->nh; g.g = x->c.patch_grid;
+    return g;
+}
+
+__device__ __forceinline__ int frame_of(const int64_t *offsets, int n_frames, int64_t j)
+{
+    int lo = 0, hi = n_frames;   // largest f with offsets[f] <= j
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__restrict__ depth,
+                                                const uint8_t *__restrict__ rgb, int rgb_ch,
+                                                const int32_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+                                                int n_frames, const double *__restrict__ transforms,
+                                                const double *__restrict__ alpha_in, int64_t P, int32_t *occ,
+                                                int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
+                                                uint32_t *__restrict__ p_rgbv, float *__restrict__ p_r2f,
+                                                double *__restrict__ p_alpha)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int64_t N = (int64_t)gc.H * gc.W;
+    int f;
+    int32_t i;
+    if (idx) {
+        f = frame_of(offsets, n_frames, j);
+        i = idx[j];
+    } else {
+        f = (int)(j / N);
+        i = (int32_t)(j - (int64_t)f * N);
+    }
+    const float z = depth[(int64_t)f * N + i];
+    GeomOut o;
+    geom_point(gc, i, z, transforms + 16 * f, o, alpha_in == nullptr);
+    if (o.flags != 7u) {
+        p_cell[j] = -1;
+        return;
+    }
+    const int32_t row = o.vox[0], col = o.vox[1], h = o.vox[2] - gc.min_h;   // memory_2.py:867
+    const int32_t cell = (row * gc.gs + col) * gc.nh + h;
+    int sx = o.pix[0], sy = o.pix[1];            // memory_2.py:870 rgb[py, px]: negative indices wrap
+    if (sx < 0) sx += gc.W;
+    if (sy < 0) sy += gc.H;
+    sx = min(max(sx, 0), gc.W - 1);
+    sy = min(max(sy, 0), gc.H - 1);
+    const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
+    p_cell[j] = cell;
+    p_patf[j] = ((uint32_t)f << 16) | (uint32_t)(o.pat[1] * gc.g + o.pat[0]);   // tokens[py, px]
+    p_rgbv[j] = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
+    p_r2f[j] = (float)o.r2;                       // memory_2.py:885 grid_feat_dis is float32
+    p_alpha[j] = alpha_in ? alpha_in[j] : o.alpha;
+    // first-touch claim: the smallest j wins an empty cell (ids are handed out in k_assign)
+    if (occ[cell] < 0) atomicMin(&occ[cell], INT_MIN + (int32_t)j);
+}
+
+__global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
+                                               const int32_t *__restrict__ occ, int64_t *__restrict__ scan_in)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int32_t c = p_cell[j];
+    int64_t v = 0;
+    if (c >= 0) {
+        v = 1;
+        if (occ[c] == INT_MIN + (int32_t)j) v |= (1ll << 32);
+    }
+    scan_in[j] = v;
+}
+
+__global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__restrict__ p_cell, int32_t *occ,
+                                                const int64_t *__restrict__ scan_in,
+                                                const int64_t *__restrict__ scan_out, int64_t *dscal, int vcap, int gs,
+                                                int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int64_t in = scan_in[j];
+    if (!(in & 1)) return;
+    const int64_t ex = scan_out[j];
+    pass_list[(uint32_t)ex] = (int32_t)j;
+    if (in >> 32) {
+        const int64_t id = dscal[DS_MAX_ID] + (ex >> 32);
+        const int32_t c = p_cell[j];
+        if (id >= vcap) {
+            dscal[DS_ERROR] = 1;        // capacity: the cell keeps its provisional (negative) value
+            return;
+        }
+        occ[c] = (int32_t)id;           // memory_2.py:890
+        const int32_t h = c % nh, rc = c / nh;
+        rgb_pos[3 * id + 0] = rc / gs;  // memory_2.py:893
+        rgb_pos[3 * id + 1] = rc % gs;
+        rgb_pos[3 * id + 2] = h;
+    }
+}
+
+__global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_out, int64_t *dscal, int vcap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t tot = scan_out[P - 1] + scan_in[P - 1];
+    const int64_t npass = tot & 0xffffffffll, nfirst = tot >> 32;
+    dscal[DS_B_NPASS] = npass;
+    dscal[DS_B_NFIRST] = nfirst;
+    dscal[DS_MAX_ID_PREV] = dscal[DS_MAX_ID];
+    int64_t m = dscal[DS_MAX_ID] + nfirst;
+    if (m > vcap) { m = vcap; dscal[DS_ERROR] = 1; }
+    dscal[DS_MAX_ID] = m;
+    dscal[DS_NPASS_TOTAL] += npass;
+    dscal[DS_NSEEN_TOTAL] += P;
+    dscal[DS_B_NSEG] = 0;
+}
+
+__global__ __launch_bounds__(TPB) void k_keys(int64_t P, const int32_t *__restrict__ p_cell,
+                                              const int32_t *__restrict__ occ, u64 *__restrict__ keys, u64 *hmap,
+                                              int nh, int64_t order_base)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int32_t c = p_cell[j];
+    u64 key = ~0ull;
+    if (c >= 0) {
+        const int32_t vid = occ[c];
+        if (vid >= 0) {
+            key = ((u64)(uint32_t)vid << 32) | (u64)(uint32_t)j;
+            // memory_2.py:901-903: `h >= max_height` in sequential order == max over (h, order)
+            const int32_t h = c % nh;
+            const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + j);
+            atomicMax(&hmap[c / nh], packed);
+        }
+    }
+    keys[j] = key;
+}
+
+__global__ __launch_bounds__(TPB) void k_hwin(int64_t P, const int32_t *__restrict__ p_cell,
+                                              const int32_t *__restrict__ occ, const u64 *__restrict__ hmap,
+                                              const uint32_t *__restrict__ p_rgbv, uint8_t *__restrict__ cv_map, int nh,
+                                              int64_t order_base)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int32_t c = p_cell[j];
+    if (c < 0 || occ[c] < 0) return;
+    const int32_t h = c % nh, rc = c / nh;
+    const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + j);
+    if (hmap[rc] == packed) {
+        const uint32_t v = p_rgbv[j];
+        cv_map[3 * (int64_t)rc + 0] = (uint8_t)(v & 0xff);
+        cv_map[3 * (int64_t)rc + 1] = (uint8_t)((v >> 8) & 0xff);
+        cv_map[3 * (int64_t)rc + 2] = (uint8_t)((v >> 16) & 0xff);
+    }
+}
+
+// memory_2.py:888-899 — one thread per voxel walks that voxel's points of the batch in order.
+__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict__ keys, const int64_t *dscal,
+                                               const uint32_t *__restrict__ p_rgbv, const double *__restrict__ p_alpha,
+                                               uint8_t *__restrict__ rgb, float *__restrict__ weight,
+                                               int32_t *__restrict__ seg_start, int64_t *dscal_w)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= P) return;
+    const u64 key = keys[i];
+    if (key == ~0ull) return;
+    const uint32_t vid = (uint32_t)(key >> 32);
+    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == vid) return;   // not a segment head
+    seg_start[atomicAdd((u64 *)&dscal_w[DS_B_NSEG], 1ull)] = (int32_t)i;
+    const bool is_new = (int64_t)vid >= dscal[DS_MAX_ID_PREV];
+    float w = 0.f;
+    uint8_t c0 = 0, c1 = 0, c2 = 0;
+    if (!is_new) {
+        w = weight[vid];
+        c0 = rgb[3 * (int64_t)vid]; c1 = rgb[3 * (int64_t)vid + 1]; c2 = rgb[3 * (int64_t)vid + 2];
+    }
+    bool first = is_new;
+    for (int64_t k = i; k < P; ++k) {
+        const u64 kk = keys[k];
+        if ((uint32_t)(kk >> 32) != vid || kk == ~0ull) break;
+        const uint32_t j = (uint32_t)kk;
+        const uint32_t v = p_rgbv[j];
+        const double a = p_alpha[j];
+        const uint8_t r0 = v & 0xff, r1 = (v >> 8) & 0xff, r2 = (v >> 16) & 0xff;
+        if (first) {                    // :890-894 new id: rgb = rgb_v, weight = f32(0 + alpha)
+            c0 = r0; c1 = r1; c2 = r2;
+            w = (float)((double)w + a);
+            first = false;
+        } else {                        // :896-899 u8*f32 -> f32 ; u8*f64 -> f64 ; truncating store
+            const double den = (double)w + a;
+            const double v0 = ((double)((float)c0 * w) + (double)r0 * a) / den;
+            const double v1 = ((double)((float)c1 * w) + (double)r1 * a) / den;
+            const double v2 = ((double)((float)c2 * w) + (double)r2 * a) / den;
+            c0 = (uint8_t)v0; c1 = (uint8_t)v1; c2 = (uint8_t)v2;
+            w = (float)den;
+        }
+    }
+    weight[vid] = w;
+    rgb[3 * (int64_t)vid] = c0; rgb[3 * (int64_t)vid + 1] = c1; rgb[3 * (int64_t)vid + 2] = c2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense feature reduce: one wavefront per voxel segment of the sorted point list.  The wave reads 64
+// sort keys at a time, run-length encodes their (frame, patch) codes with ballot/shuffle, and for every
+// run adds multiplicity x token row (lanes stride the D floats as float4, 1 KiB per wave-instruction).
+// The accumulator row is read and written exactly once per voxel per batch; token rows come from the
+// (F,g,g,D) tile that stays L2 / Infinity-Cache resident.
+template <int NV, int MODE>
+__global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ keys, int64_t P,
+                                                      const int32_t *__restrict__ seg_start, const int64_t *dscal,
+                                                      const uint32_t *__restrict__ p_patf,
+                                                      const float *__restrict__ tokens, int g2, int D,
+                                                      float *__restrict__ acc, int32_t *__restrict__ acnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    const int64_t nseg = dscal[DS_B_NSEG];
+    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
+    const int D4 = D >> 2;
+    for (int64_t s = wave; s < nseg; s += nwaves) {
+        const int64_t i0 = seg_start[s];
+        const uint32_t vid = (uint32_t)(keys[i0] >> 32);
+        float4 a[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+            a[t] = (MODE == BSC_MODE_MAX) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        int count = 0;
+        for (int64_t base = i0;; base += 64) {
+            const int64_t k = base + lane;
+            const u64 key = (k < P) ? keys[k] : ~0ull;
+            const bool inseg = (key != ~0ull) && ((uint32_t)(key >> 32) == vid);
+            const uint32_t code = inseg ? p_patf[(uint32_t)key] : 0xffffffffu;
+            const int n = __popcll(__ballot(inseg));
+            const uint32_t prev = __shfl_up(code, 1);
+            const bool head = inseg && (lane == 0 || code != prev);
+            u64 hm = __ballot(head);
+            while (hm) {
+                const int b = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                const int e = hm ? (__ffsll((long long)hm) - 1) : n;
+                const float mult = (float)(e - b);
+                const uint32_t cc = __shfl(code, b);
+                const float4 *row = (const float4 *)(tokens + ((int64_t)(cc >> 16) * g2 + (cc & 0xffffu)) * D);
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int v = lane + 64 * t;
+                    if (v < D4) {
+                        const float4 xv = row[v];
+                        if (MODE == BSC_MODE_MAX) {
+                            a[t].x = fmaxf(a[t].x, xv.x); a[t].y = fmaxf(a[t].y, xv.y);
+                            a[t].z = fmaxf(a[t].z, xv.z); a[t].w = fmaxf(a[t].w, xv.w);
+                        } else {
+                            a[t].x = fmaf(mult, xv.x, a[t].x); a[t].y = fmaf(mult, xv.y, a[t].y);
+                            a[t].z = fmaf(mult, xv.z, a[t].z); a[t].w = fmaf(mult, xv.w, a[t].w);
+                        }
+                    }
+                }
+            }
+            count += n;
+            if (n < 64) break;
+        }
+        const bool is_new = (int64_t)vid >= max_id_prev;
+        float4 *dst = (float4 *)(acc + (int64_t)vid * D);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            if (v < D4) {
+                float4 o = a[t];
+                if (!is_new) {
+                    const float4 old = dst[v];
+                    if (MODE == BSC_MODE_MAX) {
+                        o.x = fmaxf(o.x, old.x); o.y = fmaxf(o.y, old.y); o.z = fmaxf(o.z, old.z); o.w = fmaxf(o.w, old.w);
+                    } else {
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                }
+                dst[v] = o;
+            }
+        }
+        if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + count;
+    }
+}
+
+__global__ void k_rmw_count(int64_t *dscal)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) dscal[DS_RMW_TOTAL] += dscal[DS_B_NSEG];
+}
+
+// exact mode, memory_2.py:882-886: rows [row0, row0+n) of the token cache <- passing points [q0, q0+n)
+__global__ __launch_bounds__(TPB) void k_append(const int32_t *__restrict__ pass_list, int64_t q0, int64_t n,
+                                                int64_t row0, const int32_t *__restrict__ p_cell,
+                                                const uint32_t *__restrict__ p_patf, const float *__restrict__ p_r2f,
+                                                const float *__restrict__ tokens, int g2, int D, int gs, int nh,
+                                                float *__restrict__ cache_f, int32_t *__restrict__ cache_pos,
+                                                float *__restrict__ cache_d)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (w >= n) return;
+    const int32_t j = pass_list[q0 + w];
+    const uint32_t cc = p_patf[j];
+    const float4 *src = (const float4 *)(tokens + ((int64_t)(cc >> 16) * g2 + (cc & 0xffffu)) * D);
+    float4 *dst = (float4 *)(cache_f + (row0 + w) * D);
+    for (int v = lane; v < (D >> 2); v += 64) dst[v] = src[v];
+    if (lane == 0) {
+        const int32_t c = p_cell[j];
+        const int32_t h = c % nh, rc = c / nh;
+        cache_pos[3 * (row0 + w) + 0] = rc / gs;
+        cache_pos[3 * (row0 + w) + 1] = rc % gs;
+        cache_pos[3 * (row0 + w) + 2] = h;
+        cache_d[row0 + w] = p_r2f[j];
+    }
+}
+
+// debug / parity entry: full geometry of one frame's points
+__global__ __launch_bounds__(TPB) void k_geometry_debug(GeomConst gc, const float *depth, const int32_t *idx,
+                                                        const double *T, int64_t P, uint8_t *flags, double *pc,
+                                                        double *pg, int32_t *vox, int32_t *pix, int32_t *pat, double *r2,
+                                                        double *alpha)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= P) return;
+    const int32_t i = idx ? idx[j] : (int32_t)j;
+    GeomOut o;
+    memset(&o, 0, sizeof o);
+    geom_point(gc, i, depth[i], T, o, true);
+    flags[j] = (uint8_t)o.flags;
+    for (int k = 0; k < 3; ++k) { pc[3 * j + k] = o.pc[k]; pg[3 * j + k] = o.pg[k]; vox[3 * j + k] = o.vox[k]; }
+    for (int k = 0; k < 2; ++k) { pix[2 * j + k] = o.pix[k]; pat[2 * j + k] = o.pat[k]; }
+    r2[j] = o.r2;
+    alpha[j] = o.alpha;
+}
+
+bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *idx, int64_t P, uint8_t *flags,
+                                 double *pc, double *pg, int32_t *vox, int32_t *pix, int32_t *pat, double *r2,
+                                 double *alpha)
+{
+    GeomConst gc = make_geom_const(x);
+    hipLaunchKernelGGL(k_geometry_debug, dim3((unsigned)((P + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, gc, depth, idx,
+                       x->d_transforms, P, flags, pc, pg, vox, pix, pat, r2, alpha);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+template <int MODE>
+static void launch_dense(bsc_ctx *x, int64_t P, const float *tokens)
+{
+    const int D = x->c.token_dim;
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid(256 * 8), block(TPB);
+#define LD(NV)                                                                                                        \
+    hipLaunchKernelGGL((k_dense_reduce<NV, MODE>), grid, block, 0, x->stream, x->keys_b, P, x->seg_start, x->dscal,   \
+                       x->p_patf, tokens, x->g2, D, x->acc, x->acnt)
+    if (nv <= 1) LD(1);
+    else if (nv == 2) LD(2);
+    else if (nv == 3) LD(3);
+    else if (nv == 4) LD(4);
+    else LD(8);
+#undef LD
+}
+
+bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
+                        const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
+                        bsc_draw_fn draw, void *user)
+{
+    const int64_t N = (int64_t)x->c.height * x->c.width;
+    const int64_t P = idx ? offsets_host[n_frames] : (int64_t)n_frames * N;
+    if (P > x->c.max_points) {
+        bsc_set_error("bsc_ingest: %lld points exceed max_points=%d", (long long)P, x->c.max_points);
+        return BSC_E_CAPACITY;
+    }
+    if (P == 0) return BSC_OK;
+    const dim3 block(TPB), grid((unsigned)((P + TPB - 1) / TPB));
+    hipStream_t s = x->stream;
+    if (idx)
+        BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
+    GeomConst gc = make_geom_const(x);
+    hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
+                       alpha, P, x->occ, x->p_cell, x->p_patf, x->p_rgbv, x->p_r2f, x->p_alpha);
+    hipLaunchKernelGGL(k_flags, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
+    BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)P));
+    hipLaunchKernelGGL(k_assign, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->p_scan_out, x->dscal,
+                       x->c.voxel_capacity, x->c.grid_size, x->nh, x->rgb_pos, x->pass_list);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity);
+    hipLaunchKernelGGL(k_keys, grid, block, 0, s, P, x->p_cell, x->occ, x->keys_a, x->hmap, x->nh, x->order_base);
+    hipLaunchKernelGGL(k_hwin, grid, block, 0, s, P, x->p_cell, x->occ, x->hmap, x->p_rgbv, x->cv_map, x->nh,
+                       x->order_base);
+    const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
+    BSC_TRY(prim_sort_keys(x, x->keys_a, x->keys_b, (size_t)P, 0, 32 + vid_bits));
+    hipLaunchKernelGGL(k_chain, grid, block, 0, s, P, x->keys_b, x->dscal, x->p_rgbv, x->p_alpha, x->rgb, x->weight,
+                       x->seg_start, x->dscal);
+    if (x->c.mode != BSC_MODE_EXACT) {
+        if (x->timing) BSC_HIP(hipEventRecord(x->ev0, s));
+        if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, P, tokens);
+        else launch_dense<BSC_MODE_MAX>(x, P, tokens);
+        if (x->timing) BSC_HIP(hipEventRecord(x->ev1, s));
+        hipLaunchKernelGGL(k_rmw_count, dim3(1), dim3(64), 0, s, x->dscal);
+    }
+    BSC_HIP(hipGetLastError());
+    x->order_base += P;
+    if (x->c.mode == BSC_MODE_EXACT) {
+        // memory_2.py:880-886: rows fill the cache in order; the point that finds it full triggers the
+        // flush and loses its own token.
+        BSC_TRY(read_scalars(x));
+        if (x->hscal[DS_ERROR]) {
+            bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
+            return BSC_E_CAPACITY;
+        }
+        int64_t remaining = x->hscal[DS_B_NPASS], q = 0;
+        while (remaining > 0) {
+            const int64_t room = x->c.iter_size - x->iter_id;
+            const int64_t n = remaining < room ? remaining : room;
+            if (n > 0) {
+                hipLaunchKernelGGL(k_append, dim3((unsigned)((n * 64 + TPB - 1) / TPB)), block, 0, s, x->pass_list, q, n,
+                                   x->iter_id, x->p_cell, x->p_patf, x->p_r2f, tokens, x->g2, x->c.token_dim,
+                                   x->c.grid_size, x->nh, x->cache_f, x->cache_pos, x->cache_d);
+                BSC_HIP(hipGetLastError());
+                x->iter_id += n; q += n; remaining -= n;
+            }
+            if (remaining > 0) {        // next passing point meets a full cache
+                BSC_TRY(flush_cache(x, draw, user));
+                q += 1; remaining -= 1;
+            }
+        }
+    }
+    return BSC_OK;
+}

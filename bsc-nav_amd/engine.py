@@ -1,0 +1,215 @@
+"""VoxelEngine — thin Python handle on one libbscnav context (one GPU).
+
+All arithmetic of the path runs in the HIP library; this class only marshals torch device tensors
+(raw data_ptr) and NumPy host buffers across the C-ABI of include/bscnav.h.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from .geometry import cam_mat_fov, cam_mat_patch
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class VoxelEngine:
+    def __init__(self, height, width, grid_size, cell_size, floor_height, map_height, patch_grid, token_dim,
+                 mode="exact", iter_size=50000, cache_size=10, voxel_capacity=None, token_capacity=None,
+                 max_points=None, device=0, fov=90, min_depth=0.1, max_depth=10, min_h=None, max_h=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bsc_nav_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path")
+        self.lib = _lib.load()
+        c = _lib.BscConfig()
+        c.height, c.width, c.grid_size = int(height), int(width), int(grid_size)
+        c.max_h = int(map_height / cell_size) if max_h is None else int(max_h)      # memory_2.py:122
+        c.min_h = int(floor_height / cell_size) if min_h is None else int(min_h)    # memory_2.py:123
+        c.patch_grid, c.token_dim = int(patch_grid), int(token_dim)
+        c.iter_size, c.cache_size, c.mode = int(iter_size), int(cache_size), _lib.MODES[mode]
+        c.voxel_capacity = int(voxel_capacity or int(grid_size) * int(grid_size))   # memory_2.py:715
+        c.max_points = int(max_points or height * width)
+        c.token_capacity = int(token_capacity or (c.voxel_capacity * 2 + iter_size)) if mode == "exact" else 0
+        c.cell_size, c.min_depth, c.max_depth = float(cell_size), float(min_depth), float(max_depth)
+        K = cam_mat_fov(height, width, fov)
+        c.K[:] = K.flatten()
+        c.Kinv[:] = np.linalg.inv(K).flatten()              # utils.py:164
+        c.Kpatch[:] = cam_mat_patch(patch_grid, patch_grid).flatten()
+        self.cfg = c
+        self.mode = mode
+        self.device = torch.device("cuda", device)
+        self.nh = c.max_h - c.min_h
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _lib.check(self.lib.bsc_create(C.byref(c), device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self._draw = _lib.DRAW_FN(self._draw_cb)
+
+    # memory_2.py:352 — Python's global RNG, one draw per row that meets a full voxel
+    def _draw_cb(self, user, n, out):
+        k = self.cfg.cache_size
+        for i in range(n):
+            out[i] = random.choice(range(k))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bsc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _lib.check(self.lib.bsc_reset(self.h))
+
+    def ingest(self, depth, rgb, tokens, transforms, sample_idx=None, offsets=None, alpha=None):
+        """depth (F,H,W) f32, rgb (F,H,W,C) u8, tokens (F,g,g,D) f32: contiguous CUDA tensors.
+        transforms (F,4,4) float64 NumPy.  sample_idx int32 CUDA + offsets (F+1) int64 NumPy, or None."""
+        F = depth.shape[0] if depth.dim() == 3 else 1
+        assert depth.is_cuda and rgb.is_cuda and tokens.is_cuda
+        assert depth.dtype == torch.float32 and rgb.dtype == torch.uint8 and tokens.dtype == torch.float32
+        assert depth.is_contiguous() and rgb.is_contiguous() and tokens.is_contiguous()
+        T = np.ascontiguousarray(np.asarray(transforms, dtype=np.float64).reshape(F, 16))
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        if sample_idx is not None:
+            assert sample_idx.is_cuda and sample_idx.dtype == torch.int32 and off is not None and len(off) == F + 1
+        if alpha is not None:
+            assert alpha.is_cuda and alpha.dtype == torch.float64
+        _lib.check(self.lib.bsc_ingest(self.h, F, _dp(depth), _dp(rgb), rgb.shape[-1], _dp(tokens), _hp(T),
+                                       _dp(sample_idx), _hp(off), _dp(alpha), self._draw, None))
+
+    def flush(self):
+        _lib.check(self.lib.bsc_flush(self.h, self._draw, None))
+
+    def counters(self):
+        out = np.zeros(8, np.int64)
+        _lib.check(self.lib.bsc_counters(self.h, _hp(out)))
+        keys = ["max_id", "iter_id", "store_voxels", "store_tokens", "flushes", "points_passed", "points_seen",
+                "voxel_rmw"]
+        return {k: int(v) for k, v in zip(keys, out)}
+
+    def geometry(self, depth, transform, sample_idx=None):
+        P = depth.numel() if sample_idx is None else sample_idx.numel()
+        o = dict(flags=np.zeros(P, np.uint8), pc=np.zeros((P, 3)), pg=np.zeros((P, 3)), vox=np.zeros((P, 3), np.int32),
+                 pix=np.zeros((P, 2), np.int32), pat=np.zeros((P, 2), np.int32), r2=np.zeros(P), alpha=np.zeros(P))
+        T = np.ascontiguousarray(np.asarray(transform, np.float64).reshape(16))
+        _lib.check(self.lib.bsc_geometry(self.h, _dp(depth), _hp(T), _dp(sample_idx), P, _hp(o["flags"]), _hp(o["pc"]),
+                                         _hp(o["pg"]), _hp(o["vox"]), _hp(o["pix"]), _hp(o["pat"]), _hp(o["r2"]),
+                                         _hp(o["alpha"])))
+        return o
+
+    # ---- exports / imports -------------------------------------------------------------------
+    def export_rgb(self):
+        n = self.counters()["max_id"]
+        pos, rgb, w = np.zeros((n, 3), np.int32), np.zeros((n, 3), np.uint8), np.zeros(n, np.float32)
+        _lib.check(self.lib.bsc_export_rgb(self.h, _hp(pos), _hp(rgb), _hp(w)))
+        return pos, rgb, w
+
+    def export_occupied(self):
+        occ = np.zeros((self.cfg.grid_size, self.cfg.grid_size, self.nh), np.int32)
+        _lib.check(self.lib.bsc_export_occupied(self.h, _hp(occ)))
+        return occ
+
+    def export_heightmap(self):
+        gs = self.cfg.grid_size
+        mh, cv = np.zeros((gs, gs), np.float64), np.zeros((gs, gs, 3), np.uint8)
+        _lib.check(self.lib.bsc_export_heightmap(self.h, _hp(mh), _hp(cv)))
+        return mh, cv
+
+    def export_cache(self):
+        n = self.counters()["iter_id"]
+        f, p, d = np.zeros((n, self.cfg.token_dim), np.float32), np.zeros((n, 3), np.int32), np.zeros(n, np.float32)
+        _lib.check(self.lib.bsc_export_cache(self.h, _hp(f), _hp(p), _hp(d)))
+        return f, p, d
+
+    def export_store(self):
+        c = self.counters()
+        V, T = c["store_voxels"], c["store_tokens"]
+        pos, cnt = np.zeros((V, 3), np.int32), np.zeros(V, np.int32)
+        feats, dists = np.zeros((T, self.cfg.token_dim), np.float32), np.zeros(T, np.float32)
+        _lib.check(self.lib.bsc_export_store(self.h, _hp(pos), _hp(cnt), _hp(feats), _hp(dists)))
+        return pos, cnt, feats, dists
+
+    def export_dense(self):
+        n = self.counters()["max_id"]
+        acc, cnt = np.zeros((n, self.cfg.token_dim), np.float32), np.zeros(n, np.int32)
+        _lib.check(self.lib.bsc_export_dense(self.h, _hp(acc), _hp(cnt)))
+        return acc, cnt
+
+    def import_rgb(self, pos, rgb, weight):
+        pos = np.ascontiguousarray(pos, np.int32)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float32)
+        _lib.check(self.lib.bsc_import_rgb(self.h, len(pos), _hp(pos), _hp(rgb), _hp(weight)))
+
+    def import_store(self, pos, cnt, feats, dists):
+        pos = np.ascontiguousarray(pos, np.int32)
+        cnt = np.ascontiguousarray(cnt, np.int32)
+        feats = np.ascontiguousarray(feats, np.float32)
+        dists = np.ascontiguousarray(dists, np.float32)
+        _lib.check(self.lib.bsc_import_store(self.h, len(pos), len(feats), _hp(pos), _hp(cnt), _hp(feats), _hp(dists)))
+
+    def import_dense(self, acc, cnt):
+        acc = np.ascontiguousarray(acc, np.float32)
+        cnt = np.ascontiguousarray(cnt, np.int32)
+        _lib.check(self.lib.bsc_import_dense(self.h, len(cnt), _hp(acc), _hp(cnt)))
+
+    # ---- query ------------------------------------------------------------------------------------
+    def pool_query(self, tokens):
+        """tokens (B,T,D) f32 CUDA -> (D) f32 CUDA   (memory_2.py:591-608)"""
+        assert tokens.is_cuda and tokens.dtype == torch.float32 and tokens.is_contiguous()
+        B, T, D = tokens.shape
+        out = torch.empty(D, dtype=torch.float32, device=tokens.device)
+        _lib.check(self.lib.bsc_pool_query(self.h, _dp(tokens), B, T, D, _dp(out)))
+        return out
+
+    def localize(self, q, K=100, radius=None, curr=None, floor=None):
+        """q (Q,D) or (D) f32 CUDA -> (pos (Q,n,3) int32, sim (Q,n) f32, counts)."""
+        q = q.reshape(-1, self.cfg.token_dim).contiguous()
+        assert q.is_cuda and q.dtype == torch.float32
+        Q = q.shape[0]
+        pos, sim, cnt = np.zeros((Q, K, 3), np.int32), np.zeros((Q, K), np.float32), np.zeros(Q, np.int32)
+        curr_a = None if curr is None else np.ascontiguousarray(curr, np.int32)
+        lo, hi = (0, -1) if floor is None else (int(floor[0]), int(floor[1]))
+        _lib.check(self.lib.bsc_localize(self.h, _dp(q), Q, K, -1.0 if radius is None else float(radius), _hp(curr_a),
+                                         lo, hi, _hp(pos), _hp(sim), _hp(cnt)))
+        return pos, sim, cnt
+
+    def last_kernel_stats(self, which=0):
+        out = np.zeros(2, np.float64)
+        _lib.check(self.lib.bsc_last_kernel_stats(self.h, which, _hp(out)))
+        return float(out[0]), float(out[1])
+
+    # ---- multi-GPU helpers --------------------------------------------------------------------------
+    def keys_tensor(self):
+        """(max_id,3) int32 CUDA view of the voxel keys in id order (copy)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.bsc_keys_dev(self.h, C.byref(ptr), C.byref(n)))
+        out = torch.empty((n.value, 3), dtype=torch.int32, device=self.device)
+        if n.value:
+            pos, _, _ = self.export_rgb()
+            out.copy_(torch.from_numpy(pos))
+        return out
+
+    def dense_gather(self, keys):
+        keys = keys.contiguous()
+        n = keys.shape[0]
+        acc = torch.empty((n, self.cfg.token_dim), dtype=torch.float32, device=self.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.bsc_dense_gather(self.h, n, _dp(keys), _dp(acc), _dp(cnt)))
+        return acc, cnt
+
+    def dense_replace(self, keys, acc, cnt):
+        _lib.check(self.lib.bsc_dense_replace(self.h, keys.shape[0], _dp(keys.contiguous()), _dp(acc.contiguous()),
+                                              _dp(cnt.contiguous())))

@@ -1,0 +1,72 @@
+"""Host-side geometry of the memory path: intrinsics, pose chain, point sub-sampling.
+
+These few 3x3 / 4x4 operations per frame stay on the host in NumPy / SciPy, exactly as the
+reference evaluates them, so that the matrices handed to the kernels are bit-identical to the
+reference's:
+  cam_mat_fov      utils.py:181-186   cam_mat_patch  utils.py:144-150
+  pose_vec2tf      utils.py:133-141   PoseChain      memory_2.py:844-851,860
+  sample_indices   memory_2.py:747-749 (global NumPy RNG, Fisher-Yates over all N pixels)
+"""
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+
+def cam_mat_fov(h, w, fov=90):
+    m = np.eye(3)
+    m[0, 0] = m[1, 1] = w / (2.0 * np.tan(np.deg2rad(fov / 2)))   # both focal lengths from the WIDTH
+    m[0, 2] = w / 2.0
+    m[1, 2] = h / 2.0
+    return m
+
+
+def cam_mat_patch(h, w):
+    m = np.eye(3)
+    m[0, 0] = m[1, 1] = w / 2.0
+    m[0, 2] = w / 2.0
+    m[1, 2] = h / 2.0
+    return m
+
+
+def pose_vec2tf(pose):
+    """(px, py, pz, qx, qy, qz, qw) -> 4x4."""
+    pose = np.asarray(pose, dtype=np.float64)
+    tf = np.eye(4)
+    tf[:3, 3] = pose[:3].flatten()
+    tf[:3, :3] = R.from_quat(pose[3:].flatten()).as_matrix()
+    return tf
+
+
+class PoseChain:
+    """pc_transform = inv(B T0 B^-1) (B T B^-1) B base2cam; the map frame is the first ingested pose."""
+
+    def __init__(self, base_forward_axis=(0, 0, -1), base_left_axis=(-1, 0, 0), base_up_axis=(0, 1, 0),
+                 base2cam_rot=(1, 0, 0, 0, -1, 0, 0, 0, -1), sensor_height=1.5):
+        self.base_transform = np.eye(4)
+        self.base_transform[0, :3] = base_forward_axis
+        self.base_transform[1, :3] = base_left_axis
+        self.base_transform[2, :3] = base_up_axis
+        self.base2cam_tf = np.eye(4)
+        self.base2cam_tf[:3, :3] = np.array([base2cam_rot]).reshape((3, 3))
+        self.base2cam_tf[1, 3] = sensor_height
+        self.inv_init_base_tf = None
+        self.init_base_tf = None
+        self.tf = None
+
+    def reset(self):
+        self.inv_init_base_tf = None
+
+    def pc_transform(self, pose):
+        B = self.base_transform
+        if self.inv_init_base_tf is None:
+            self.init_base_tf = B @ pose_vec2tf(pose) @ np.linalg.inv(B)
+            self.inv_init_base_tf = np.linalg.inv(self.init_base_tf)
+        base_pose = B @ pose_vec2tf(pose) @ np.linalg.inv(B)
+        self.tf = self.inv_init_base_tf @ base_pose
+        return np.ascontiguousarray(self.tf @ B @ self.base2cam_tf)
+
+
+def sample_indices(n_pixels, rate):
+    """The reference's shuffled sub-sampling; consumes np.random's global stream identically."""
+    idx = np.arange(n_pixels)
+    np.random.shuffle(idx)
+    return np.ascontiguousarray(idx[::rate].astype(np.int32))

@@ -1,0 +1,146 @@
+/*
+ * bscnav.h — C-ABI of libbscnav.so, the MI355X (gfx950) implementation of BSC-Nav's
+ * structured-spatial-memory construction and query path.
+ *
+ * The reference (Heathcliff-saku/BSC-Nav) has no native code and no FFI: its boundary for
+ * this path is the Python class VoxelTokenMemory (memory_2.py:38).  The entry points below
+ * are what a ctypes binding inside that class binds instead of the per-point Python loops;
+ * each one cites the reference lines it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns a bsc_status
+ *     (0 = ok, negative = error) and bsc_last_error() returns a thread-local message.
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g. torch tensors);
+ *     "host" pointers are ordinary host memory.  The library owns only the state inside
+ *     bsc_ctx and copies in/out through the export/import calls.
+ *   - one bsc_ctx per GPU; a ctx is not thread-safe; calls are ordered on the stream given
+ *     at creation (pass the caller's hipStream_t, or NULL for the default stream).
+ *   - there is NO CPU fallback: bsc_create fails when no gfx950 device is present.
+ */
+#ifndef BSCNAV_H
+#define BSCNAV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t bsc_status;
+#define BSC_OK 0
+#define BSC_E_INVALID (-1)   /* bad argument / configuration                       */
+#define BSC_E_CAPACITY (-2)  /* voxel or token capacity exceeded (memory_2.py:715 overflows silently) */
+#define BSC_E_HIP (-3)       /* HIP runtime error                                   */
+#define BSC_E_STATE (-4)     /* call not valid in the ctx's feature mode            */
+
+/* feature modes */
+#define BSC_MODE_EXACT 0     /* reference semantics: token cache + <=cache_size tokens per voxel */
+#define BSC_MODE_MEAN 1      /* dense reduce: per-voxel sum + count (north-star mode)             */
+#define BSC_MODE_MAX 2       /* dense reduce: per-voxel element-wise max                          */
+
+typedef struct bsc_config {
+    int32_t height, width;       /* frame H, W (args.py:27-28)                                  */
+    int32_t grid_size;           /* gs (args.py:58)                                             */
+    int32_t min_h, max_h;        /* int(floor_height/cs), int(map_height/cs) (memory_2.py:122-123) */
+    int32_t patch_grid;          /* g, tokens per side (memory_2.py:80-83)                      */
+    int32_t token_dim;           /* D (memory_2.py:107)                                         */
+    int32_t iter_size;           /* token-cache rows (memory_2.py:109)                          */
+    int32_t cache_size;          /* tokens per voxel (memory_2.py:111)                          */
+    int32_t mode;                /* BSC_MODE_*                                                  */
+    int32_t voxel_capacity;      /* rows of grid_rgb/weight/... (reference: gs*gs, memory_2.py:715) */
+    int32_t max_points;          /* largest number of points one bsc_ingest call may carry      */
+    int64_t token_capacity;      /* rows of the per-voxel token pool (exact mode)               */
+    double cell_size;            /* cs (args.py:57)                                             */
+    double min_depth, max_depth; /* strict bounds (utils.py:175-177)                            */
+    double K[9];                 /* calib_mat, row-major (utils.py:181-186)                     */
+    double Kinv[9];              /* np.linalg.inv(calib_mat) (utils.py:164)                     */
+    double Kpatch[9];            /* patch-grid intrinsics (utils.py:144-150)                    */
+} bsc_config;
+
+typedef struct bsc_ctx bsc_ctx;
+
+/* Replacement-index source for full voxels: fill out[0..n) with draws in [0, cache_size)
+ * in the order the reference would call random.choice(range(cache_size)) (memory_2.py:352). */
+typedef void (*bsc_draw_fn)(void *user, uint32_t n, uint32_t *out);
+
+const char *bsc_last_error(void);
+const char *bsc_version(void);
+
+/* VoxelTokenMemory.__init__/_init_cache (memory_2.py:39,708-722): allocate all state in HBM. */
+bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hip_stream, bsc_ctx **out);
+void bsc_destroy(bsc_ctx *ctx);
+/* _init_cache again (load_memory, memory_2.py:172-184) */
+bsc_status bsc_reset(bsc_ctx *ctx);
+
+/* obs2voxeltoken's per-point loop (memory_2.py:859-903) for a batch of n_frames frames.
+ *   depth_dev   (n_frames,H,W) f32          rgb_dev (n_frames,H,W,rgb_channels) u8
+ *   tokens_dev  (n_frames,g,g,D) f32        transforms_host (n_frames,16) f64 = pc_transform (memory_2.py:860)
+ *   sample_idx_dev  int32 pixel indices, frame f owns [offsets_host[f], offsets_host[f+1]) in the
+ *                   reference's shuffled order (memory_2.py:747-749); NULL = every pixel, row-major
+ *   alpha_dev   optional f64 per point (same indexing as sample_idx): host-computed
+ *               exp(-r2/1.2) (memory_2.py:873-875); NULL = computed on the device
+ * Frame order and point order inside the call define the sequential semantics (first-touch ids,
+ * rgb running mean, top-down map ties, token-cache order).  In exact mode draw() is called when a
+ * token-cache flush meets full voxels. */
+bsc_status bsc_ingest(bsc_ctx *ctx, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
+                      int32_t rgb_channels, const float *tokens_dev, const double *transforms_host,
+                      const int32_t *sample_idx_dev, const int64_t *offsets_host, const double *alpha_dev,
+                      bsc_draw_fn draw, void *user);
+
+/* update_memory_dist_base (memory_2.py:326-358): all iter_size rows incl. the zero rows. */
+bsc_status bsc_flush(bsc_ctx *ctx, bsc_draw_fn draw, void *user);
+
+/* counters (host sync): out[0]=max_id out[1]=iter_id out[2]=store voxels out[3]=store tokens
+ * out[4]=flushes out[5]=points passed so far out[6]=points seen so far out[7]=voxel-row RMWs (dense) */
+bsc_status bsc_counters(bsc_ctx *ctx, int64_t *out8_host);
+
+/* geometry only (utils.py:153-214, memory_2.py:864-875) for one frame, outputs to host; NULL skips.
+ * vox is row,col,h before the -min_h shift; flags bit0 depth-valid, bit1 in-range, bit2 patch-in-range */
+bsc_status bsc_geometry(bsc_ctx *ctx, const float *depth_dev, const double *transform_host,
+                        const int32_t *sample_idx_dev, int64_t n_points, uint8_t *flags_host, double *pc_host,
+                        double *pg_host, int32_t *vox_host, int32_t *pix_host, int32_t *pat_host,
+                        double *r2_host, double *alpha_host);
+
+/* on-disk layout exchange (memory_2.py:1136-1145 save, :189-200 load); host buffers sized from bsc_counters */
+bsc_status bsc_export_rgb(bsc_ctx *ctx, int32_t *pos_host, uint8_t *rgb_host, float *weight_host);
+bsc_status bsc_export_occupied(bsc_ctx *ctx, int32_t *occ_host /* (gs,gs,max_h-min_h) */);
+bsc_status bsc_export_heightmap(bsc_ctx *ctx, double *max_height_host, uint8_t *cv_map_host);
+bsc_status bsc_export_cache(bsc_ctx *ctx, float *feat_host, int32_t *pos_host, float *dis_host);
+/* feature store in HDF5 name order: pos (V,3), cnt (V), feats (T,D), dists (T)  (feat.h5df, memory_2.py:330-354) */
+bsc_status bsc_export_store(bsc_ctx *ctx, int32_t *pos_host, int32_t *cnt_host, float *feats_host, float *dists_host);
+/* dense modes: accumulator rows in voxel-id order: acc (max_id,D) sum-or-max, cnt (max_id) */
+bsc_status bsc_export_dense(bsc_ctx *ctx, float *acc_host, int32_t *cnt_host);
+bsc_status bsc_import_rgb(bsc_ctx *ctx, int64_t max_id, const int32_t *pos_host, const uint8_t *rgb_host,
+                          const float *weight_host);
+bsc_status bsc_import_store(bsc_ctx *ctx, int64_t n_voxels, int64_t n_tokens, const int32_t *pos_host,
+                            const int32_t *cnt_host, const float *feats_host, const float *dists_host);
+bsc_status bsc_import_dense(bsc_ctx *ctx, int64_t max_id, const float *acc_host, const int32_t *cnt_host);
+
+/* voxel_localized, query pooling (memory_2.py:591-608): tokens_dev (B,T,D) -> out_dev (D) */
+bsc_status bsc_pool_query(bsc_ctx *ctx, const float *tokens_dev, int32_t B, int32_t T, int32_t D, float *out_dev);
+
+/* voxel_localized scan (memory_2.py:623-671) for n_queries pooled queries q_dev (Q,D):
+ * cosine vs every stored token, per-voxel max, stable top-K in HDF5 name order.
+ * radius<0 disables the sphere filter (:624-629); floor_lo>floor_hi disables the floor filter (:633-640).
+ * out_pos_host (Q,K,3) i32, out_sim_host (Q,K) f32, out_count_host (Q) = rows actually written. */
+bsc_status bsc_localize(bsc_ctx *ctx, const float *q_dev, int32_t n_queries, int32_t K, double radius,
+                        const int32_t *curr_host, int32_t floor_lo, int32_t floor_hi, int32_t *out_pos_host,
+                        float *out_sim_host, int32_t *out_count_host);
+
+/* multi-GPU merge helpers (dense modes).  The library never calls RCCL: the host
+ * moves the buffers with torch.distributed and hands them back.
+ *   bsc_dense_gather : rows of the local map for the given voxel keys -> acc_dev (n,D), cnt_dev (n);
+ *                      keys this rank never touched give zeros (mean) / -inf (max) and count 0
+ *   bsc_dense_replace: replace the whole map by n merged voxels (keys, acc, cnt) in the given order */
+bsc_status bsc_dense_gather(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev /* (n,3) */, float *acc_dev, int32_t *cnt_dev);
+bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, const float *acc_dev, const int32_t *cnt_dev);
+/* device views for the host-side collective: voxel keys (max_id,3) i32 */
+bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
+
+/* timing of the last bsc_ingest / bsc_localize on the ctx stream, measured with HIP events
+ * around the dominant kernel (feature scatter / cosine scan): out[0]=ms, out[1]=algorithmic bytes */
+bsc_status bsc_last_kernel_stats(bsc_ctx *ctx, int32_t which /*0 ingest, 1 localize*/, double *out2_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

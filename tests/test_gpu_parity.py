@@ -1,0 +1,271 @@
+"""HIP path (through the C-ABI of libbscnav.so) against the golden vectors and the CPU oracle.
+
+Bit-exact: voxel indices, ids, counts, token-cache rows, rgb bytes, weights, top-down map, token store.
+Floating point (dense feature sums, similarities): tolerance written at each assert.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device (no CPU fallback exists)")
+    return torch
+
+
+def _engine(cfg, mode="exact", **kw):
+    import bsc_nav_amd as B
+    return B.VoxelEngine(cfg["H"], cfg["W"], cfg["gs"], cfg["cs"], cfg["floor_height"], cfg["map_height"], cfg["g"],
+                         cfg["D"], mode=mode, iter_size=cfg.get("iter_size", 50000), **kw)
+
+
+def _oracle(cfg, mode=0):
+    from oracle import oracle as orc
+    c = orc.make_config(cfg["H"], cfg["W"], cfg["gs"], cfg["cs"], cfg["floor_height"], cfg["map_height"], cfg["g"],
+                        cfg["D"], iter_size=cfg.get("iter_size", 50000), mode=mode)
+    return orc, c, orc.OracleMemory(c)
+
+
+@pytest.mark.parametrize("name", gu.GEOMETRY_FIXTURES)
+def test_geometry_bit_exact(torch_cuda, name):
+    import synth
+    torch = torch_cuda
+    z = gu.load(name)
+    H, W = int(z["H"]), int(z["W"])
+    _, depth, poses = synth.make_frames(int(z["seed"]), 2, H, W, str(z["kind"]), start_yaw_steps=1)
+    assert synth.checksum(depth[1], poses) == str(z["input_sha"])
+    import bsc_nav_amd as B
+    eng = B.VoxelEngine(H, W, int(z["gs"]), float(z["cs"]), 0.0, 1.0, int(z["g"]), 8, mode="mean", voxel_capacity=16,
+                        min_h=int(z["minh"]), max_h=int(z["maxh"]))
+    d = torch.from_numpy(depth[1]).cuda()
+    idx = torch.from_numpy(z["pick"]).cuda()
+    o = eng.geometry(d, z["pc_tf"], idx)
+    m = z["mask"].astype(bool)
+    assert np.array_equal((o["flags"] & 1).astype(bool), m)
+    assert np.array_equal(o["pc"][m], z["pc"].T[m])
+    assert np.array_equal(o["pg"][m], z["pg"].T[m])
+    assert np.array_equal(o["vox"][m], z["vox"][m])
+    assert np.array_equal(o["pix"][m], z["pix"][m])
+    assert np.array_equal(o["pat"][m], z["pat"][m])
+    assert np.array_equal(o["r2"][m], z["r2"][m])
+    ulp = np.abs(o["alpha"][m] - z["alpha"][m]) / np.spacing(z["alpha"][m])
+    assert ulp.max() <= 1.0            # device exp vs NumPy exp: last-ulp only
+    eng.close()
+
+
+def _numpy_alpha(orc, c, depth, idx, T):
+    g = orc.geometry(c, depth, idx, T)
+    return np.array([np.exp(-r / (2 * 0.6)) for r in g["r2"]], dtype=np.float64)   # memory_2.py:873-875
+
+
+def _run_engine(torch, z, batched=False, alpha_mode="numpy"):
+    """Drive the HIP engine like obs2voxeltoken does, frame by frame (or all frames in one call)."""
+    import bsc_nav_amd as B
+    from oracle import oracle as orc
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    N = cfg["H"] * cfg["W"]
+    P_max = sum(len(range(0, N, cfg["s"])) for _ in range(cfg["F"]))
+    eng = _engine(cfg, max_points=max(P_max, N))
+    oc = orc.make_config(cfg["H"], cfg["W"], cfg["gs"], cfg["cs"], cfg["floor_height"], cfg["map_height"], cfg["g"],
+                         cfg["D"])
+    chain = B.PoseChain()
+    np.random.seed(cfg["seed"])
+    random.seed(cfg["seed"])
+    d_depth = torch.from_numpy(depth).cuda()
+    d_rgb = torch.from_numpy(rgb).cuda()
+    d_tok = torch.from_numpy(tokens).cuda()
+    Ts, idxs, alphas, per_frame = [], [], [], []
+    for f in range(cfg["F"]):
+        T = chain.pc_transform(poses[f])
+        idx = B.sample_indices(N, cfg["s"])
+        alpha = _numpy_alpha(orc, oc, depth[f], idx, T) if alpha_mode == "numpy" else None
+        if batched:
+            Ts.append(T); idxs.append(idx); alphas.append(alpha)
+            continue
+        eng.ingest(d_depth[f:f + 1], d_rgb[f:f + 1], d_tok[f:f + 1], T[None], torch.from_numpy(idx).cuda(),
+                   np.array([0, len(idx)]), None if alpha is None else torch.from_numpy(alpha).cuda())
+        k = eng.counters()
+        per_frame.append((k["iter_id"], k["max_id"]))
+    if batched:
+        off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])])
+        eng.ingest(d_depth, d_rgb, d_tok, np.stack(Ts), torch.from_numpy(np.concatenate(idxs)).cuda(), off,
+                   None if alpha_mode != "numpy" else torch.from_numpy(np.concatenate(alphas)).cuda())
+    return cfg, eng, np.array(per_frame, np.int64)
+
+
+def _assert_state_matches_golden(eng, z):
+    import synth
+    k = eng.counters()
+    assert k["max_id"] == int(z["max_id"]) and k["iter_id"] == int(z["iter_id"])
+    f, p, d = eng.export_cache()
+    assert np.array_equal(p, z["cache_pos"])
+    assert np.array_equal(f[:, 0].astype(np.int32), z["cache_src"])
+    assert np.array_equal(d, z["cache_dis"])
+    assert synth.checksum(f) == str(z["cache_sha"])
+    pos, rgb, w = eng.export_rgb()
+    assert np.array_equal(pos, z["grid_rgb_pos"])
+    assert np.array_equal(rgb, z["grid_rgb"])
+    assert np.array_equal(w, z["weight"])
+    occ = eng.export_occupied()
+    assert int((occ >= 0).sum()) == int(z["occ_nnz"])
+    assert np.array_equal(occ[pos[:, 0], pos[:, 1], pos[:, 2]], np.arange(len(pos)))
+    mh, cv = eng.export_heightmap()
+    rc = np.argwhere(np.isfinite(mh)).astype(np.int32)
+    assert np.array_equal(rc, z["map_rc"])
+    assert np.array_equal(mh[rc[:, 0], rc[:, 1]].astype(np.int32), z["map_h"])
+    assert np.array_equal(cv[rc[:, 0], rc[:, 1]], z["map_rgb"])
+
+
+@pytest.mark.parametrize("name", gu.INGEST_FIXTURES)
+def test_ingest_exact_matches_reference(torch_cuda, name):
+    z = gu.load(name)
+    cfg, eng, per_frame = _run_engine(torch_cuda, z)
+    assert np.array_equal(per_frame, z["per_frame_iter_max"])
+    _assert_state_matches_golden(eng, z)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["g2_mini_s1", "g2_c1_s50_iid", "g3_flush_small_cache"])
+def test_ingest_one_batched_call_equals_frame_by_frame(torch_cuda, name):
+    z = gu.load(name)
+    cfg, eng, _ = _run_engine(torch_cuda, z, batched=True)
+    _assert_state_matches_golden(eng, z)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", gu.INGEST_FIXTURES)
+def test_flush_store_and_localize_match_reference(torch_cuda, name):
+    import synth
+    torch = torch_cuda
+    z = gu.load(name)
+    cfg, eng, _ = _run_engine(torch, z)
+    eng.flush()
+    pos, cnt, feats, dists = eng.export_store()
+    assert np.array_equal(pos, z["store_pos"])
+    assert np.array_equal(cnt, z["store_cnt"])
+    assert np.array_equal(feats[:, 0].astype(np.int32), z["store_src"])
+    assert np.array_equal(dists, z["store_dis"])
+    assert synth.checksum(feats) == str(z["store_sha"])
+    for q in gu.query_specs(z):
+        qtok = gu.query_tokens(q, cfg["seed"], cfg["D"], feats)
+        pooled = eng.pool_query(torch.from_numpy(qtok).cuda())
+        # f32 pooling, different summation order than torch: 2e-6 relative
+        np.testing.assert_allclose(pooled.cpu().numpy(), q["pooled"].reshape(-1), rtol=2e-6, atol=2e-6)
+        p, s, n = eng.localize(torch.from_numpy(q["pooled"].reshape(1, -1)).cuda(), K=q["K"], radius=q["radius"],
+                               curr=q["curr"], floor=q["floor"])
+        assert n[0] == len(q["pos"])
+        gu.assert_topk_matches(p[0, :n[0]], s[0, :n[0]], q["pos"], q["sim"])   # scores within 2e-6 (bar: 1e-3)
+    eng.close()
+
+
+def test_store_roundtrip_import_export(torch_cuda):
+    torch = torch_cuda
+    z = gu.load("g2_mini_s7_yaw")
+    cfg, eng, _ = _run_engine(torch, z)
+    eng.flush()
+    rgbs = eng.export_rgb()
+    store = eng.export_store()
+    eng2 = _engine(cfg)
+    eng2.import_rgb(*rgbs)
+    eng2.import_store(*store)
+    for a, b in zip(eng2.export_store(), store):
+        assert np.array_equal(a, b)
+    for a, b in zip(eng2.export_rgb(), rgbs):
+        assert np.array_equal(a, b)
+    assert np.array_equal(eng2.export_occupied(), eng.export_occupied())
+    q = next(gu.query_specs(z))
+    qd = torch.from_numpy(q["pooled"].reshape(1, -1)).cuda()
+    p1, s1, _ = eng.localize(qd, K=q["K"])
+    p2, s2, _ = eng2.localize(qd, K=q["K"])
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+    eng.close(); eng2.close()
+
+
+def test_device_alpha_within_last_ulp_effects(torch_cuda):
+    """Without host alpha the device exp() may differ from NumPy's in the last ulp."""
+    z = gu.load("g2_mini_s1")
+    _, eng, _ = _run_engine(torch_cuda, z, alpha_mode="device")
+    pos, rgb, w = eng.export_rgb()
+    assert np.array_equal(pos, z["grid_rgb_pos"])
+    assert (rgb != z["grid_rgb"]).mean() < 1e-3
+    np.testing.assert_allclose(w, z["weight"], rtol=3e-7, atol=0)
+    eng.close()
+
+
+@pytest.mark.parametrize("mode,omode", [("mean", 1), ("max", 2)])
+@pytest.mark.parametrize("name", ["g2_mini_s1", "g2_c1_s50_iid"])
+def test_dense_modes_match_oracle(torch_cuda, name, mode, omode):
+    """North-star dense reduce: ids/positions/counts bit-exact, feature rows within 1e-3 (fp32 order)."""
+    import bsc_nav_amd as B
+    torch = torch_cuda
+    z = gu.load(name)
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    orc, oc, om = _oracle(cfg, omode)
+    N = cfg["H"] * cfg["W"]
+    eng = _engine(cfg, mode=mode, max_points=N * cfg["F"])
+    chain = B.PoseChain()
+    Ts = [chain.pc_transform(p) for p in poses]
+    for f in range(cfg["F"]):
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f])
+    half = cfg["F"] // 2          # two multi-frame batches, every pixel (sample rate 1, row-major order)
+    for a, b in ((0, half), (half, cfg["F"])):
+        eng.ingest(torch.from_numpy(depth[a:b]).cuda(), torch.from_numpy(rgb[a:b]).cuda(),
+                   torch.from_numpy(tokens[a:b]).cuda(), np.stack(Ts[a:b]))
+    acc, cnt = eng.export_dense()
+    oacc, ocnt = om.export_dense()
+    opos, orgb, ow = om.export_rgb()
+    pos, rgbv, w = eng.export_rgb()
+    assert np.array_equal(pos, opos)                 # first-touch ids bit-exact
+    assert np.array_equal(cnt, ocnt)                 # counts bit-exact
+    assert (rgbv != orgb).mean() < 1e-3              # device exp vs libm exp, last ulp
+    if mode == "max":
+        assert np.array_equal(acc, oacc)             # max is order independent: bit-exact
+    else:
+        np.testing.assert_allclose(acc, oacc, rtol=1e-3, atol=1e-3)
+        mean, omean = acc / cnt[:, None], oacc / ocnt[:, None]
+        np.testing.assert_allclose(mean, omean, rtol=1e-3, atol=1e-3)
+    # localize over the dense map
+    qtok = gu.synth.make_query_tokens(5, 1, 256, cfg["D"])
+    q = orc.pool_query(qtok)
+    p, s, n = eng.localize(torch.from_numpy(q.reshape(1, -1)).cuda(), K=50)
+    op, os_ = om.localize(q, K=50)
+    gu.assert_topk_matches(p[0, :n[0]], s[0, :n[0]], op, os_, tol=5e-6)
+    k = eng.counters()
+    assert k["points_seen"] == N * cfg["F"] and k["max_id"] == len(opos)
+    eng.close()
+
+
+def test_batched_queries_equal_single_queries(torch_cuda):
+    torch = torch_cuda
+    z = gu.load("g2_c1_s50_iid")
+    cfg, eng, _ = _run_engine(torch, z)
+    eng.flush()
+    rs = np.random.RandomState(3)
+    Q = rs.standard_normal((11, cfg["D"])).astype(np.float32)
+    pb, sb, nb = eng.localize(torch.from_numpy(Q).cuda(), K=30)
+    for i in range(len(Q)):
+        p1, s1, n1 = eng.localize(torch.from_numpy(Q[i:i + 1]).cuda(), K=30)
+        assert np.array_equal(pb[i], p1[0]) and np.array_equal(sb[i], s1[0]) and nb[i] == n1[0]
+    eng.close()
+
+
+def test_capacity_error_is_loud(torch_cuda):
+    import bsc_nav_amd as B
+    z = gu.load("g2_mini_s1")
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    eng = _engine(cfg, mode="mean", voxel_capacity=100)
+    T = B.PoseChain().pc_transform(poses[0])
+    torch = torch_cuda
+    eng.ingest(torch.from_numpy(depth[:1]).cuda(), torch.from_numpy(rgb[:1]).cuda(), torch.from_numpy(tokens[:1]).cuda(),
+               T[None])
+    with pytest.raises(B._lib.BscError):
+        eng.counters()
+    eng.close()
