@@ -27,11 +27,11 @@ def _engine(cfg, mode="exact", **kw):
                          cfg["D"], mode=mode, iter_size=cfg.get("iter_size", 50000), **kw)
 
 
-def _oracle(cfg, mode=0):
+def _oracle(cfg, mode=0, voxel_capacity=None):
     from oracle import oracle as orc
     c = orc.make_config(cfg["H"], cfg["W"], cfg["gs"], cfg["cs"], cfg["floor_height"], cfg["map_height"], cfg["g"],
                         cfg["D"], iter_size=cfg.get("iter_size", 50000), mode=mode)
-    return orc, c, orc.OracleMemory(c)
+    return orc, c, orc.OracleMemory(c, voxel_capacity)
 
 
 @pytest.mark.parametrize("name", gu.GEOMETRY_FIXTURES)
@@ -208,9 +208,10 @@ def test_dense_modes_match_oracle(torch_cuda, name, mode, omode):
     torch = torch_cuda
     z = gu.load(name)
     cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
-    orc, oc, om = _oracle(cfg, omode)
     N = cfg["H"] * cfg["W"]
-    eng = _engine(cfg, mode=mode, max_points=N * cfg["F"])
+    vcap = min(N * cfg["F"], cfg["gs"] * cfg["gs"] * 64)     # every pixel ingested: more voxels than gs*gs
+    orc, oc, om = _oracle(cfg, omode, vcap)
+    eng = _engine(cfg, mode=mode, max_points=N * cfg["F"], voxel_capacity=vcap)
     chain = B.PoseChain()
     Ts = [chain.pc_transform(p) for p in poses]
     for f in range(cfg["F"]):
