@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — RGB-D frames/s into the voxel feature memory (BASELINE.json metric), one rank per GPU.
+
+A step = one batch of synthetic 640x480 RGB-D frames through the hot path, inputs resident in HBM:
+    ViT-B/16 patch features (random weights, bf16 MFMA via PyTorch-ROCm)  ->  libbscnav bsc_ingest
+    (fp64 unprojection, first-touch voxel ids, rgb chain, top-down map, dense per-voxel feature reduce).
+Workload: BASELINE.json configs[1] — 640x480 frames, 768-D tokens (14x14 patch grid), 256^3 grid of 0.1 m
+cells, every pixel ingested (depth_sample_rate 1), "room" depth (camera random-walking inside an 8x3x6 m box).
+With N>1 ranks each rank ingests its own frame shard (weak scaling) and the per-rank maps are merged by one
+RCCL reduce-scatter at the end of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (k_dense_reduce, HBM
+bound): algorithmic bytes / HIP-event time measured live; `cpu_baseline` is the plain-C oracle (port of
+the reference loop) timed on this box's host cores over a bounded sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step (per rank)")
+    ap.add_argument("--kind", default="room", choices=["room", "iid"])
+    ap.add_argument("--mode", default="mean", choices=["mean", "max"])
+    ap.add_argument("--arch", default="vit_b16")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the encoder eagerly instead of a HIP graph")
+    ap.add_argument("--localize", action="store_true", help="also time localize top-K (reported in extra)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import bsc_nav_amd as B
+    from bsc_nav_amd import synthetic, encoder, dist as bdist
+
+    H, W, gs, cs = a.height, a.width, a.grid, 0.1
+    vit = encoder.RandomViT(a.arch, image_size=224, seed=0).cuda()
+    g, D = vit.grid, vit.out_dim
+    half = gs * cs / 2.0
+    N = H * W
+    n_steps = a.steps + a.warmup
+    n_frames = n_steps * a.batch
+    vcap = 3_000_000 if a.kind == "room" else min(60_000_000, max(3_000_000, n_frames * N // 2))
+    eng = B.VoxelEngine(H, W, gs, cs, -half, half, g, D, mode=a.mode, voxel_capacity=vcap, max_points=a.batch * N,
+                        device=local_rank)
+    # ---- synthetic frames of this rank's shard, resident in HBM before the clock starts ----
+    poses = synthetic.random_walk_poses(1000 + rank, n_frames)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    rgbs, depths = [], []
+    for s in range(n_steps):
+        r, d, _ = synthetic.make_frames(17 + 1000 * rank + s, a.batch, H, W, a.kind, device="cuda",
+                                        poses=poses[s * a.batch:(s + 1) * a.batch])
+        rgbs.append(r)
+        depths.append(d)
+    enc = vit.patch_tokens if a.no_graph else encoder.GraphedEncoder(vit, a.batch, H, W, 4)
+
+    def step(s):
+        tok = enc(rgbs[s])
+        eng.ingest(depths[s], rgbs[s], tok, Ts[s * a.batch:(s + 1) * a.batch])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        step(s)
+    barrier()
+    c0 = eng.counters()
+    eng.kernel_stats(0, reset=True)
+    t0 = time.perf_counter()
+    for s in range(a.warmup, n_steps):
+        step(s)
+    merge_info = None
+    if world > 1:
+        merge_info = bdist.merge_dense_maps(eng)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ks = eng.kernel_stats(0)
+    c1 = eng.counters() if world == 1 else None
+
+    out = None
+    if rank == 0:
+        frames = a.steps * a.batch * world
+        out = {
+            "metric": "RGB-D frames/sec into voxel feature memory", "value": frames / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry / f32 features",
+            "data": "synthetic",
+            "config": {"workload": f"{a.batch * a.steps} synthetic {W}x{H} RGB-D frames per GPU ({a.kind} depth, every "
+                                   f"pixel), {a.arch} random weights {D}-D tokens {g}x{g}, {gs}^3 grid of {cs} m cells, "
+                                   f"dense {a.mode} reduce" + (", + RCCL reduce-scatter merge" if world > 1 else ""),
+                       "frames_per_step": a.batch, "parallelism": f"frames sharded x{world}"},
+        }
+        if merge_info:
+            out["config"]["merge"] = merge_info
+    # ---- per-stage split (untimed extra pass) and roofline of the dominant hand-written kernel ----
+    if rank == 0 and world == 1:
+        launches = max(1, ks["launches"])
+        U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per launch
+        U_new = (c1["max_id"] - c0["max_id"]) / a.steps
+        P_pass = (c1["points_passed"] - c0["points_passed"]) / a.steps
+        # algorithmic bytes of one k_dense_reduce launch: accumulator rows RMW (new rows
+        # are written only) + counts + token tile once + sorted keys and patch codes of the passing points
+        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * 4 + 12 * P_pass
+        ms = ks["ms"] / launches
+        achieved = alg / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_dense_reduce", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "bytes_per_launch": alg, "ms_per_launch": ms, "voxel_rows_per_launch": U,
+                           "points_per_launch": P_pass}
+        # stage split
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        tok = enc(rgbs[0])
+        e0.record()
+        for s in range(a.warmup, min(n_steps, a.warmup + 8)):
+            tok = enc(rgbs[s])
+        e1.record()
+        for s in range(a.warmup, min(n_steps, a.warmup + 8)):
+            eng.ingest(depths[s], rgbs[s], tok, Ts[s * a.batch:(s + 1) * a.batch])
+        e2.record()
+        torch.cuda.synchronize()
+        k = min(n_steps, a.warmup + 8) - a.warmup
+        enc_ms, ing_ms = e0.elapsed_time(e1) / k, e1.elapsed_time(e2) / k
+        out["stages"] = {"encoder_ms_per_step": enc_ms, "ingest_ms_per_step": ing_ms,
+                         "encoder_tflops": vit.flops_per_frame() * a.batch / (enc_ms * 1e-3) / 1e12,
+                         "voxels": c1["max_id"]}
+        if a.localize:
+            q = torch.randn(1, D, device="cuda")
+            eng.localize(q, K=100)
+            eng.kernel_stats(1, reset=True)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(10):
+                eng.localize(q, K=100)
+            torch.cuda.synchronize()
+            lat = (time.perf_counter() - t) / 10
+            ls = eng.kernel_stats(1)
+            out["localize"] = {"latency_ms": lat * 1e3, "cosine_ms": ls["ms"] / max(1, ls["launches"]),
+                               "cosine_GBs": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9, "voxels": c1["max_id"]}
+    # ---- CPU baseline: the plain-C oracle (port of the reference loop) on a bounded sample ----
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+        oc = orc.make_config(H, W, gs, cs, -half, half, g, D, mode=1 if a.mode == "mean" else 2)
+        om = orc.OracleMemory(oc, voxel_capacity=2_000_000)
+        tok_h = vit.patch_tokens(rgbs[0]).cpu().numpy()
+        rgb_h, dep_h = rgbs[0].cpu().numpy(), depths[0].cpu().numpy()
+        t = time.perf_counter()
+        nf = 0
+        while nf < a.batch and (nf < 2 or time.perf_counter() - t < a.cpu_seconds):
+            om.ingest_frame(dep_h[nf], rgb_h[nf], None, Ts[nf], tok_h[nf])
+            nf += 1
+        cdt = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": nf / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"first {nf} frames of the same workload through oracle/bsc_oracle.c "
+                                         f"(memory path only: geometry + voxel scatter, encoder excluded), "
+                                         f"{cdt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ SIGNATURES = {
     "bsc_dense_gather": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_dense_replace": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
-    "bsc_last_kernel_stats": (_I32, [_VP, _I32, _VP]),
+    "bsc_kernel_stats": (_I32, [_VP, _I32, _I32, _VP]),
 }
 
 _lib = None

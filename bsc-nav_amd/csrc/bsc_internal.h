@@ -7,6 +7,7 @@
 #include "../../include/bscnav.h"
 
 typedef unsigned long long u64;
+#define BSC_EV_RING 512
 
 // device scalar block indices (int64 each)
 enum {
@@ -63,6 +64,7 @@ struct bsc_ctx {
     u64 *keys_a, *keys_b;
     int32_t *pass_list;
     int32_t *seg_start;
+    int32_t *seg_last;
     double *d_transforms; // (max_frames,16)
     int64_t *d_offsets;   // (max_frames+1)
     int max_frames;
@@ -85,8 +87,10 @@ struct bsc_ctx {
     size_t prim_tmp_bytes;
     // bookkeeping
     int64_t order_base; // global point counter (top-down map tie order)
-    hipEvent_t ev0, ev1;
-    double last_ms[2], last_bytes[2];
+    // HIP-event ring around the dominant kernels (0: dense feature reduce, 1: cosine scan)
+    hipEvent_t ev[2][2 * BSC_EV_RING];
+    int ev_n[2];
+    double stat_bytes[2];
     bool timing;
 };
 
@@ -126,6 +130,19 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
                          int32_t floor_lo, int32_t floor_hi, int32_t *out_pos, float *out_sim, int32_t *out_count);
 bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out);
 bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the stream)
+// record the start / stop event of launch number ev_n[which] (ring; older launches are overwritten)
+static inline void stat_begin(bsc_ctx *x, int which)
+{
+    if (x->timing) (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING)], x->stream);
+}
+static inline void stat_end(bsc_ctx *x, int which, double bytes)
+{
+    if (x->timing) {
+        (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING) + 1], x->stream);
+        x->ev_n[which]++;
+        x->stat_bytes[which] += bytes;
+    }
+}
 
 static inline int ceil_log2_u64(uint64_t v)
 {

@@ -144,7 +144,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_rgbv, np); ALLOC(x->p_r2f, np); ALLOC(x->p_alpha, np);
     ALLOC(x->p_scan_in, np); ALLOC(x->p_scan_out, np);
     ALLOC(x->keys_a, np); ALLOC(x->keys_b, np);
-    ALLOC(x->pass_list, np); ALLOC(x->seg_start, np);
+    ALLOC(x->pass_list, np); ALLOC(x->seg_start, np); ALLOC(x->seg_last, np);
     ALLOC(x->d_transforms, (int64_t)x->max_frames * 16);
     ALLOC(x->d_offsets, x->max_frames + 1);
     ALLOC(x->l_key_a, vcap + 1); ALLOC(x->l_key_b, vcap + 1);
@@ -155,8 +155,8 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
     hipError_t e = hipMalloc(&x->prim_tmp, x->prim_tmp_bytes);
     if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
-    BSC_HIP(hipEventCreate(&x->ev0));
-    BSC_HIP(hipEventCreate(&x->ev1));
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < 2 * BSC_EV_RING; ++i) BSC_HIP(hipEventCreate(&x->ev[w][i]));
     x->timing = true;
     bsc_status st = reset_state(x);
     if (st != BSC_OK) { bsc_destroy(x); return st; }
@@ -172,14 +172,15 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     void *ptrs[] = {x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
                     x->p_rgbv, x->p_r2f, x->p_alpha, x->p_scan_in, x->p_scan_out, x->keys_a, x->keys_b, x->pass_list,
-                    x->seg_start, x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
+                    x->seg_start, x->seg_last, x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->prim_tmp};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
-    if (x->ev0) hipEventDestroy(x->ev0);
-    if (x->ev1) hipEventDestroy(x->ev1);
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < 2 * BSC_EV_RING; ++i)
+            if (x->ev[w][i]) hipEventDestroy(x->ev[w][i]);
     free(x);
 }
 
@@ -219,11 +220,11 @@ extern "C" bsc_status bsc_flush(bsc_ctx *x, bsc_draw_fn draw, void *user)
     return flush_cache(x, draw, user);
 }
 
-__global__ void k_store_totals(int n, const int32_t *cnt, int64_t *out2)
+__global__ __launch_bounds__(TPB) void k_store_totals(int n, const int32_t *__restrict__ cnt, int64_t *out2)
 {
     __shared__ long long sv[TPB], st[TPB];
     long long v = 0, t = 0;
-    for (int i = threadIdx.x; i < n; i += TPB) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
         const int c = cnt[i];
         v += c > 0;
         t += c;
@@ -234,7 +235,10 @@ __global__ void k_store_totals(int n, const int32_t *cnt, int64_t *out2)
         if (threadIdx.x < o) { sv[threadIdx.x] += sv[threadIdx.x + o]; st[threadIdx.x] += st[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out2[0] = sv[0]; out2[1] = st[0]; }
+    if (threadIdx.x == 0) {
+        atomicAdd((u64 *)&out2[0], (u64)sv[0]);
+        atomicAdd((u64 *)&out2[1], (u64)st[0]);
+    }
 }
 
 extern "C" bsc_status bsc_counters(bsc_ctx *x, int64_t *out)
@@ -242,7 +246,8 @@ extern "C" bsc_status bsc_counters(bsc_ctx *x, int64_t *out)
     if (!x || !out) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
     const int32_t *cnt = x->c.mode == BSC_MODE_EXACT ? x->store_cnt : x->acnt;
-    hipLaunchKernelGGL(k_store_totals, dim3(1), dim3(TPB), 0, x->stream, x->c.voxel_capacity + 1, cnt, x->dscal + 12);
+    BSC_HIP(hipMemsetAsync(x->dscal + 12, 0, sizeof(int64_t) * 2, x->stream));
+    hipLaunchKernelGGL(k_store_totals, dim3(512), dim3(TPB), 0, x->stream, x->c.voxel_capacity + 1, cnt, x->dscal + 12);
     BSC_TRY(read_scalars(x));
     out[0] = x->hscal[DS_MAX_ID];
     out[1] = x->iter_id;
@@ -643,21 +648,22 @@ extern "C" bsc_status bsc_keys_dev(bsc_ctx *x, const int32_t **keys_dev, int64_t
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_last_kernel_stats(bsc_ctx *x, int32_t which, double *out)
+extern "C" bsc_status bsc_kernel_stats(bsc_ctx *x, int32_t which, int32_t reset, double *out)
 {
     if (!x || !out || which < 0 || which > 1) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
     BSC_HIP(hipStreamSynchronize(x->stream));
-    float ms = 0.f;
-    hipError_t e = hipEventElapsedTime(&ms, x->ev0, x->ev1);
-    out[0] = (e == hipSuccess) ? (double)ms : -1.0;
-    if (which == 0) {
-        // algorithmic bytes of the last dense reduce: U voxel rows read+written, plus counts and the token tile
-        BSC_TRY(read_scalars(x));
-        const double U = (double)x->hscal[DS_B_NSEG], D = x->c.token_dim;
-        out[1] = U * (2.0 * D * 4.0 + 8.0);
-    } else {
-        out[1] = x->last_bytes[1];
+    const int n = x->ev_n[which], m = n < BSC_EV_RING ? n : BSC_EV_RING;
+    double total = 0.0;
+    for (int i = n - m; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, x->ev[which][2 * (i % BSC_EV_RING)], x->ev[which][2 * (i % BSC_EV_RING) + 1]) == hipSuccess)
+            total += ms;
     }
+    out[0] = total;                 // ms summed over the last m launches
+    out[1] = (double)m;             // launches covered
+    out[2] = x->stat_bytes[which];  // algorithmic bytes accumulated since the last reset (localize only)
+    out[3] = (double)n;             // launches since the last reset
+    if (reset) { x->ev_n[which] = 0; x->stat_bytes[which] = 0.0; }
     return BSC_OK;
 }

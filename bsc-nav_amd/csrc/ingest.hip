@@ -7,9 +7,11 @@
 //   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
 //               first toucher of every still-empty cell                         (1 thread / point)
 //   k_flags + exclusive scan + k_assign      first-touch points get ids max_id + rank in order
-//   k_keys      sort key (voxel id << 32 | j) and top-down map atomicMax on (h, order)
-//   radix sort  groups the points of a voxel, in order
-//   k_chain     per voxel: sequential truncating weighted rgb mean            (1 thread / voxel)
+//   k_keys      sort key (voxel id << 32 | j)
+//   radix sort  groups the points of a voxel, in order; k_segheads lists the voxel segments
+//   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
+//               (h, order of the voxel's latest point)                        (1 wavefront / voxel)
+//   k_hwin      the winning voxel of each map cell writes its colour
 //   k_dense_reduce  per voxel: run-length (frame,patch) pairs x token rows -> one RMW of the
 //               D-float accumulator row                                       (1 wavefront / voxel)
 //   k_append    exact mode: token rows into the cache in order                (1 wavefront / row)
@@ -149,8 +151,7 @@ __global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_
 }
 
 __global__ __launch_bounds__(TPB) void k_keys(int64_t P, const int32_t *__restrict__ p_cell,
-                                              const int32_t *__restrict__ occ, u64 *__restrict__ keys, u64 *hmap,
-                                              int nh, int64_t order_base)
+                                              const int32_t *__restrict__ occ, u64 *__restrict__ keys)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= P) return;
@@ -158,79 +159,112 @@ __global__ __launch_bounds__(TPB) void k_keys(int64_t P, const int32_t *__restri
     u64 key = ~0ull;
     if (c >= 0) {
         const int32_t vid = occ[c];
-        if (vid >= 0) {
-            key = ((u64)(uint32_t)vid << 32) | (u64)(uint32_t)j;
-            // memory_2.py:901-903: `h >= max_height` in sequential order == max over (h, order)
-            const int32_t h = c % nh;
-            const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + j);
-            atomicMax(&hmap[c / nh], packed);
-        }
+        if (vid >= 0) key = ((u64)(uint32_t)vid << 32) | (u64)(uint32_t)j;
     }
     keys[j] = key;
 }
 
-__global__ __launch_bounds__(TPB) void k_hwin(int64_t P, const int32_t *__restrict__ p_cell,
-                                              const int32_t *__restrict__ occ, const u64 *__restrict__ hmap,
-                                              const uint32_t *__restrict__ p_rgbv, uint8_t *__restrict__ cv_map, int nh,
-                                              int64_t order_base)
-{
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= P) return;
-    const int32_t c = p_cell[j];
-    if (c < 0 || occ[c] < 0) return;
-    const int32_t h = c % nh, rc = c / nh;
-    const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + j);
-    if (hmap[rc] == packed) {
-        const uint32_t v = p_rgbv[j];
-        cv_map[3 * (int64_t)rc + 0] = (uint8_t)(v & 0xff);
-        cv_map[3 * (int64_t)rc + 1] = (uint8_t)((v >> 8) & 0xff);
-        cv_map[3 * (int64_t)rc + 2] = (uint8_t)((v >> 16) & 0xff);
-    }
-}
-
-// memory_2.py:888-899 — one thread per voxel walks that voxel's points of the batch in order.
-__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict__ keys, const int64_t *dscal,
-                                               const uint32_t *__restrict__ p_rgbv, const double *__restrict__ p_alpha,
-                                               uint8_t *__restrict__ rgb, float *__restrict__ weight,
-                                               int32_t *__restrict__ seg_start, int64_t *dscal_w)
+// segment heads of the sorted (voxel id, order) list -> unordered list of segment start positions
+__global__ __launch_bounds__(TPB) void k_segheads(int64_t P, const u64 *__restrict__ keys, int32_t *__restrict__ seg_start,
+                                                  int64_t *dscal)
 {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= P) return;
     const u64 key = keys[i];
     if (key == ~0ull) return;
-    const uint32_t vid = (uint32_t)(key >> 32);
-    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == vid) return;   // not a segment head
-    seg_start[atomicAdd((u64 *)&dscal_w[DS_B_NSEG], 1ull)] = (int32_t)i;
-    const bool is_new = (int64_t)vid >= dscal[DS_MAX_ID_PREV];
-    float w = 0.f;
-    uint8_t c0 = 0, c1 = 0, c2 = 0;
-    if (!is_new) {
-        w = weight[vid];
-        c0 = rgb[3 * (int64_t)vid]; c1 = rgb[3 * (int64_t)vid + 1]; c2 = rgb[3 * (int64_t)vid + 2];
-    }
-    bool first = is_new;
-    for (int64_t k = i; k < P; ++k) {
-        const u64 kk = keys[k];
-        if ((uint32_t)(kk >> 32) != vid || kk == ~0ull) break;
-        const uint32_t j = (uint32_t)kk;
-        const uint32_t v = p_rgbv[j];
-        const double a = p_alpha[j];
-        const uint8_t r0 = v & 0xff, r1 = (v >> 8) & 0xff, r2 = (v >> 16) & 0xff;
-        if (first) {                    // :890-894 new id: rgb = rgb_v, weight = f32(0 + alpha)
-            c0 = r0; c1 = r1; c2 = r2;
-            w = (float)((double)w + a);
-            first = false;
-        } else {                        // :896-899 u8*f32 -> f32 ; u8*f64 -> f64 ; truncating store
-            const double den = (double)w + a;
-            const double v0 = ((double)((float)c0 * w) + (double)r0 * a) / den;
-            const double v1 = ((double)((float)c1 * w) + (double)r1 * a) / den;
-            const double v2 = ((double)((float)c2 * w) + (double)r2 * a) / den;
-            c0 = (uint8_t)v0; c1 = (uint8_t)v1; c2 = (uint8_t)v2;
-            w = (float)den;
+    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == (uint32_t)(key >> 32)) return;
+    seg_start[atomicAdd((u64 *)&dscal[DS_B_NSEG], 1ull)] = (int32_t)i;
+}
+
+// memory_2.py:888-903 — one WAVEFRONT per voxel walks that voxel's points of the batch in order.
+// The chain c' = trunc((f32(c*w) + r*a) / (w + a)), w' = f32(w + a) is sequential by definition (truncation
+// and f32 rounding at every step), so parallelism is across voxels; within the wave the 64 lanes prefetch 64
+// points at a time (coalesced keys, gathered rgb / alpha) and the steps run out of registers through
+// wave shuffles, lanes 0..2 carrying the R, G, B channels.  The same wave settles the top-down map:
+// `h >= max_height` in sequential order == max over (h, order), and a voxel's latest point is the last
+// element of its segment, so one atomicMax per voxel replaces one per point.
+__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict__ keys, const int64_t *dscal,
+                                               const int32_t *__restrict__ seg_start,
+                                               const uint32_t *__restrict__ p_rgbv, const double *__restrict__ p_alpha,
+                                               const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
+                                               float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
+                                               int gs, int64_t order_base)
+{
+    const int lane = threadIdx.x & 63;
+    const int ch = lane < 3 ? lane : 2;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    const int64_t nseg = dscal[DS_B_NSEG];
+    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
+    for (int64_t s = wave; s < nseg; s += nwaves) {
+        const int64_t i0 = seg_start[s];
+        const uint32_t vid = (uint32_t)(keys[i0] >> 32);
+        const bool is_new = (int64_t)vid >= max_id_prev;
+        float w = 0.f;
+        uint32_t c = 0;
+        if (!is_new) {
+            w = weight[vid];
+            c = rgb[3 * (int64_t)vid + ch];
+        }
+        bool first = is_new;
+        uint32_t last_j = 0;
+        for (int64_t base = i0;; base += 64) {
+            const int64_t k = base + lane;
+            const u64 key = (k < P) ? keys[k] : ~0ull;
+            const bool inseg = (key != ~0ull) && ((uint32_t)(key >> 32) == vid);
+            const uint32_t j = (uint32_t)key;
+            const uint32_t rv = inseg ? p_rgbv[j] : 0u;
+            const double al = inseg ? p_alpha[j] : 0.0;
+            const int n = __popcll(__ballot(inseg));
+            for (int t = 0; t < n; ++t) {
+                const double a = __shfl(al, t);
+                const uint32_t r = (__shfl(rv, t) >> (8 * ch)) & 0xffu;
+                if (first) {                    // :890-894 new id: rgb = rgb_v, weight = f32(0 + alpha)
+                    c = r;
+                    w = (float)((double)w + a);
+                    first = false;
+                } else {                        // :896-899 u8*f32 -> f32 ; u8*f64 -> f64 ; truncating store
+                    const double den = (double)w + a;
+                    const double v = ((double)((float)c * w) + (double)r * a) / den;
+                    c = (uint32_t)(uint8_t)v;
+                    w = (float)den;
+                }
+            }
+            if (n > 0) last_j = __shfl(j, n - 1);
+            if (n < 64) break;
+        }
+        if (lane < 3) rgb[3 * (int64_t)vid + lane] = (uint8_t)c;
+        if (lane == 0) {
+            weight[vid] = w;
+            const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
+            const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + last_j);
+            atomicMax(&hmap[(int64_t)row * gs + col], packed);
+            seg_last[s] = (int32_t)last_j;
         }
     }
-    weight[vid] = w;
-    rgb[3 * (int64_t)vid] = c0; rgb[3 * (int64_t)vid + 1] = c1; rgb[3 * (int64_t)vid + 2] = c2;
+}
+
+// top-down map colour: the voxel whose (h, order) won the cell writes the rgb of its latest point
+__global__ __launch_bounds__(TPB) void k_hwin(const int64_t *dscal, const u64 *__restrict__ keys,
+                                              const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_last,
+                                              const int32_t *__restrict__ rgb_pos, const u64 *__restrict__ hmap,
+                                              const uint32_t *__restrict__ p_rgbv, uint8_t *__restrict__ cv_map, int gs,
+                                              int64_t order_base)
+{
+    const int64_t nseg = dscal[DS_B_NSEG];
+    for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * TPB) {
+        const uint32_t vid = (uint32_t)(keys[seg_start[s]] >> 32);
+        const uint32_t last_j = (uint32_t)seg_last[s];
+        const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
+        const int64_t rc = (int64_t)row * gs + col;
+        const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + last_j);
+        if (hmap[rc] == packed) {
+            const uint32_t v = p_rgbv[last_j];
+            cv_map[3 * rc + 0] = (uint8_t)(v & 0xff);
+            cv_map[3 * rc + 1] = (uint8_t)((v >> 8) & 0xff);
+            cv_map[3 * rc + 2] = (uint8_t)((v >> 16) & 0xff);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,18 +452,20 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     hipLaunchKernelGGL(k_assign, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->p_scan_out, x->dscal,
                        x->c.voxel_capacity, x->c.grid_size, x->nh, x->rgb_pos, x->pass_list);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity);
-    hipLaunchKernelGGL(k_keys, grid, block, 0, s, P, x->p_cell, x->occ, x->keys_a, x->hmap, x->nh, x->order_base);
-    hipLaunchKernelGGL(k_hwin, grid, block, 0, s, P, x->p_cell, x->occ, x->hmap, x->p_rgbv, x->cv_map, x->nh,
-                       x->order_base);
+    hipLaunchKernelGGL(k_keys, grid, block, 0, s, P, x->p_cell, x->occ, x->keys_a);
     const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
     BSC_TRY(prim_sort_keys(x, x->keys_a, x->keys_b, (size_t)P, 0, 32 + vid_bits));
-    hipLaunchKernelGGL(k_chain, grid, block, 0, s, P, x->keys_b, x->dscal, x->p_rgbv, x->p_alpha, x->rgb, x->weight,
-                       x->seg_start, x->dscal);
+    hipLaunchKernelGGL(k_segheads, grid, block, 0, s, P, x->keys_b, x->seg_start, x->dscal);
+    const dim3 wgrid(256 * 8);
+    hipLaunchKernelGGL(k_chain, wgrid, block, 0, s, P, x->keys_b, x->dscal, x->seg_start, x->p_rgbv, x->p_alpha,
+                       x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last, x->c.grid_size, x->order_base);
+    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, s, x->dscal, x->keys_b, x->seg_start, x->seg_last, x->rgb_pos, x->hmap,
+                       x->p_rgbv, x->cv_map, x->c.grid_size, x->order_base);
     if (x->c.mode != BSC_MODE_EXACT) {
-        if (x->timing) BSC_HIP(hipEventRecord(x->ev0, s));
+        stat_begin(x, 0);
         if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, P, tokens);
         else launch_dense<BSC_MODE_MAX>(x, P, tokens);
-        if (x->timing) BSC_HIP(hipEventRecord(x->ev1, s));
+        stat_end(x, 0, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, points)
         hipLaunchKernelGGL(k_rmw_count, dim3(1), dim3(64), 0, s, x->dscal);
     }
     BSC_HIP(hipGetLastError());

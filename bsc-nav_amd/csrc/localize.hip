@@ -265,7 +265,7 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     hipLaunchKernelGGL(k_normalize_q, dim3(nq), dim3(64), 0, s, q_dev, D, x->l_q);
     // dense acnt has no slot for the grid_0_0_0 group: k_candidates reads cnt[vcap]; acnt is allocated vcap+1
     int done = 0;
-    if (x->timing) BSC_HIP(hipEventRecord(x->ev0, s));
+    stat_begin(x, 1);
     while (done < nq && n_rows > 0) {      // the row matrix is streamed once per group of up to 8 queries
         const int left = nq - done;
         if (left >= 8) { launch_cosine<8>(x, rows, n_rows, done); done += 8; }
@@ -273,8 +273,7 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         else if (left >= 2) { launch_cosine<2>(x, rows, n_rows, done); done += 2; }
         else { launch_cosine<1>(x, rows, n_rows, done); done += 1; }
     }
-    if (x->timing) BSC_HIP(hipEventRecord(x->ev1, s));
-    x->last_bytes[1] = (double)n_rows * D * 4.0 * ((nq + 7) / 8) + (double)nq * n_rows * 4.0;
+    stat_end(x, 1, (double)n_rows * D * 4.0 * ((nq + 7) / 8) + (double)nq * n_rows * 4.0);
     const double r2 = radius * radius;
     for (int qi = 0; qi < nq; ++qi) {
         hipLaunchKernelGGL(k_candidates, cgrid, block, 0, s, n_cand, max_id, vcap, x->rgb_pos, cnt, x->store_rows,

@@ -1,0 +1,166 @@
+"""Multi-GPU layer: frames shard across ranks, per-rank voxel maps merge with ONE exchange step.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  The reference is
+single-process; this module is the new frame-sharded design of SURVEY.md §8e:
+
+  merge_dense_maps   (dense mean / max modes)
+     1. all-gather of the per-rank voxel keys  -> identical sorted union on every rank
+     2. each rank lays its rows out in union order (bsc_dense_gather; untouched voxels are neutral)
+     3. reduce-scatter of the (U,D) accumulators and (U,) counts: rank r ends up owning the r-th
+        contiguous slice of the union.  xGMI is point-to-point, so reduce-scatter (all 7 links busy)
+        is preferred over a ring all-reduce followed by a broadcast.
+  localize_sharded   every rank scans its slice, all-gather of the (Q,K) local winners, K-way merge
+                     with the reference's tie order (HDF5 group-name order).
+
+The exact (token-cache) mode is order-defined and does not shard: "replicas only" (DESIGN.md).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_SENTINEL = (1 << 62)
+
+
+def pack_keys(keys):
+    """(n,3) int32 [row,col,h] -> (n,) int64 sortable code."""
+    k = keys.to(torch.int64)
+    return (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+
+
+def unpack_keys(codes):
+    out = torch.stack([(codes >> 42) & 0x1FFFFF, (codes >> 21) & 0x1FFFFF, codes & 0x1FFFFF], dim=1).to(torch.int32)
+    out[codes >= _SENTINEL] = -1         # padding keys fall outside every grid
+    return out
+
+
+def name_key_np(pos):
+    """HDF5 link-name order of 'grid_r_c_h' as a sortable tuple (see localize.hip)."""
+    def field(v, last):
+        s = str(int(v))
+        syms = [int(ch) + (1 if last else 0) for ch in s] + [0 if last else 10] * (6 - len(s))
+        k = 0
+        for x in syms:
+            k = k * 11 + x
+        return k
+    return (field(pos[0], False), field(pos[1], False), field(pos[2], True))
+
+
+def _world(group):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def all_gather_ragged(t, group=None):
+    """All-gather of 1-D tensors of different lengths -> list of tensors (one per rank)."""
+    rank, world = _world(group)
+    if world == 1:
+        return [t]
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def union_keys(local_codes, group=None):
+    """Sorted union of every rank's voxel codes, padded with sentinels to a multiple of the world size."""
+    rank, world = _world(group)
+    parts = all_gather_ragged(local_codes, group)
+    union = torch.unique(torch.cat(parts))          # sorted ascending
+    n_union = union.numel()
+    per = (n_union + world - 1) // world if n_union else 0
+    if per * world > n_union:
+        union = torch.cat([union, torch.full((per * world - n_union,), _SENTINEL, dtype=torch.int64,
+                                             device=union.device)])
+    return union, n_union, per
+
+
+def reduce_scatter_rows(rows, op, per, group=None):
+    """rows (world*per, ...) -> this rank's (per, ...) slice of the element-wise reduction."""
+    rank, world = _world(group)
+    if world == 1:
+        return rows
+    out = torch.empty((per,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    backend = dist.get_backend(group)
+    if backend == "gloo":                           # CPU test path: gloo has no reduce_scatter
+        full = rows.clone()
+        dist.all_reduce(full, op=op, group=group)
+        out.copy_(full[rank * per:(rank + 1) * per])
+    else:
+        dist.reduce_scatter_tensor(out, rows.contiguous(), op=op, group=group)
+    return out
+
+
+def merge_dense_maps(engine, group=None):
+    """Merge per-rank dense maps; afterwards rank r holds slice r of the global voxel set.
+
+    `engine` needs: mode, keys_tensor(), dense_gather(keys), dense_replace(keys, acc, cnt).
+    Returns dict(n_union, per_rank, n_local)."""
+    rank, world = _world(group)
+    keys = engine.keys_tensor()
+    codes = pack_keys(keys) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=keys.device)
+    union, n_union, per = union_keys(codes, group)
+    if world == 1:
+        return dict(n_union=n_union, per_rank=n_union, n_local=n_union)
+    ukeys = unpack_keys(union)
+    acc, cnt = engine.dense_gather(ukeys)
+    op = dist.ReduceOp.MAX if engine.mode == "max" else dist.ReduceOp.SUM
+    my_acc = reduce_scatter_rows(acc, op, per, group)
+    my_cnt = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, per, group)
+    mine = union[rank * per:(rank + 1) * per]
+    n_local = int((mine < _SENTINEL).sum().item())
+    engine.dense_replace(ukeys[rank * per:rank * per + n_local].contiguous(), my_acc[:n_local].contiguous(),
+                         my_cnt[:n_local].contiguous())
+    return dict(n_union=n_union, per_rank=per, n_local=n_local)
+
+
+def merge_topk(pos_list, sim_list, K):
+    """K-way merge of per-rank winners with the reference's order: similarity descending, ties in
+    HDF5 group-name order (memory_2.py:665 stable sort over name-sorted keys)."""
+    pos = np.concatenate([np.asarray(p).reshape(-1, 3) for p in pos_list])
+    sim = np.concatenate([np.asarray(s).reshape(-1) for s in sim_list])
+    order = sorted(range(len(sim)), key=lambda i: (-float(sim[i]),) + name_key_np(pos[i]))[:K]
+    return pos[order], sim[order]
+
+
+def localize_sharded(engine, q, K=100, radius=None, curr=None, floor=None, group=None):
+    """q (Q,D) identical on every rank -> global (Q,<=K,3) positions and (Q,<=K) similarities."""
+    rank, world = _world(group)
+    pos, sim, cnt = engine.localize(q, K=K, radius=radius, curr=curr, floor=floor)
+    if world == 1:
+        return [pos[i, :cnt[i]] for i in range(len(cnt))], [sim[i, :cnt[i]] for i in range(len(cnt))]
+    dev = q.device
+    Q = pos.shape[0]
+    rec = torch.zeros((Q, K, 4), dtype=torch.float64, device=dev)       # pos exact in f64, sim widened
+    rec[..., :3] = torch.from_numpy(pos.astype(np.float64)).to(dev)
+    rec[..., 3] = torch.from_numpy(sim.astype(np.float64)).to(dev)
+    n = torch.from_numpy(cnt.astype(np.int64)).to(dev)
+    recs = [torch.empty_like(rec) for _ in range(world)]
+    ns = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(recs, rec, group=group)
+    dist.all_gather(ns, n, group=group)
+    out_p, out_s = [], []
+    for qi in range(Q):
+        pl, sl = [], []
+        for r in range(world):
+            m = int(ns[r][qi].item())
+            a = recs[r][qi, :m].cpu().numpy()
+            pl.append(a[:, :3].astype(np.int32))
+            sl.append(a[:, 3].astype(np.float32))
+        p, s = merge_topk(pl, sl, K)
+        out_p.append(p)
+        out_s.append(s)
+    return out_p, out_s
+
+
+def shard_frames(n_frames, group=None):
+    """Contiguous frame block of this rank: [start, stop)."""
+    rank, world = _world(group)
+    per = (n_frames + world - 1) // world
+    return min(rank * per, n_frames), min((rank + 1) * per, n_frames)

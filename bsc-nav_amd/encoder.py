@@ -1,0 +1,136 @@
+"""Patch-feature providers: the per-frame ViT forward of the memory path (memory_2.py:732-742).
+
+The reference takes DINOv2 `x_norm_patchtokens` from torch.hub (third-party, not vendored, weights not
+available offline), so encoder numerics are parity-unpinned.  What IS pinned is the
+interface: rgb u8 (H,W,3) -> /255 -> resize (query_h, query_w) -> ImageNet normalise -> ViT ->
+final-LayerNorm'd patch tokens, reshaped (g, g, D) and indexed [py, px].
+
+`RandomViT` is a plain ViT (B/16: 12x768x12, L/14: 24x1024x16 with 4 register tokens) with
+trunc_normal(0.02) weights.  Its dense GEMMs run on MFMA through PyTorch-ROCm (hipBLASLt) in bf16;
+outputs are returned in fp32 for the voxel kernels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+VIT_SHAPES = {
+    "vit_b16": dict(patch=16, width=768, depth=12, heads=12, mlp=3072, registers=0),
+    "vit_l14": dict(patch=14, width=1024, depth=24, heads=16, mlp=4096, registers=4),
+    "vit_tiny_test": dict(patch=16, width=64, depth=2, heads=4, mlp=128, registers=0),
+}
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class _Block(nn.Module):
+    def __init__(self, width, heads, mlp):
+        super().__init__()
+        self.heads = heads
+        self.ln1 = nn.LayerNorm(width, eps=1e-6)
+        self.qkv = nn.Linear(width, 3 * width)
+        self.proj = nn.Linear(width, width)
+        self.ln2 = nn.LayerNorm(width, eps=1e-6)
+        self.fc1 = nn.Linear(width, mlp)
+        self.fc2 = nn.Linear(mlp, width)
+
+    def forward(self, x):
+        B, T, C = x.shape
+        qkv = self.qkv(self.ln1(x)).reshape(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x = x + self.proj(a.transpose(1, 2).reshape(B, T, C))
+        x = x + self.fc2(F.gelu(self.fc1(self.ln2(x))))
+        return x
+
+
+class RandomViT(nn.Module):
+    def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16):
+        super().__init__()
+        s = VIT_SHAPES[arch]
+        self.arch, self.image_size, self.patch = arch, image_size, s["patch"]
+        self.grid = image_size // s["patch"]
+        self.width = s["width"]
+        self.registers = s["registers"]
+        self.compute_dtype = dtype
+        g = torch.Generator().manual_seed(seed)
+        self.patch_embed = nn.Linear(3 * s["patch"] * s["patch"], s["width"])   # conv(p, stride p) as one GEMM
+        self.cls = nn.Parameter(torch.zeros(1, 1, s["width"]))
+        self.reg = nn.Parameter(torch.zeros(1, s["registers"], s["width"])) if s["registers"] else None
+        self.pos = nn.Parameter(torch.zeros(1, 1 + self.grid * self.grid, s["width"]))
+        self.blocks = nn.ModuleList([_Block(s["width"], s["heads"], s["mlp"]) for _ in range(s["depth"])])
+        self.norm = nn.LayerNorm(s["width"], eps=1e-6)
+        self.head = nn.Linear(s["width"], out_dim, bias=False) if out_dim and out_dim != s["width"] else None
+        self.out_dim = out_dim or s["width"]
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.trunc_normal_(p, std=0.02, generator=g)
+        self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
+        self.eval()
+        # weights live in the compute dtype: no per-call casts (autocast would re-cast 50+ weights per forward)
+        for name, prm in self.named_parameters():
+            prm.data = prm.data.to(dtype)
+            prm.requires_grad_(False)
+
+    @torch.no_grad()
+    def preprocess(self, rgb):
+        """rgb (B,H,W,>=3) u8 -> (B,3,S,S) normalised float (memory_2.py:733-736, transform_ :71-74)."""
+        x = rgb[..., :3].permute(0, 3, 1, 2).float() / 255
+        if x.shape[-2:] != (self.image_size, self.image_size):
+            x = F.interpolate(x, size=(self.image_size, self.image_size), mode="bilinear", antialias=True,
+                              align_corners=False)
+        return (x - self.mean) / self.std
+
+    @torch.no_grad()
+    def forward_features(self, x):
+        """(B,3,S,S) -> {'x_norm_patchtokens': (B, g*g, D)}  (the key the reference reads, memory_2.py:739)."""
+        B, g, p = x.shape[0], self.grid, self.patch
+        x = x.to(self.compute_dtype)
+        t = x.reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * p * p)
+        t = self.patch_embed(t)
+        t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
+        if self.reg is not None:
+            t = torch.cat([t[:, :1], self.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
+        for blk in self.blocks:
+            t = blk(t)
+        t = self.norm(t)[:, 1 + self.registers:]
+        if self.head is not None:
+            t = self.head(t)
+        return {"x_norm_patchtokens": t.float()}
+
+    @torch.no_grad()
+    def patch_tokens(self, rgb):
+        """rgb (B,H,W,C) u8 on the device -> (B, g, g, D) fp32 contiguous."""
+        t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
+        return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()
+
+    def flops_per_frame(self):
+        s = VIT_SHAPES[self.arch]
+        T = 1 + self.registers + self.grid * self.grid
+        w, m = s["width"], s["mlp"]
+        per_layer = 2 * T * w * 3 * w + 2 * T * w * w + 2 * 2 * T * w * m + 2 * 2 * T * T * w
+        return s["depth"] * per_layer + 2 * self.grid * self.grid * 3 * self.patch * self.patch * w
+
+
+class GraphedEncoder:
+    """Replays the encoder for a fixed batch shape from a captured HIP graph (launch-bound at small batch)."""
+
+    def __init__(self, vit, batch, H, W, channels=4):
+        self.vit = vit
+        self.static_in = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                vit.patch_tokens(self.static_in)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = vit.patch_tokens(self.static_in)
+
+    def __call__(self, rgb):
+        self.static_in.copy_(rgb)
+        self.graph.replay()
+        return self.static_out

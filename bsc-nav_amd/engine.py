@@ -186,10 +186,11 @@ class VoxelEngine:
                                          lo, hi, _hp(pos), _hp(sim), _hp(cnt)))
         return pos, sim, cnt
 
-    def last_kernel_stats(self, which=0):
-        out = np.zeros(2, np.float64)
-        _lib.check(self.lib.bsc_last_kernel_stats(self.h, which, _hp(out)))
-        return float(out[0]), float(out[1])
+    def kernel_stats(self, which=0, reset=False):
+        """HIP-event time of the dominant kernel: dict(ms, launches, bytes, launches_since_reset)."""
+        out = np.zeros(4, np.float64)
+        _lib.check(self.lib.bsc_kernel_stats(self.h, which, 1 if reset else 0, _hp(out)))
+        return dict(ms=float(out[0]), launches=int(out[1]), bytes=float(out[2]), launches_since_reset=int(out[3]))
 
     # ---- multi-GPU helpers --------------------------------------------------------------------------
     def keys_tensor(self):

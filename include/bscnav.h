@@ -136,9 +136,11 @@ bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, c
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
 bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
 
-/* timing of the last bsc_ingest / bsc_localize on the ctx stream, measured with HIP events
- * around the dominant kernel (feature scatter / cosine scan): out[0]=ms, out[1]=algorithmic bytes */
-bsc_status bsc_last_kernel_stats(bsc_ctx *ctx, int32_t which /*0 ingest, 1 localize*/, double *out2_host);
+/* HIP-event timing of the dominant kernel of each path, recorded on the ctx stream around every launch
+ * (which 0: dense feature reduce of bsc_ingest, 1: cosine scan of bsc_localize).
+ * out[0]=ms summed over the covered launches, out[1]=launches covered (ring of 512), out[2]=algorithmic
+ * bytes accumulated (localize; for ingest derive them from bsc_counters), out[3]=launches since reset. */
+bsc_status bsc_kernel_stats(bsc_ctx *ctx, int32_t which, int32_t reset, double *out4_host);
 
 #ifdef __cplusplus
 }
