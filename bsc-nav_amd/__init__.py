@@ -6,5 +6,7 @@ through the shim package of that name at the repository root.
 from . import _lib
 from .engine import VoxelEngine
 from .geometry import PoseChain, cam_mat_fov, cam_mat_patch, pose_vec2tf, sample_indices
+from .config import MemoryArgs
+from .memory import VoxelTokenMemory
 
-__all__ = ["VoxelEngine", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "_lib"]
+__all__ = ["VoxelEngine", "VoxelTokenMemory", "MemoryArgs", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "_lib"]

@@ -1,0 +1,60 @@
+"""create_memory_for_dataset-shaped driver (create_memory_for_dataset.py:54-137) over a frame source.
+
+The reference loops over habitat episodes, derives a memory directory per scene island, skips scenes whose
+directory exists (load instead of build) and otherwise explores the scene with the simulator.  The simulator
+is out of scope here; the same call order runs over any `FrameSource`:
+    initial_memory() -> per frame obs2voxeltoken / ingest_frames -> final flush -> save.
+"""
+import os
+
+import numpy as np
+
+from . import synthetic
+from .memory import VoxelTokenMemory
+
+
+class SyntheticScene:
+    """Seeded stand-in for one scene island: yields batches of (rgb, depth, poses) resident on the device."""
+
+    def __init__(self, name, seed, n_frames, height, width, kind="room", batch=16):
+        self.name, self.seed, self.n_frames, self.kind, self.batch = name, seed, n_frames, kind, batch
+        self.height, self.width = height, width
+        self.poses = synthetic.random_walk_poses(seed, n_frames)
+
+    def __iter__(self):
+        for s in range(0, self.n_frames, self.batch):
+            p = self.poses[s:s + self.batch]
+            rgb, depth, _ = synthetic.make_frames(self.seed * 7919 + s, len(p), self.height, self.width, self.kind,
+                                                  poses=p)
+            yield rgb, depth, p
+
+
+def create_memory_for_dataset(args, scenes, encoder, feature_mode="mean", root=None, **memory_kwargs):
+    """For every scene: build the memory (or load it when its directory exists, create_memory_for_dataset.py:103).
+
+    Returns {scene name: memory directory}."""
+    root = root or args.memory_path
+    out = {}
+    memory = None
+    for scene in scenes:
+        memory_path = os.path.join(root, scene.name)                     # :97-99
+        args.load_memory_path = memory_path
+        if memory is None:
+            memory = VoxelTokenMemory(args, memory_path=memory_path, preload_dino=encoder, need_diffusion=False,
+                                      feature_mode=feature_mode, max_frames_per_call=scene.batch, **memory_kwargs)
+        if os.path.exists(memory_path):                                  # :103-109 load instead of rebuilding
+            memory.load_memory(init_state=None)
+            out[scene.name] = memory_path
+            continue
+        memory.memory_save_path = memory_path
+        memory.load_memory(build_map=True)                               # fresh caches (memory_2.py:172-184)
+        memory.memory_save_path = memory_path
+        memory.initial_memory()
+        for rgb, depth, poses in scene:
+            memory.ingest_frames(rgb, depth, poses)
+            memory.base_height.append(float(poses[-1][1]))
+        if feature_mode == "exact":
+            memory.update_memory_dist_base()                             # memory_2.py:1135 final flush
+        memory.save_memory(original_pos=np.asarray(scene.poses[0][:3], dtype=np.float32))
+        out[scene.name] = memory.memory_save_path
+    return out

@@ -1,0 +1,403 @@
+"""VoxelTokenMemory — drop-in for the reference class of the same name (memory_2.py:38), backed by libbscnav.
+
+Same constructor signature, method names, argument meaning and return types as the reference for the
+memory construction / query path, so that BSCAgent.GESObjectNavRobot and create_memory_for_dataset.py can
+hold this object instead.  What differs, by design:
+  * the per-point Python loop, the HDF5 flush loop and the per-voxel scan run as HIP kernels;
+  * simulator (NavEnv), detector (YOLO-World) and diffusion model are optional injected collaborators;
+  * `feature_mode="exact"` keeps the reference's token-cache semantics bit for bit, `"mean"` / `"max"`
+    are the dense per-voxel reductions (north-star mode) and are mergeable across GPUs.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import store
+from .config import from_namespace
+from .engine import VoxelEngine
+from .geometry import PoseChain, cam_mat_fov, sample_indices
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class VoxelTokenMemory:
+    def __init__(self, args, memory_path=None, init_state=None, build_map=False, preload_dino=None,
+                 preload_yolo=None, need_diffusion=True, *, feature_mode="exact", env=None, imaginer=None,
+                 token_dim=None, patch_size=None, voxel_capacity=None, token_capacity=None, gpu=0,
+                 alpha_source="device", max_frames_per_call=1, quiet=True):
+        self.args = args
+        self.cfg = from_namespace(args)
+        self.device = "cuda"                                    # memory_2.py:41
+        if not torch.cuda.is_available():
+            raise RuntimeError("VoxelTokenMemory (bsc_nav_amd) needs a ROCm GPU; there is no CPU path")
+        self.gpu = gpu
+        self.dinov2 = preload_dino                               # anything with forward_features(x)[...]
+        self.yolow = preload_yolo
+        self.imaginer = imaginer                                 # text -> list of images (memory_2.py:258-276)
+        self.Env = env                                           # NavEnv-like collaborator (env.py:49)
+        self.quiet = quiet
+        self.feature_mode = feature_mode
+        self.alpha_source = alpha_source
+        if memory_path:                                          # memory_2.py:61-64
+            self.memory_save_path = memory_path
+        else:
+            self.memory_save_path = os.path.join(self.cfg.memory_path, self.cfg.scene_name)
+        c = self.cfg
+        self.patch_h = self.patch_w = int(patch_size or c.patch_size)          # memory_2.py:80-83
+        self.n_patch_w = c.query_width // self.patch_w
+        self.n_patch_h = c.query_height // self.patch_h
+        if self.n_patch_w != self.n_patch_h:
+            raise ValueError("square patch grids only (the reference reshapes to (n_patch_w, n_patch_h))")
+        self.chain = PoseChain(c.base_forward_axis, c.base_left_axis, c.base_up_axis, c.base2cam_rot, c.sensor_height)
+        self.base_transform = self.chain.base_transform
+        self.base2cam_tf = self.chain.base2cam_tf
+        self.cs = c.cell_size
+        self.gs = int(c.grid_size)
+        self.depth_sample_rate = c.depth_sample_rate
+        self.calib_mat = cam_mat_fov(c.height, c.width, fov=90)                # memory_2.py:102
+        self.min_depth, self.max_depth = c.min_depth, c.max_depth
+        self.token_dim = int(token_dim or c.token_dim)
+        self.iter_size, self.cache_size = c.iter_size, c.cache_size
+        self.camera_height = c.sensor_height
+        self.floor_height, self.map_height = c.floor_height, c.map_height
+        self.maxh = int(self.map_height / self.cs)                             # memory_2.py:122-123
+        self.minh = int(self.floor_height / self.cs)
+        self.base_height = []
+        self.long_memory_dict = []
+        self.feat_path = None
+        self._voxel_capacity = voxel_capacity
+        self._token_capacity = token_capacity
+        self._max_frames = max_frames_per_call
+        self.engine = None
+        self._make_engine()
+
+    # ------------------------------------------------------------------------------------------
+    def _make_engine(self):
+        if self.engine is not None:
+            self.engine.close()
+        c = self.cfg
+        self.engine = VoxelEngine(c.height, c.width, self.gs, self.cs, self.floor_height, self.map_height,
+                                  self.n_patch_w, self.token_dim, mode=self.feature_mode, iter_size=self.iter_size,
+                                  cache_size=self.cache_size, voxel_capacity=self._voxel_capacity,
+                                  token_capacity=self._token_capacity, max_points=self._max_frames * c.height * c.width,
+                                  device=self.gpu, min_depth=self.min_depth, max_depth=self.max_depth,
+                                  min_h=self.minh, max_h=self.maxh)
+        self.chain.reset()
+
+    def _log(self, *a):
+        if not self.quiet:
+            print(*a)
+
+    # state the reference keeps as NumPy attributes, exported from HBM on access
+    @property
+    def max_id(self):
+        return self.engine.counters()["max_id"]
+
+    @property
+    def iter_id(self):
+        return self.engine.counters()["iter_id"]
+
+    @property
+    def grid_rgb_pos(self):
+        return self.engine.export_rgb()[0]
+
+    @property
+    def grid_rgb(self):
+        return self.engine.export_rgb()[1]
+
+    @property
+    def weight(self):
+        return self.engine.export_rgb()[2]
+
+    @property
+    def occupied_ids(self):
+        return self.engine.export_occupied()
+
+    @property
+    def cv_map(self):
+        return self.engine.export_heightmap()[1]
+
+    @property
+    def max_height(self):
+        return self.engine.export_heightmap()[0]
+
+    @property
+    def inv_init_base_tf(self):
+        return [] if self.chain.inv_init_base_tf is None else self.chain.inv_init_base_tf
+
+    # ------------------------------------------------------------------------------------------
+    def initial_memory(self):
+        """memory_2.py:298-309 — never overwrites: appends _1, _2, ... (split('_')[0] quirk kept)."""
+        count = 1
+        while os.path.exists(self.memory_save_path):
+            self.memory_save_path = self.memory_save_path.split("_")[0]
+            self.memory_save_path = f"{self.memory_save_path}_{count}"
+            count += 1
+        os.makedirs(self.memory_save_path)
+        self.feat_path = self.memory_save_path + "/feat.h5df"
+        self._log("memory init at:", self.memory_save_path)
+
+    def get_total_token_count(self):
+        """memory_2.py:312-323."""
+        k = self.engine.counters()
+        self._log("total_tokens:", k["store_tokens"])
+        return k["store_tokens"]
+
+    def update_memory_dist_base(self):
+        """memory_2.py:326-358 — flush ALL iter_size cache rows into the per-voxel token store."""
+        t1 = time.time()
+        self.engine.flush()
+        self._log(f"finish updating, time:{time.time() - t1}")
+
+    # ------------------------------------------------------------------------------------------
+    def _get_patch_token(self, img):
+        """memory_2.py:732-742: u8 (H,W,3) -> /255 -> resize -> normalise -> patch tokens (g,g,D) on device."""
+        x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device).unsqueeze(0)
+        x = x.permute(0, 3, 1, 2).float() / 255
+        x = self._transform_tensor(x)
+        with torch.no_grad():
+            tok = self.dinov2.forward_features(x)["x_norm_patchtokens"].squeeze(0)
+            tok = tok.reshape(self.n_patch_w, self.n_patch_h, -1)
+        return tok
+
+    def _transform_tensor(self, x):
+        """transform_ (memory_2.py:71-74): Resize((qh,qw)) on a float tensor (bilinear, antialias) + Normalize."""
+        c = self.cfg
+        if x.shape[-2:] != (c.query_height, c.query_width):
+            x = torch.nn.functional.interpolate(x, size=(c.query_height, c.query_width), mode="bilinear",
+                                                antialias=True, align_corners=False)
+        mean = torch.tensor(IMAGENET_MEAN, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD, device=x.device).view(1, 3, 1, 1)
+        return (x - mean) / std
+
+    def transform(self, pil_img):
+        """transform (memory_2.py:66-70): PIL -> Resize -> ToTensor -> Normalize, (3,qh,qw) float."""
+        from PIL import Image
+        c = self.cfg
+        img = pil_img.convert("RGB").resize((c.query_width, c.query_height), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255
+        mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+        std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+        return (x - mean) / std
+
+    def _host_alpha(self, depth, idx):
+        """exp(-r^2/1.2) evaluated exactly as the reference does on the host (memory_2.py:873-875, utils.py:153-173)."""
+        h, w = depth.shape
+        y, x = np.divmod(idx.astype(np.int64), w)
+        p2d = np.vstack([x + 0.5, y + 0.5, np.ones_like(x, dtype=np.float64)])
+        pc = (np.linalg.inv(self.calib_mat) @ p2d) * depth.reshape(-1)[idx].reshape(1, -1)
+        r2 = (pc[0] * pc[0] + pc[1] * pc[1]) + pc[2] * pc[2]
+        return np.exp(-r2 / (2 * 0.6))
+
+    def obs2voxeltoken(self, obs, pose):
+        """memory_2.py:842-903 — one RGB-D frame into the memory."""
+        T = self.chain.pc_transform(np.asarray(pose, dtype=np.float64))
+        self.tf = self.chain.tf
+        rgb = np.ascontiguousarray(np.array(obs["rgb"])[:, :, :3])
+        depth = np.ascontiguousarray(np.array(obs["depth"]), dtype=np.float32)
+        patch_tokens = self._get_patch_token(rgb).float().contiguous()
+        idx = sample_indices(depth.size, self.depth_sample_rate)              # global NumPy RNG, as the reference
+        alpha = None
+        if self.alpha_source == "host":
+            with np.errstate(all="ignore"):
+                alpha = torch.from_numpy(self._host_alpha(depth, idx)).to(self.device)
+        self.engine.ingest(torch.from_numpy(depth).to(self.device).unsqueeze(0),
+                           torch.from_numpy(rgb).to(self.device).unsqueeze(0), patch_tokens.unsqueeze(0), T[None],
+                           torch.from_numpy(idx).to(self.device), np.array([0, len(idx)], np.int64), alpha)
+
+    def ingest_frames(self, rgb, depth, poses, tokens=None):
+        """Batched ingest (new): rgb (F,H,W,C) u8, depth (F,H,W) f32 device tensors, poses (F,7).
+        Every pixel is ingested when depth_sample_rate == 1, otherwise the reference's shuffled sub-sampling
+        is drawn per frame.  Tokens default to self.dinov2.patch_tokens(rgb)."""
+        F = rgb.shape[0]
+        Ts = np.stack([self.chain.pc_transform(p) for p in np.asarray(poses, dtype=np.float64)])
+        if tokens is None:
+            tokens = self.dinov2.patch_tokens(rgb)
+        if self.depth_sample_rate == 1 and self.feature_mode != "exact":
+            self.engine.ingest(depth, rgb, tokens, Ts)
+            return
+        N = depth.shape[1] * depth.shape[2]
+        idxs = [sample_indices(N, self.depth_sample_rate) for _ in range(F)]
+        off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
+        self.engine.ingest(depth, rgb, tokens, Ts, torch.from_numpy(np.concatenate(idxs)).to(self.device), off)
+
+    # ------------------------------------------------------------------------------------------
+    def imaginary(self, text_prompts, vis=False):
+        """memory_2.py:258-276 — text -> images; the generator is an injected collaborator here."""
+        if self.imaginer is None:
+            raise RuntimeError("text prompts need an image generator: pass imaginer=callable(text, n) -> images "
+                               "(the reference uses Stable-Diffusion-3.5, memory_2.py:258-276)")
+        return self.imaginer(text_prompts, self.cfg.imagenary_num)
+
+    def _query_embedding(self, prompt):
+        """memory_2.py:566-608: prompt -> pooled (1,D) query on the device."""
+        if isinstance(prompt, torch.Tensor) and prompt.dim() <= 2:
+            return prompt.to(self.device, torch.float32).reshape(-1, self.token_dim)[:1].contiguous()
+        if isinstance(prompt, torch.Tensor) and prompt.dim() == 3:                 # (B,T,D) patch tokens
+            tokens = prompt.to(self.device, torch.float32).contiguous()
+        else:
+            if isinstance(prompt, str):
+                imgs = self.imaginary(prompt)
+                imgs = getattr(imgs, "images", imgs)
+                x = torch.stack([i if isinstance(i, torch.Tensor) else self.transform(i) for i in imgs])
+            elif isinstance(prompt, torch.Tensor):                                  # (B,3,H,W) already transformed
+                x = prompt
+            else:
+                x = torch.stack([self.transform(prompt)])
+            with torch.no_grad():
+                tokens = self.dinov2.forward_features(x.to(self.device))["x_norm_patchtokens"].float().contiguous()
+        return self.engine.pool_query(tokens).reshape(1, -1)
+
+    def voxel_localized(self, prompt, K=100, batch_size=300, region_radius=np.inf, curr_grid=None):
+        """memory_2.py:563-671 -> (top1 (1,3), positions (K,3) int64, similarities (K,) float64)."""
+        t1 = time.time()
+        q = self._query_embedding(prompt)
+        radius = None if region_radius == np.inf else float(region_radius)
+        floor = None
+        if getattr(self.args, "load_single_floor", False) and hasattr(self, "floor_min_height"):
+            floor = (self.floor_min_height, self.floor_max_height)
+        pos, sim, cnt = self.engine.localize(q, K=K, radius=radius, curr=curr_grid, floor=floor)
+        n = int(cnt[0])
+        if n == 0:
+            raise IndexError("list index out of range")          # the reference indexes top_k_positions[0]
+        top_pos = pos[0, :n].astype(np.int64)
+        top_sim = sim[0, :n].astype(np.float64)
+        self._log(f"finish localizing, time:{time.time() - t1}")
+        return np.array([top_pos[0]]), top_pos, top_sim
+
+    def long_memory_filter(self):
+        """memory_2.py:693-705."""
+        if getattr(self.args, "load_single_floor", False) and hasattr(self, "floor_min_height"):
+            return [o for o in self.long_memory_dict if self.floor_min_height <= o["loc"][2] <= self.floor_max_height]
+        return self.long_memory_dict
+
+    # ------------------------------------------------------------------------------------------
+    def save_memory(self, original_pos=None):
+        """The save block of exploring_create_memory (memory_2.py:1136-1145), plus the flat token store."""
+        path = self.memory_save_path
+        os.makedirs(path, exist_ok=True)
+        pos, rgb, w = self.engine.export_rgb()
+        if original_pos is None:
+            original_pos = getattr(getattr(self.Env, "original_state", None), "position", np.zeros(3))
+        store.save_rgb_state(path, pos, rgb, w, self.engine.export_occupied(), len(pos), original_pos, self.minh,
+                             self.maxh, self.base_height, self.long_memory_dict)
+        if self.feature_mode == "exact":
+            store.save_token_store(path, *self.engine.export_store())
+        else:
+            store.save_dense(path, *self.engine.export_dense())
+
+    def load_memory(self, init_state=None, build_map=False):
+        """memory_2.py:166-256."""
+        if self.Env is not None and hasattr(self.Env, "reset"):
+            self.Env.reset(self.args, init_state=init_state, build_map=build_map)
+        self.memory_save_path = getattr(self.args, "load_memory_path", self.memory_save_path)
+        self.base_height = []
+        if build_map:
+            self.engine.reset()
+            self.chain.reset()
+            return
+        path = self.memory_save_path
+        st = store.load_rgb_state(path)
+        if (st["minh"], st["maxh"]) != (self.minh, self.maxh):        # memory_2.py:200
+            self.minh, self.maxh = st["minh"], st["maxh"]
+            self.floor_height, self.map_height = self.minh * self.cs, self.maxh * self.cs
+            self._make_engine()
+        self.feat_path = path + "/feat.h5df"
+        self.engine.import_rgb(st["pos"], st["rgb"], st["weight"])
+        if self.feature_mode == "exact":
+            self.engine.import_store(*store.load_token_store(path))
+        else:
+            self.engine.import_dense(*store.load_dense(path))
+        self.long_memory_dict = st["long_memory"]
+        self.original_pos = st["original_pos"]
+        if self.Env is not None and hasattr(self.Env, "original_state"):
+            self.Env.original_state.position = st["original_pos"]
+        if getattr(self.args, "load_single_floor", False):
+            self.base_height = st["base_height"]
+            if self.Env is not None:
+                current_height = self.Env.agent.get_state().position[1]
+            else:
+                current_height = float(st["original_pos"][1])
+            self._select_floor(st["pos"], st["rgb"], current_height)
+
+    def _select_floor(self, grid_rgb_pos, grid_rgb, current_height):
+        """memory_2.py:202-252: DBSCAN over recorded base heights -> z-range of the current floor."""
+        from sklearn.cluster import DBSCAN
+        base = np.array(self.base_height).reshape(-1, 1)
+        min_samples = len(self.base_height) // 5 if len(self.base_height) // 5 > 0 else 1
+        clustering = DBSCAN(eps=0.4, min_samples=min_samples).fit(base)
+        floor_heights = []
+        for label in set(clustering.labels_):
+            if label != -1:
+                floor_heights.append(np.mean(base[clustering.labels_ == label]))
+        self.floor_heights = sorted(floor_heights)
+        self.num_floors = len(self.floor_heights)
+        current_floor = int(np.argmin(np.abs(np.array(self.floor_heights) - current_height)))
+        pos_range = [grid_rgb_pos[:, 2].min(), grid_rgb_pos[:, 2].max()]
+        if self.num_floors == 1:
+            rng = pos_range
+        else:
+            ranges = []
+            fh = self.floor_heights
+            for i in range(self.num_floors):
+                if i == 0:
+                    lo, hi = pos_range[0], pos_range[0] + (fh[1] - fh[0]) / self.cs
+                elif i == self.num_floors - 1:
+                    lo, hi = pos_range[0] + (fh[i] - fh[0]) / self.cs, pos_range[1]
+                else:
+                    lo, hi = pos_range[0] + (fh[i] - fh[0]) / self.cs, pos_range[0] + (fh[i + 1] - fh[0]) / self.cs
+                ranges.append([int(lo) + 1, int(hi) - 1])
+            rng = ranges[current_floor]
+        self.floor_min_height, self.floor_max_height = int(rng[0]), int(rng[1])
+        mask = np.logical_and(grid_rgb_pos[:, 2] >= self.floor_min_height, grid_rgb_pos[:, 2] <= self.floor_max_height)
+        np.save(self.memory_save_path + f"/grid_rgb_pos_floor_{current_floor}.npy", grid_rgb_pos[mask])
+        np.save(self.memory_save_path + f"/grid_rgb_floor_{current_floor}.npy", grid_rgb[mask])
+        return current_floor
+
+    # ------------------------------------------------------------------------------------------
+    # simulator-driven loops: thin restatements over an injected NavEnv-like `Env` (env.py:49-296)
+    def long_memory(self, obs):
+        """memory_2.py:905-945 needs the YOLO-World detector; out of scope of the hot path."""
+        return None
+
+    def excute(self, obs, actions):
+        """memory_2.py:1086-1101."""
+        for action in actions:
+            if action != "stop":
+                obs = self.Env.sims.step(action)
+                st = self.Env.agent.get_state()
+                pos, rot = st.position, st.rotation
+                pose = np.array([pos[0], pos[1], pos[2], rot.x, rot.y, rot.z, rot.w])
+                self.obs2voxeltoken(obs, pose)
+                self.long_memory(obs)
+        return obs
+
+    def exploring_create_memory(self):
+        """memory_2.py:1104-1145: random navigable goals + 360 degree sweeps, final flush, save."""
+        self.initial_memory()
+        obs = self.Env.sims.get_sensor_observations(0)
+        self.init_height = self.Env.agent.get_state().position[1]
+        pf = self.Env.plnner.pathfinder
+        for _ in range(int(self.cfg.random_move_num)):
+            subgoal = pf.get_random_navigable_point()
+            island_begin = pf.get_island(self.Env.agent.get_state().position)
+            while (not pf.is_navigable(subgoal)) or (pf.get_island(subgoal) != island_begin):
+                subgoal = pf.get_random_navigable_point()
+            try:
+                path, goal = self.Env.move2point(subgoal)
+                obs = self.excute(obs, path)
+                self.base_height.append(self.Env.agent.get_state().position[1])
+                obs = self.excute(obs, ["turn_left"] * int(360 / self.cfg.turn_left))
+            except Exception as e:   # the reference swallows move failures (memory_2.py:1126-1128)
+                self._log(f"move failed: {e}")
+                continue
+        if self.feature_mode == "exact":
+            self.update_memory_dist_base()
+        self.save_memory()
+
+    def create_memory(self):
+        raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop; use "
+                                  "exploring_create_memory() or feed frames through obs2voxeltoken()")

@@ -1,0 +1,105 @@
+"""The Python drop-in (VoxelTokenMemory) driven exactly like the reference drives its own class."""
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeDino:
+    """forward_features(x) -> the fixture's tokens for the current frame (the reference test harness did the same)."""
+
+    def __init__(self, tokens):
+        self.tokens, self.frame, self.query = tokens, 0, None
+
+    def forward_features(self, x):
+        import torch
+        if self.query is not None:
+            return {"x_norm_patchtokens": torch.from_numpy(self.query).cuda()}
+        t = torch.from_numpy(self.tokens[self.frame]).cuda()
+        return {"x_norm_patchtokens": t.reshape(1, -1, t.shape[-1])}
+
+
+def _memory(cfg, tokens, tmp, **kw):
+    import bsc_nav_amd as B
+    args = B.MemoryArgs(width=cfg["W"], height=cfg["H"], grid_size=cfg["gs"], cell_size=cfg["cs"],
+                        floor_height=cfg["floor_height"], map_height=cfg["map_height"], depth_sample_rate=cfg["s"],
+                        query_width=cfg["g"] * 14, query_height=cfg["g"] * 14, memory_path=str(tmp), scene_name="scene",
+                        token_dim=cfg["D"], iter_size=cfg.get("iter_size", 50000))
+    dino = FakeDino(tokens)
+    return B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False, alpha_source="host", **kw), dino, args
+
+
+@pytest.mark.parametrize("name", ["g2_mini_s7_yaw", "g2_c1_s1000", "g3_flush_small_cache"])
+def test_dropin_class_matches_reference_end_to_end(tmp_path, name):
+    import torch
+    z = gu.load(name)
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    mem, dino, args = _memory(cfg, tokens, tmp_path)
+    np.random.seed(cfg["seed"])
+    random.seed(cfg["seed"])
+    for f in range(cfg["F"]):
+        dino.frame = f
+        mem.obs2voxeltoken({"rgb": rgb[f], "depth": depth[f]}, poses[f])
+    assert mem.max_id == int(z["max_id"]) and mem.iter_id == int(z["iter_id"])
+    assert np.array_equal(mem.grid_rgb_pos, z["grid_rgb_pos"])
+    assert np.array_equal(mem.grid_rgb, z["grid_rgb"])          # host alpha == NumPy's exp: bit-exact bytes
+    assert np.array_equal(mem.weight, z["weight"])
+    mem.update_memory_dist_base()
+    pos, cnt, feats, dists = mem.engine.export_store()
+    assert np.array_equal(pos, z["store_pos"]) and np.array_equal(cnt, z["store_cnt"])
+    for q in gu.query_specs(z):
+        if q["floor"] is not None:
+            continue
+        dino.query = gu.query_tokens(q, cfg["seed"], cfg["D"], feats)
+        kw = {} if q["radius"] is None else dict(region_radius=q["radius"], curr_grid=q["curr"])
+        top1, tpos, tsim = mem.voxel_localized(torch.zeros(q["B"], 3, 8, 8), K=q["K"], **kw)
+        dino.query = None
+        assert top1.shape == (1, 3) and tpos.dtype == np.int64 and tsim.dtype == np.float64   # reference types
+        gu.assert_topk_matches(tpos, tsim, q["pos"], q["sim"], tol=5e-6)
+    # save in the reference's on-disk layout, reload into a fresh object, same answers
+    mem.initial_memory()
+    mem.save_memory(original_pos=np.zeros(3, np.float32))
+    d = mem.memory_save_path
+    assert np.load(d + "/grid_rgb_pos.npy").dtype == np.int32 and np.load(d + "/grid_rgb.npy").dtype == np.uint8
+    assert np.load(d + "/weight.npy").dtype == np.float32
+    occ = np.load(d + "/occupied_ids.npy")
+    assert occ.shape == (cfg["gs"], cfg["gs"], mem.maxh - mem.minh) and occ.dtype == np.int32
+    assert int(np.load(d + "/max_id.npy")) == int(z["max_id"])
+    assert list(np.load(d + "/map_height.npy")) == [mem.minh, mem.maxh]
+    assert os.path.exists(d + "/long_memory.json") and os.path.exists(d + "/feat_features.npy")
+    mem2, dino2, args2 = _memory(cfg, tokens, tmp_path)
+    args2.load_memory_path = d
+    mem2.load_memory()
+    q = next(gu.query_specs(z))
+    qt = torch.from_numpy(q["pooled"]).cuda()
+    a, b = mem.voxel_localized(qt, K=q["K"]), mem2.voxel_localized(qt, K=q["K"])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(mem2.occupied_ids, occ)
+
+
+def test_dataset_loop_with_random_vit(tmp_path):
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dataset, encoder
+    H, W = 96, 128
+    vit = encoder.RandomViT("vit_tiny_test", image_size=224).cuda()
+    args = B.MemoryArgs(width=W, height=H, grid_size=128, floor_height=-6.4, map_height=6.4, depth_sample_rate=1,
+                        query_width=224, query_height=224, patch_size=16, token_dim=vit.out_dim,
+                        memory_path=str(tmp_path))
+    scenes = [dataset.SyntheticScene("sceneA", 1, 12, H, W, batch=4), dataset.SyntheticScene("sceneB", 2, 8, H, W, batch=4)]
+    out = dataset.create_memory_for_dataset(args, scenes, vit, feature_mode="mean", voxel_capacity=200000)
+    for name, d in out.items():
+        n = int(np.load(d + "/max_id.npy"))
+        assert n > 500
+        acc, cnt = np.load(d + "/dense_acc.npy"), np.load(d + "/dense_cnt.npy")
+        assert acc.shape == (n, vit.out_dim) and cnt.sum() > H * W
+        assert np.isfinite(acc).all()
+    # second call finds the directories and loads instead of rebuilding (create_memory_for_dataset.py:103)
+    out2 = dataset.create_memory_for_dataset(args, scenes, vit, feature_mode="mean", voxel_capacity=200000)
+    assert out2 == out
