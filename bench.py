@@ -135,15 +135,16 @@ def main():
         U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per launch
         U_new = (c1["max_id"] - c0["max_id"]) / a.steps
         P_pass = (c1["points_passed"] - c0["points_passed"]) / a.steps
-        # algorithmic bytes of one k_dense_reduce launch: accumulator rows RMW (new rows
-        # are written only) + counts + token tile once + sorted keys and patch codes of the passing points
-        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * 4 + 12 * P_pass
+        n_pairs = (c1["pairs"] - c0["pairs"]) / a.steps
+        # algorithmic bytes of one k_dense_reduce launch: accumulator rows RMW (new rows are
+        # written only) + counts + token tile once + the sorted (voxel,frame,patch) pair list (key 8 B + count 4 B)
+        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * 4 + 12 * n_pairs
         ms = ks["ms"] / launches
         achieved = alg / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_dense_reduce", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "bytes_per_launch": alg, "ms_per_launch": ms, "voxel_rows_per_launch": U,
-                           "points_per_launch": P_pass}
+                           "points_per_launch": P_pass, "pairs_per_launch": n_pairs}
         # stage split
         torch.cuda.synchronize()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))

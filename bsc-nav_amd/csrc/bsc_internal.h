@@ -22,6 +22,11 @@ enum {
     DS_N_HITS = 8,      // flush: rows that met a full voxel
     DS_B_NSEG = 9,      // batch: voxel segments in the sorted point list
     DS_RMW_TOTAL = 10,  // dense: voxel rows read-modify-written since creation
+    DS_B_NPAIR = 11,    // batch: unique (voxel, frame, patch) pairs emitted by the tiles
+    DS_TMP0 = 12,       // bsc_counters scratch (store voxels / tokens)
+    DS_TMP1 = 13,
+    DS_B_NPSEG = 14,    // batch: voxel segments of the sorted pair list
+    DS_PAIR_TOTAL = 15, // dense: pairs reduced since creation
     DS_COUNT = 16
 };
 
@@ -57,14 +62,31 @@ struct bsc_ctx {
     // ---- per-batch scratch (max_points) ----
     int32_t *p_cell;
     uint32_t *p_patf;
-    uint32_t *p_rgbv;
+    uint32_t *p_rgbv_s[2];   // double-buffered: read by the rgb chain on the side stream
     float *p_r2f;
-    double *p_alpha;
+    double *p_alpha_s[2];
     int64_t *p_scan_in, *p_scan_out;
-    u64 *keys_a, *keys_b;
+    uint32_t *skey_a, *sval_a;          // point sort: key = voxel id, value = j (stable radix sort keeps j order)
+    uint32_t *skey_b_s[2], *sval_b_s[2];
+    int32_t *blk_cnt, *blk_off;         // per-block head counts / offsets (deterministic compaction)
+    int64_t nblk_cap;
+    u64 *f_keys_a, *f_keys_b;  // flush-private sort buffers (iter_size)
     int32_t *pass_list;
-    int32_t *seg_start;
-    int32_t *seg_last;
+    int32_t *seg_start_s[2];
+    int32_t *seg_last_s[2];
+    int64_t *bscal_s[2];       // per-set scalars: [0] voxel segments of the batch, [1] max_id before the batch
+    int cur_set;
+    hipStream_t side;          // rgb chain + top-down map run here, overlapped with the dense reduce / next encoder
+    hipEvent_t ev_ready[2], ev_done[2];
+    bool ev_done_valid[2];
+    u64 *pair_key_a, *pair_key_b;   // dense: voxel id << cb | frame << pb | patch
+    u64 *pstage_key;                // per-tile staging of the LDS-aggregated pairs
+    uint32_t *pstage_cnt;
+    int32_t *tile_cnt, *tile_off;
+    int64_t max_tiles;
+    uint32_t *pair_cnt_a, *pair_cnt_b;
+    int32_t *pseg_start;
+    int64_t pair_cap;
     double *d_transforms; // (max_frames,16)
     int64_t *d_offsets;   // (max_frames+1)
     int max_frames;
@@ -114,6 +136,10 @@ size_t prim_workspace_bytes(size_t max_items);
 bsc_status prim_sort_keys(bsc_ctx *x, const u64 *in, u64 *out, size_t n, int begin_bit, int end_bit);
 bsc_status prim_sort_pairs(bsc_ctx *x, const u64 *kin, u64 *kout, const uint32_t *vin, uint32_t *vout, size_t n,
                            int begin_bit, int end_bit);
+bsc_status prim_sort_pairs_onesweep(bsc_ctx *x, const u64 *kin, u64 *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                                    int begin_bit, int end_bit);
+bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                               size_t n, int begin_bit, int end_bit);
 bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
 bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
 bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
@@ -126,10 +152,17 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                         const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
                         bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
+bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels);
+bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames);
+// list of segment starts of a sorted key array (segments = runs of equal key >> shift; keys == invalid are skipped);
+// the number of segments is written to *count_dev.  Deterministic: per-block counts + exclusive scan.
+bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev);
+bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev);
 bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, double radius, const int32_t *curr,
                          int32_t floor_lo, int32_t floor_hi, int32_t *out_pos, float *out_sim, int32_t *out_count);
 bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out);
-bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the stream)
+bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the main stream)
+bsc_status sync_all(bsc_ctx *x);     // main + side stream
 // record the start / stop event of launch number ev_n[which] (ring; older launches are overwritten)
 static inline void stat_begin(bsc_ctx *x, int which)
 {

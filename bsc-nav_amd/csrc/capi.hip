@@ -22,6 +22,13 @@ void bsc_set_error(const char *fmt, ...)
 extern "C" const char *bsc_last_error(void) { return g_err; }
 extern "C" const char *bsc_version(void) { return "bscnav 0.1 (gfx950)"; }
 
+bsc_status sync_all(bsc_ctx *x)
+{
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    BSC_HIP(hipStreamSynchronize(x->side));
+    return BSC_OK;
+}
+
 bsc_status read_scalars(bsc_ctx *x)
 {
     BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->stream));
@@ -58,6 +65,8 @@ static void fill(bsc_ctx *x, T *p, int64_t n, T v)
 static bsc_status reset_state(bsc_ctx *x)
 {
     hipStream_t s = x->stream;
+    if (x->side) BSC_HIP(hipStreamSynchronize(x->side));
+    x->ev_done_valid[0] = x->ev_done_valid[1] = false;
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
     const int64_t vcap = x->c.voxel_capacity;
     fill<int32_t>(x, x->occ, x->ncell, -1);                                     // memory_2.py:717
@@ -137,21 +146,43 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         ALLOC(x->f_rowseg, c.iter_size); ALLOC(x->f_rowe, c.iter_size); ALLOC(x->f_headpos, c.iter_size);
         ALLOC(x->f_win, (int64_t)c.iter_size * c.cache_size);
         ALLOC(x->f_draws, c.iter_size);
+        ALLOC(x->f_keys_a, c.iter_size); ALLOC(x->f_keys_b, c.iter_size);
     } else {
         ALLOC(x->acc, vcap * D);
         ALLOC(x->acnt, vcap + 1);
     }
-    ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_rgbv, np); ALLOC(x->p_r2f, np); ALLOC(x->p_alpha, np);
+    ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->p_scan_in, np); ALLOC(x->p_scan_out, np);
-    ALLOC(x->keys_a, np); ALLOC(x->keys_b, np);
-    ALLOC(x->pass_list, np); ALLOC(x->seg_start, np); ALLOC(x->seg_last, np);
+    ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
+    x->nblk_cap = np / 1024 + 16;
+    ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
+    ALLOC(x->pass_list, np);
+    for (int k = 0; k < 2; ++k) {
+        ALLOC(x->p_rgbv_s[k], np); ALLOC(x->p_alpha_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
+        ALLOC(x->seg_start_s[k], np); ALLOC(x->seg_last_s[k], np); ALLOC(x->bscal_s[k], 4);
+        BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
+        BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
+    }
+    BSC_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
+    if (c.mode != BSC_MODE_EXACT) {
+        x->pair_cap = np;
+        ALLOC(x->pair_key_a, np); ALLOC(x->pair_key_b, np); ALLOC(x->pair_cnt_a, np); ALLOC(x->pair_cnt_b, np);
+        ALLOC(x->pseg_start, np);
+        const int64_t npix = (int64_t)c.height * c.width;
+        const int64_t fmax = (np + npix - 1) / npix;
+        const int64_t t2d = fmax * ((c.width + 31) / 32) * ((c.height + 31) / 32), t1d = (np + 1023) / 1024;
+        x->max_tiles = (t2d > t1d ? t2d : t1d) + 1;
+        ALLOC(x->pstage_key, x->max_tiles * 1024); ALLOC(x->pstage_cnt, x->max_tiles * 1024);
+        ALLOC(x->tile_cnt, x->max_tiles); ALLOC(x->tile_off, x->max_tiles);
+    }
     ALLOC(x->d_transforms, (int64_t)x->max_frames * 16);
     ALLOC(x->d_offsets, x->max_frames + 1);
     ALLOC(x->l_key_a, vcap + 1); ALLOC(x->l_key_b, vcap + 1);
     ALLOC(x->l_val_a, vcap + 1); ALLOC(x->l_val_b, vcap + 1);
     ALLOC(x->l_name_rank, vcap + 1);
     ALLOC(x->l_q, 1024 * D);
-    const int64_t prim_items = (np > vcap + 1) ? np : vcap + 1;
+    int64_t prim_items = (np > vcap + 1) ? np : vcap + 1;
+    if (x->max_tiles > prim_items) prim_items = x->max_tiles;
     x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
     hipError_t e = hipMalloc(&x->prim_tmp, x->prim_tmp_bytes);
     if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
@@ -169,15 +200,25 @@ extern "C" void bsc_destroy(bsc_ctx *x)
 {
     if (!x) return;
     hipSetDevice(x->device);
+    if (x->side) hipStreamSynchronize(x->side);
+    hipStreamSynchronize(x->stream);
     void *ptrs[] = {x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
-                    x->p_rgbv, x->p_r2f, x->p_alpha, x->p_scan_in, x->p_scan_out, x->keys_a, x->keys_b, x->pass_list,
-                    x->seg_start, x->seg_last, x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
+                    x->p_rgbv_s[0], x->p_rgbv_s[1], x->p_r2f, x->p_alpha_s[0], x->p_alpha_s[1], x->p_scan_in, x->p_scan_out,
+                    x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
+                    x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_start_s[0], x->seg_start_s[1],
+                    x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
+                    x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->prim_tmp};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
+    if (x->side) hipStreamDestroy(x->side);
+    for (int k = 0; k < 2; ++k) {
+        if (x->ev_ready[k]) hipEventDestroy(x->ev_ready[k]);
+        if (x->ev_done[k]) hipEventDestroy(x->ev_done[k]);
+    }
     for (int w = 0; w < 2; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i)
             if (x->ev[w][i]) hipEventDestroy(x->ev[w][i]);
@@ -246,17 +287,19 @@ extern "C" bsc_status bsc_counters(bsc_ctx *x, int64_t *out)
     if (!x || !out) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
     const int32_t *cnt = x->c.mode == BSC_MODE_EXACT ? x->store_cnt : x->acnt;
-    BSC_HIP(hipMemsetAsync(x->dscal + 12, 0, sizeof(int64_t) * 2, x->stream));
-    hipLaunchKernelGGL(k_store_totals, dim3(512), dim3(TPB), 0, x->stream, x->c.voxel_capacity + 1, cnt, x->dscal + 12);
+    BSC_HIP(hipMemsetAsync(x->dscal + DS_TMP0, 0, sizeof(int64_t) * 2, x->stream));
+    hipLaunchKernelGGL(k_store_totals, dim3(512), dim3(TPB), 0, x->stream, x->c.voxel_capacity + 1, cnt, x->dscal + DS_TMP0);
     BSC_TRY(read_scalars(x));
     out[0] = x->hscal[DS_MAX_ID];
     out[1] = x->iter_id;
-    out[2] = x->hscal[12];
-    out[3] = x->hscal[13];
+    out[2] = x->hscal[DS_TMP0];
+    out[3] = x->hscal[DS_TMP1];
     out[4] = x->n_flush;
     out[5] = x->hscal[DS_NPASS_TOTAL];
     out[6] = x->hscal[DS_NSEEN_TOTAL];
     out[7] = x->hscal[DS_RMW_TOTAL];
+    out[8] = x->hscal[DS_PAIR_TOTAL];
+    out[9] = x->hscal[DS_B_NPAIR];
     if (x->hscal[DS_ERROR]) {
         bsc_set_error("device capacity error flag %lld (1 voxel_capacity, 2 token_capacity)", (long long)x->hscal[DS_ERROR]);
         return BSC_E_CAPACITY;
@@ -301,6 +344,7 @@ extern "C" bsc_status bsc_export_rgb(bsc_ctx *x, int32_t *pos, uint8_t *rgb, flo
 {
     if (!x) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));
     BSC_TRY(read_scalars(x));
     const int64_t n = x->hscal[DS_MAX_ID];
     if (n == 0) return BSC_OK;
@@ -323,7 +367,7 @@ extern "C" bsc_status bsc_export_heightmap(bsc_ctx *x, double *max_height, uint8
 {
     if (!x) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
-    BSC_HIP(hipStreamSynchronize(x->stream));
+    BSC_TRY(sync_all(x));
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
     if (max_height) {
         u64 *h = (u64 *)malloc(sizeof(u64) * gs2);
@@ -622,6 +666,7 @@ extern "C" bsc_status bsc_dense_replace(bsc_ctx *x, int64_t n, const int32_t *ke
     BSC_HIP(hipSetDevice(x->device));
     hipStream_t s = x->stream;
     // the feature map is replaced; rgb / weight / top-down map stay rank-local (multi-GPU)
+    BSC_TRY(sync_all(x));
     fill<int32_t>(x, x->occ, x->ncell, -1);
     BSC_HIP(hipMemsetAsync(x->acnt, 0, sizeof(int32_t) * (x->c.voxel_capacity + 1), s));
     if (n > 0) {

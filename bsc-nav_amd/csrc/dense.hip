@@ -1,0 +1,403 @@
+// dense.hip — dense per-voxel feature reduce (mean / max modes): the HBM-bound heart of the ingest.
+//
+// Every pixel of a ViT patch carries the same token, so the unit of feature work is not the point but the
+// unique (voxel, frame, patch) PAIR with its multiplicity:
+//
+//   k_keys_pairs   one workgroup per tile of 1024 points (32x32 pixel tiles when every pixel is ingested,
+//                  1024 consecutive points otherwise).  Writes the (voxel id << 32 | j) sort key of the rgb
+//                  chain and aggregates the tile's (voxel, frame, patch) codes in an LDS hash table
+//                  (ds_cmpst_b64 insert + ds_add count); the distinct pairs are appended to a global list.
+//                  A 10 cm voxel 2 m away covers ~16x16 pixels, so a tile collapses 1024 points to a
+//                  handful of pairs.
+//   radix sort     of the pair list by (voxel, frame, patch) -> each voxel's pairs are contiguous and equal
+//                  codes coming from neighbouring tiles are adjacent.
+//   k_pair_heads   voxel segments of the sorted pair list.
+//   k_dense_reduce one wavefront per voxel: merges equal codes (integer multiplicities, so the result does
+//                  not depend on the order tiles were appended in), accumulates multiplicity x token row with
+//                  16-byte loads (lanes stride D, 1 KiB per wave-instruction, token tile L2 / MALL resident)
+//                  and performs exactly ONE read-modify-write of the voxel's (D,) f32 accumulator row.
+//
+// Algorithmic HBM bytes of k_dense_reduce per call: (2U - U_new) * D*4 + 8U + F*g^2*D*4 + 12 * n_pairs.
+#include "bsc_internal.h"
+
+#include <math.h>
+
+#define TPB 256
+#define PT_TILE 1024
+#define PT_HS 2048
+
+__device__ __forceinline__ u64 mix64(u64 x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 29;
+    return x;
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int H, int W, int tx_n, int ty_n,
+                                                    const int32_t *__restrict__ p_cell, const int32_t *__restrict__ occ,
+                                                    const uint32_t *__restrict__ p_patf, uint32_t *__restrict__ skey,
+                                                    uint32_t *__restrict__ sval, u64 *__restrict__ pstage_key,
+                                                    uint32_t *__restrict__ pstage_cnt, int32_t *__restrict__ tile_cnt,
+                                                    int pb, int cb)
+{
+    __shared__ u64 hkey[PAIRS ? PT_HS : 1];
+    __shared__ uint32_t hcnt[PAIRS ? PT_HS : 1];
+    __shared__ int nloc;
+    const int tid = threadIdx.x;
+    if (PAIRS) {
+        for (int s = tid; s < PT_HS; s += TPB) { hkey[s] = ~0ull; hcnt[s] = 0u; }
+        if (tid == 0) nloc = 0;
+        __syncthreads();
+    }
+    const int64_t tile = blockIdx.x;
+    int64_t jbase = tile * PT_TILE;
+    int x0 = 0, y0 = 0;
+    if (tiled2d) {
+        const int per_frame = tx_n * ty_n;
+        const int64_t f = tile / per_frame;
+        const int r = (int)(tile - f * per_frame);
+        y0 = (r / tx_n) * 32;
+        x0 = (r % tx_n) * 32;
+        jbase = f * (int64_t)H * W;
+    }
+    for (int l = tid; l < PT_TILE; l += TPB) {
+        int64_t j;
+        if (tiled2d) {
+            const int y = y0 + (l >> 5), x = x0 + (l & 31);
+            if (x >= W || y >= H) continue;
+            j = jbase + (int64_t)y * W + x;
+        } else {
+            j = jbase + l;
+            if (j >= P) continue;
+        }
+        const int32_t c = p_cell[j];
+        uint32_t key = 0xffffffffu;
+        u64 code = ~0ull;
+        if (c >= 0) {
+            const int32_t vid = occ[c];
+            if (vid >= 0) {
+                key = (uint32_t)vid;
+                if (PAIRS) {
+                    const uint32_t pf = p_patf[j];      // frame << 16 | patch  ->  voxel << cb | frame << pb | patch
+                    code = ((u64)(uint32_t)vid << cb) | ((u64)(pf >> 16) << pb) | (u64)(pf & 0xffffu);
+                }
+            }
+        }
+        if (PAIRS) {
+            // wave-level pre-aggregation: neighbouring pixels share (voxel, frame, patch), so one lane per
+            // distinct code inserts with the group's population instead of 64 conflicting LDS atomics
+            u64 todo = __ballot(code != ~0ull);
+            int rounds = 0;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const u64 lcode = __shfl(code, leader);
+                const u64 same = __ballot(code == lcode);
+                if ((threadIdx.x & 63) == leader) {
+                    uint32_t h = (uint32_t)mix64(lcode) & (PT_HS - 1);
+                    for (;;) {
+                        const u64 old = atomicCAS(&hkey[h], ~0ull, lcode);
+                        if (old == ~0ull || old == lcode) { atomicAdd(&hcnt[h], (uint32_t)__popcll(same)); break; }
+                        h = (h + 1) & (PT_HS - 1);
+                    }
+                }
+                todo &= ~same;
+                if (++rounds == 8) break;
+            }
+            if (todo & (1ull << (threadIdx.x & 63))) {      // scattered remainder (iid-like input): per-lane insert
+                uint32_t h = (uint32_t)mix64(code) & (PT_HS - 1);
+                for (;;) {
+                    const u64 old = atomicCAS(&hkey[h], ~0ull, code);
+                    if (old == ~0ull || old == code) { atomicAdd(&hcnt[h], 1u); break; }
+                    h = (h + 1) & (PT_HS - 1);
+                }
+            }
+        }
+        skey[j] = key;
+        sval[j] = (uint32_t)j;
+    }
+    if (PAIRS) {
+        // the tile's distinct pairs go to its private staging slice (no global same-address atomics);
+        // k_pair_compact packs the slices after an exclusive scan of the per-tile counts
+        __syncthreads();
+        for (int s = tid; s < PT_HS; s += TPB) {
+            const u64 code = hkey[s];
+            if (code != ~0ull) {
+                const int li = atomicAdd(&nloc, 1);
+                pstage_key[tile * PT_TILE + li] = code;
+                pstage_cnt[tile * PT_TILE + li] = hcnt[s];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) tile_cnt[tile] = nloc;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int32_t *__restrict__ tile_cnt,
+                                                      const int32_t *__restrict__ tile_off,
+                                                      const u64 *__restrict__ pstage_key,
+                                                      const uint32_t *__restrict__ pstage_cnt, u64 *__restrict__ pair_key,
+                                                      uint32_t *__restrict__ pair_cnt, int64_t pair_cap, int64_t *dscal)
+{
+    const int64_t tile = blockIdx.x;
+    const int n = tile_cnt[tile];
+    const int64_t off = tile_off[tile];
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        if (off + i < pair_cap) {
+            pair_key[off + i] = pstage_key[tile * PT_TILE + i];
+            pair_cnt[off + i] = pstage_cnt[tile * PT_TILE + i];
+        }
+    }
+    if (tile == n_tiles - 1 && threadIdx.x == 0) dscal[DS_B_NPAIR] = off + n;
+}
+
+// ---- deterministic compaction of segment heads: per-block counts, exclusive scan, per-block write --------------
+#define HB 1024   // elements per block
+template <typename K>
+__device__ __forceinline__ bool is_head(const K *__restrict__ keys, int64_t i, int64_t n, int shift, K invalid)
+{
+    if (i >= n) return false;
+    const K k = keys[i];
+    if (k == invalid) return false;
+    return i == 0 || (keys[i - 1] >> shift) != (k >> shift);
+}
+
+template <typename K>
+__global__ __launch_bounds__(TPB) void k_head_count(const K *__restrict__ keys, int64_t n, int shift, K invalid,
+                                                    int32_t *__restrict__ blk_cnt)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int t = 0; t < HB / TPB; ++t)
+        local += is_head(keys, (int64_t)blockIdx.x * HB + t * TPB + threadIdx.x, n, shift, invalid) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+}
+
+template <typename K>
+__global__ __launch_bounds__(TPB) void k_head_write(const K *__restrict__ keys, int64_t n, int shift, K invalid,
+                                                    const int32_t *__restrict__ blk_off, int32_t *__restrict__ out,
+                                                    int64_t *count_dev)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int32_t base = blk_off[blockIdx.x];
+    for (int t = 0; t < HB / TPB; ++t) {
+        const int64_t i = (int64_t)blockIdx.x * HB + t * TPB + threadIdx.x;
+        if (is_head(keys, i, n, shift, invalid)) out[base + atomicAdd(&cnt, 1)] = (int32_t)i;
+    }
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_dev = (int64_t)base + cnt;
+}
+
+template <typename K>
+static bsc_status compact_heads(bsc_ctx *x, const K *keys, int64_t n, int shift, K invalid, int32_t *out,
+                                int64_t *count_dev)
+{
+    const int64_t nb = (n + HB - 1) / HB;
+    if (nb > x->nblk_cap) { bsc_set_error("compact_heads: block table too small"); return BSC_E_CAPACITY; }
+    hipLaunchKernelGGL((k_head_count<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->blk_cnt);
+    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nb));
+    hipLaunchKernelGGL((k_head_write<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->blk_off,
+                       out, count_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev)
+{
+    return compact_heads<uint32_t>(x, keys, n, 0, 0xffffffffu, out, count_dev);
+}
+
+bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev)
+{
+    return compact_heads<u64>(x, keys, n, shift, ~0ull, out, count_dev);
+}
+
+template <int NV, int MODE>
+__device__ __forceinline__ void apply_run(float4 (&a)[NV], uint32_t code, uint32_t cnt, const float *__restrict__ tokens,
+                                          int g2, int D, int D4, int lane, int pb)
+{
+    const float mult = (float)cnt;
+    const float4 *row = (const float4 *)(tokens + ((int64_t)(code >> pb) * g2 + (code & ((1u << pb) - 1u))) * D);
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int v = lane + 64 * t;
+        if (v < D4) {
+            const float4 xv = row[v];
+            if (MODE == BSC_MODE_MAX) {
+                a[t].x = fmaxf(a[t].x, xv.x); a[t].y = fmaxf(a[t].y, xv.y);
+                a[t].z = fmaxf(a[t].z, xv.z); a[t].w = fmaxf(a[t].w, xv.w);
+            } else {
+                a[t].x = fmaf(mult, xv.x, a[t].x); a[t].y = fmaf(mult, xv.y, a[t].y);
+                a[t].z = fmaf(mult, xv.z, a[t].z); a[t].w = fmaf(mult, xv.w, a[t].w);
+            }
+        }
+    }
+}
+
+template <int NV, int MODE>
+__global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pkey, const uint32_t *__restrict__ pcnt,
+                                                      int64_t n_pairs, const int32_t *__restrict__ seg_start,
+                                                      const int64_t *dscal, const float *__restrict__ tokens, int g2,
+                                                      int D, float *__restrict__ acc, int32_t *__restrict__ acnt, int pb,
+                                                      int cb)
+{
+    const u64 cmask = (1ull << cb) - 1ull;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    const int64_t nseg = dscal[DS_B_NPSEG];
+    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
+    const int D4 = D >> 2;
+    for (int64_t s = wave; s < nseg; s += nwaves) {
+        const int64_t i0 = seg_start[s];
+        const uint32_t vid = (uint32_t)(pkey[i0] >> cb);
+        float4 a[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+            a[t] = (MODE == BSC_MODE_MAX) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t total = 0;
+        uint32_t pend_code = 0xffffffffu, pend_cnt = 0;     // run still open (may continue in the next 64 pairs)
+        for (int64_t base = i0;; base += 64) {
+            const int64_t k = base + lane;
+            const u64 key = (k < n_pairs) ? pkey[k] : ~0ull;
+            const bool inseg = (k < n_pairs) && ((uint32_t)(key >> cb) == vid);
+            const uint32_t code = inseg ? (uint32_t)(key & cmask) : 0xffffffffu;
+            const uint32_t cnt = inseg ? pcnt[k] : 0u;
+            const int n = __popcll(__ballot(inseg));
+            uint32_t ps = cnt;                               // inclusive prefix sum of the multiplicities
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(ps, o);
+                if (lane >= o) ps += t;
+            }
+            const uint32_t prev = __shfl_up(code, 1);
+            const bool head = inseg && (lane == 0 || code != prev);
+            u64 hm = __ballot(head);
+            while (hm) {
+                const int b = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                const int e = hm ? (__ffsll((long long)hm) - 1) : n;
+                const uint32_t run = __shfl(ps, e - 1) - (b > 0 ? __shfl(ps, b - 1) : 0u);
+                const uint32_t cc = __shfl(code, b);
+                if (cc == pend_code) {
+                    pend_cnt += run;
+                } else {
+                    if (pend_cnt) apply_run<NV, MODE>(a, pend_code, pend_cnt, tokens, g2, D, D4, lane, pb);
+                    pend_code = cc;
+                    pend_cnt = run;
+                }
+            }
+            if (n > 0) total += __shfl(ps, n - 1);
+            if (n < 64) break;
+        }
+        if (pend_cnt) apply_run<NV, MODE>(a, pend_code, pend_cnt, tokens, g2, D, D4, lane, pb);
+        const bool is_new = (int64_t)vid >= max_id_prev;
+        float4 *dst = (float4 *)(acc + (int64_t)vid * D);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            if (v < D4) {
+                float4 o = a[t];
+                if (!is_new) {
+                    const float4 old = dst[v];
+                    if (MODE == BSC_MODE_MAX) {
+                        o.x = fmaxf(o.x, old.x); o.y = fmaxf(o.y, old.y); o.z = fmaxf(o.z, old.z); o.w = fmaxf(o.w, old.w);
+                    } else {
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                }
+                dst[v] = o;
+            }
+        }
+        if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)total;
+    }
+}
+
+__global__ void k_dense_counters(int64_t *dscal)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        dscal[DS_RMW_TOTAL] += dscal[DS_B_NPSEG];
+        dscal[DS_PAIR_TOTAL] += dscal[DS_B_NPAIR];
+    }
+}
+
+static inline int code_patch_bits(const bsc_ctx *x) { return ceil_log2_u64((uint64_t)x->g2); }
+static inline int code_bits(const bsc_ctx *x, int n_frames) { return code_patch_bits(x) + ceil_log2_u64((uint64_t)n_frames); }
+
+template <int MODE>
+static void launch_dense(bsc_ctx *x, int64_t n_pairs, const float *tokens, int pb, int cb)
+{
+    const int D = x->c.token_dim;
+    const int nv = (D / 4 + 63) / 64;
+    const dim3 grid(256 * 8), block(TPB);
+#define LD(NV)                                                                                                          \
+    hipLaunchKernelGGL((k_dense_reduce<NV, MODE>), grid, block, 0, x->stream, x->pair_key_b, x->pair_cnt_b, n_pairs,    \
+                       x->pseg_start, x->dscal, tokens, x->g2, D, x->acc, x->acnt, pb, cb)
+    if (nv <= 1) LD(1);
+    else if (nv == 2) LD(2);
+    else if (nv == 3) LD(3);
+    else if (nv == 4) LD(4);
+    else LD(8);
+#undef LD
+}
+
+// point sort keys (voxel id, j) for every point; in the dense modes also the per-tile (voxel, frame, patch) pairs
+bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels)
+{
+    const bool pairs = x->c.mode != BSC_MODE_EXACT;
+    const int H = x->c.height, W = x->c.width;
+    const int tx_n = (W + 31) / 32, ty_n = (H + 31) / 32;
+    const int64_t tiles = all_pixels ? (int64_t)n_frames * tx_n * ty_n : (P + PT_TILE - 1) / PT_TILE;
+    if (pairs && tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
+    const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
+    const dim3 grid((unsigned)tiles), block(TPB);
+    if (pairs) {
+        hipLaunchKernelGGL((k_keys_pairs<true>), grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n,
+                           x->p_cell, x->occ, x->p_patf, x->skey_a, x->sval_a, x->pstage_key, x->pstage_cnt, x->tile_cnt,
+                           pb, cb);
+        BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
+        hipLaunchKernelGGL(k_pair_compact, grid, block, 0, x->stream, tiles, x->tile_cnt, x->tile_off, x->pstage_key,
+                           x->pstage_cnt, x->pair_key_a, x->pair_cnt_a, x->pair_cap, x->dscal);
+    } else {
+        hipLaunchKernelGGL((k_keys_pairs<false>), grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n,
+                           x->p_cell, x->occ, x->p_patf, x->skey_a, x->sval_a, (u64 *)nullptr, (uint32_t *)nullptr,
+                           (int32_t *)nullptr, pb, cb);
+    }
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames)
+{
+    hipStream_t s = x->stream;
+    BSC_TRY(read_scalars(x));                     // number of pairs of this call (one small readback)
+    if (x->hscal[DS_ERROR]) {
+        bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
+        return BSC_E_CAPACITY;
+    }
+    const int64_t n_pairs = x->hscal[DS_B_NPAIR];
+    if (n_pairs > x->pair_cap) {
+        bsc_set_error("pair list overflow (%lld > %lld)", (long long)n_pairs, (long long)x->pair_cap);
+        return BSC_E_CAPACITY;
+    }
+    if (n_pairs == 0) return BSC_OK;
+    const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
+    const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
+    BSC_TRY(prim_sort_pairs_onesweep(x, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, (size_t)n_pairs, 0,
+                                     cb + vid_bits));
+    BSC_TRY(compact_heads_u64(x, x->pair_key_b, n_pairs, cb, x->pseg_start, x->dscal + DS_B_NPSEG));
+    stat_begin(x, 0);
+    if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, tokens, pb, cb);
+    else launch_dense<BSC_MODE_MAX>(x, n_pairs, tokens, pb, cb);
+    stat_end(x, 0, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, pairs)
+    hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}

@@ -138,13 +138,13 @@ bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user)
     const dim3 block(TPB), grid((n + TPB - 1) / TPB), wgrid((unsigned)(((int64_t)n * 64 + TPB - 1) / TPB));
     const int ebits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
     hipLaunchKernelGGL(k_flush_keys, grid, block, 0, s, n, x->cache_pos, x->occ, x->c.grid_size, x->nh,
-                       x->c.voxel_capacity, x->keys_a);
-    BSC_TRY(prim_sort_keys(x, x->keys_a, x->keys_b, (size_t)n, 0, 20 + ebits));
-    hipLaunchKernelGGL(k_flush_heads, grid, block, 0, s, n, x->keys_b, x->f_hit /*tmp*/);
+                       x->c.voxel_capacity, x->f_keys_a);
+    BSC_TRY(prim_sort_keys(x, x->f_keys_a, x->f_keys_b, (size_t)n, 0, 20 + ebits));
+    hipLaunchKernelGGL(k_flush_heads, grid, block, 0, s, n, x->f_keys_b, x->f_hit /*tmp*/);
     BSC_TRY(prim_inclusive_max_i32(x, x->f_hit, x->f_headpos, (size_t)n));
-    hipLaunchKernelGGL(k_flush_plan, grid, block, 0, s, n, x->keys_b, x->f_headpos, x->store_cnt, x->store_rows, cs,
+    hipLaunchKernelGGL(k_flush_plan, grid, block, 0, s, n, x->f_keys_b, x->f_headpos, x->store_cnt, x->store_rows, cs,
                        x->dscal, x->c.token_capacity, x->f_rowdst, x->f_hit, x->f_rowseg, x->f_rowe);
-    hipLaunchKernelGGL(k_flush_counts, grid, block, 0, s, n, x->keys_b, x->f_headpos, x->store_cnt, cs);
+    hipLaunchKernelGGL(k_flush_counts, grid, block, 0, s, n, x->f_keys_b, x->f_headpos, x->store_cnt, cs);
     hipLaunchKernelGGL(k_flush_copy, wgrid, block, 0, s, n, x->f_rowdst, x->cache_f, x->cache_d, D, x->pool, x->pool_d);
     BSC_TRY(prim_exclusive_sum_i32(x, x->f_hit, x->f_hidx, (size_t)n));
     hipLaunchKernelGGL(k_flush_nhits, dim3(1), dim3(64), 0, s, n, x->f_hit, x->f_hidx, x->dscal);

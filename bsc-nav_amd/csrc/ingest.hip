@@ -7,13 +7,14 @@
 //   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
 //               first toucher of every still-empty cell                         (1 thread / point)
 //   k_flags + exclusive scan + k_assign      first-touch points get ids max_id + rank in order
-//   k_keys      sort key (voxel id << 32 | j)
-//   radix sort  groups the points of a voxel, in order; k_segheads lists the voxel segments
+//   k_keys_pairs (dense.hip) sort key = voxel id, value = j; LDS aggregation of (voxel, frame, patch) pairs
+//   radix sort  (stable, on the voxel id bits only) groups the points of a voxel in order; the segment
+//               starts are compacted deterministically (block counts + scan)
 //   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
 //               (h, order of the voxel's latest point)                        (1 wavefront / voxel)
 //   k_hwin      the winning voxel of each map cell writes its colour
-//   k_dense_reduce  per voxel: run-length (frame,patch) pairs x token rows -> one RMW of the
-//               D-float accumulator row                                       (1 wavefront / voxel)
+//   dense.hip   pair sort + k_dense_reduce: multiplicity x token rows -> one RMW of the D-float
+//               accumulator row per voxel                                     (1 wavefront / voxel)
 //   k_append    exact mode: token rows into the cache in order                (1 wavefront / row)
 #include "bsc_internal.h"
 #include "geometry_dev.h"
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__rest
     }
 }
 
-__global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_out, int64_t *dscal, int vcap)
+__global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_out, int64_t *dscal, int vcap,
+                         int64_t *bscal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int64_t tot = scan_out[P - 1] + scan_in[P - 1];
@@ -148,32 +150,10 @@ __global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_
     dscal[DS_NPASS_TOTAL] += npass;
     dscal[DS_NSEEN_TOTAL] += P;
     dscal[DS_B_NSEG] = 0;
-}
-
-__global__ __launch_bounds__(TPB) void k_keys(int64_t P, const int32_t *__restrict__ p_cell,
-                                              const int32_t *__restrict__ occ, u64 *__restrict__ keys)
-{
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= P) return;
-    const int32_t c = p_cell[j];
-    u64 key = ~0ull;
-    if (c >= 0) {
-        const int32_t vid = occ[c];
-        if (vid >= 0) key = ((u64)(uint32_t)vid << 32) | (u64)(uint32_t)j;
-    }
-    keys[j] = key;
-}
-
-// segment heads of the sorted (voxel id, order) list -> unordered list of segment start positions
-__global__ __launch_bounds__(TPB) void k_segheads(int64_t P, const u64 *__restrict__ keys, int32_t *__restrict__ seg_start,
-                                                  int64_t *dscal)
-{
-    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= P) return;
-    const u64 key = keys[i];
-    if (key == ~0ull) return;
-    if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == (uint32_t)(key >> 32)) return;
-    seg_start[atomicAdd((u64 *)&dscal[DS_B_NSEG], 1ull)] = (int32_t)i;
+    bscal[0] = 0;
+    bscal[1] = dscal[DS_MAX_ID_PREV];
+    dscal[DS_B_NPAIR] = 0;
+    dscal[DS_B_NPSEG] = 0;
 }
 
 // memory_2.py:888-903 — one WAVEFRONT per voxel walks that voxel's points of the batch in order.
@@ -183,7 +163,8 @@ __global__ __launch_bounds__(TPB) void k_segheads(int64_t P, const u64 *__restri
 // wave shuffles, lanes 0..2 carrying the R, G, B channels.  The same wave settles the top-down map:
 // `h >= max_height` in sequential order == max over (h, order), and a voxel's latest point is the last
 // element of its segment, so one atomicMax per voxel replaces one per point.
-__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict__ keys, const int64_t *dscal,
+__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const uint32_t *__restrict__ skey,
+                                               const uint32_t *__restrict__ sval, const int64_t *bscal,
                                                const int32_t *__restrict__ seg_start,
                                                const uint32_t *__restrict__ p_rgbv, const double *__restrict__ p_alpha,
                                                const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
@@ -194,11 +175,11 @@ __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict_
     const int ch = lane < 3 ? lane : 2;
     const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
-    const int64_t nseg = dscal[DS_B_NSEG];
-    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
+    const int64_t nseg = bscal[0];
+    const int64_t max_id_prev = bscal[1];
     for (int64_t s = wave; s < nseg; s += nwaves) {
         const int64_t i0 = seg_start[s];
-        const uint32_t vid = (uint32_t)(keys[i0] >> 32);
+        const uint32_t vid = skey[i0];
         const bool is_new = (int64_t)vid >= max_id_prev;
         float w = 0.f;
         uint32_t c = 0;
@@ -210,9 +191,8 @@ __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict_
         uint32_t last_j = 0;
         for (int64_t base = i0;; base += 64) {
             const int64_t k = base + lane;
-            const u64 key = (k < P) ? keys[k] : ~0ull;
-            const bool inseg = (key != ~0ull) && ((uint32_t)(key >> 32) == vid);
-            const uint32_t j = (uint32_t)key;
+            const bool inseg = (k < P) && (skey[k] == vid);
+            const uint32_t j = inseg ? sval[k] : 0u;
             const uint32_t rv = inseg ? p_rgbv[j] : 0u;
             const double al = inseg ? p_alpha[j] : 0.0;
             const int n = __popcll(__ballot(inseg));
@@ -245,15 +225,15 @@ __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const u64 *__restrict_
 }
 
 // top-down map colour: the voxel whose (h, order) won the cell writes the rgb of its latest point
-__global__ __launch_bounds__(TPB) void k_hwin(const int64_t *dscal, const u64 *__restrict__ keys,
+__global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const uint32_t *__restrict__ skey,
                                               const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_last,
                                               const int32_t *__restrict__ rgb_pos, const u64 *__restrict__ hmap,
                                               const uint32_t *__restrict__ p_rgbv, uint8_t *__restrict__ cv_map, int gs,
                                               int64_t order_base)
 {
-    const int64_t nseg = dscal[DS_B_NSEG];
+    const int64_t nseg = bscal[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * TPB) {
-        const uint32_t vid = (uint32_t)(keys[seg_start[s]] >> 32);
+        const uint32_t vid = skey[seg_start[s]];
         const uint32_t last_j = (uint32_t)seg_last[s];
         const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
         const int64_t rc = (int64_t)row * gs + col;
@@ -265,95 +245,6 @@ __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *dscal, const u64 *_
             cv_map[3 * rc + 2] = (uint8_t)((v >> 16) & 0xff);
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Dense feature reduce: one wavefront per voxel segment of the sorted point list.  The wave reads 64
-// sort keys at a time, run-length encodes their (frame, patch) codes with ballot/shuffle, and for every
-// run adds multiplicity x token row (lanes stride the D floats as float4, 1 KiB per wave-instruction).
-// The accumulator row is read and written exactly once per voxel per batch; token rows come from the
-// (F,g,g,D) tile that stays L2 / Infinity-Cache resident.
-template <int NV, int MODE>
-__global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ keys, int64_t P,
-                                                      const int32_t *__restrict__ seg_start, const int64_t *dscal,
-                                                      const uint32_t *__restrict__ p_patf,
-                                                      const float *__restrict__ tokens, int g2, int D,
-                                                      float *__restrict__ acc, int32_t *__restrict__ acnt)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
-    const int64_t nseg = dscal[DS_B_NSEG];
-    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
-    const int D4 = D >> 2;
-    for (int64_t s = wave; s < nseg; s += nwaves) {
-        const int64_t i0 = seg_start[s];
-        const uint32_t vid = (uint32_t)(keys[i0] >> 32);
-        float4 a[NV];
-#pragma unroll
-        for (int t = 0; t < NV; ++t)
-            a[t] = (MODE == BSC_MODE_MAX) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-        int count = 0;
-        for (int64_t base = i0;; base += 64) {
-            const int64_t k = base + lane;
-            const u64 key = (k < P) ? keys[k] : ~0ull;
-            const bool inseg = (key != ~0ull) && ((uint32_t)(key >> 32) == vid);
-            const uint32_t code = inseg ? p_patf[(uint32_t)key] : 0xffffffffu;
-            const int n = __popcll(__ballot(inseg));
-            const uint32_t prev = __shfl_up(code, 1);
-            const bool head = inseg && (lane == 0 || code != prev);
-            u64 hm = __ballot(head);
-            while (hm) {
-                const int b = __ffsll((long long)hm) - 1;
-                hm &= hm - 1;
-                const int e = hm ? (__ffsll((long long)hm) - 1) : n;
-                const float mult = (float)(e - b);
-                const uint32_t cc = __shfl(code, b);
-                const float4 *row = (const float4 *)(tokens + ((int64_t)(cc >> 16) * g2 + (cc & 0xffffu)) * D);
-#pragma unroll
-                for (int t = 0; t < NV; ++t) {
-                    const int v = lane + 64 * t;
-                    if (v < D4) {
-                        const float4 xv = row[v];
-                        if (MODE == BSC_MODE_MAX) {
-                            a[t].x = fmaxf(a[t].x, xv.x); a[t].y = fmaxf(a[t].y, xv.y);
-                            a[t].z = fmaxf(a[t].z, xv.z); a[t].w = fmaxf(a[t].w, xv.w);
-                        } else {
-                            a[t].x = fmaf(mult, xv.x, a[t].x); a[t].y = fmaf(mult, xv.y, a[t].y);
-                            a[t].z = fmaf(mult, xv.z, a[t].z); a[t].w = fmaf(mult, xv.w, a[t].w);
-                        }
-                    }
-                }
-            }
-            count += n;
-            if (n < 64) break;
-        }
-        const bool is_new = (int64_t)vid >= max_id_prev;
-        float4 *dst = (float4 *)(acc + (int64_t)vid * D);
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            const int v = lane + 64 * t;
-            if (v < D4) {
-                float4 o = a[t];
-                if (!is_new) {
-                    const float4 old = dst[v];
-                    if (MODE == BSC_MODE_MAX) {
-                        o.x = fmaxf(o.x, old.x); o.y = fmaxf(o.y, old.y); o.z = fmaxf(o.z, old.z); o.w = fmaxf(o.w, old.w);
-                    } else {
-                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                    }
-                }
-                dst[v] = o;
-            }
-        }
-        if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + count;
-    }
-}
-
-__global__ void k_rmw_count(int64_t *dscal)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) dscal[DS_RMW_TOTAL] += dscal[DS_B_NSEG];
 }
 
 // exact mode, memory_2.py:882-886: rows [row0, row0+n) of the token cache <- passing points [q0, q0+n)
@@ -412,23 +303,6 @@ bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *
     return BSC_OK;
 }
 
-template <int MODE>
-static void launch_dense(bsc_ctx *x, int64_t P, const float *tokens)
-{
-    const int D = x->c.token_dim;
-    const int nv = (D / 4 + 63) / 64;
-    const dim3 grid(256 * 8), block(TPB);
-#define LD(NV)                                                                                                        \
-    hipLaunchKernelGGL((k_dense_reduce<NV, MODE>), grid, block, 0, x->stream, x->keys_b, P, x->seg_start, x->dscal,   \
-                       x->p_patf, tokens, x->g2, D, x->acc, x->acnt)
-    if (nv <= 1) LD(1);
-    else if (nv == 2) LD(2);
-    else if (nv == 3) LD(3);
-    else if (nv == 4) LD(4);
-    else LD(8);
-#undef LD
-}
-
 bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
                         const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
                         bsc_draw_fn draw, void *user)
@@ -442,32 +316,41 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (P == 0) return BSC_OK;
     const dim3 block(TPB), grid((unsigned)((P + TPB - 1) / TPB));
     hipStream_t s = x->stream;
+    // scratch set of this call; the rgb chain of the call before last may still be reading it on the side stream
+    const int set = x->cur_set;
+    x->cur_set ^= 1;
+    if (x->ev_done_valid[set]) BSC_HIP(hipStreamWaitEvent(s, x->ev_done[set], 0));
+    uint32_t *p_rgbv = x->p_rgbv_s[set];
+    double *p_alpha = x->p_alpha_s[set];
+    uint32_t *skey_b = x->skey_b_s[set], *sval_b = x->sval_b_s[set];
     if (idx)
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
     GeomConst gc = make_geom_const(x);
     hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
-                       alpha, P, x->occ, x->p_cell, x->p_patf, x->p_rgbv, x->p_r2f, x->p_alpha);
+                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rgbv, x->p_r2f, p_alpha);
     hipLaunchKernelGGL(k_flags, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
     BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)P));
     hipLaunchKernelGGL(k_assign, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->p_scan_out, x->dscal,
                        x->c.voxel_capacity, x->c.grid_size, x->nh, x->rgb_pos, x->pass_list);
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity);
-    hipLaunchKernelGGL(k_keys, grid, block, 0, s, P, x->p_cell, x->occ, x->keys_a);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity,
+                       x->bscal_s[set]);
+    BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr));
     const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
-    BSC_TRY(prim_sort_keys(x, x->keys_a, x->keys_b, (size_t)P, 0, 32 + vid_bits));
-    hipLaunchKernelGGL(k_segheads, grid, block, 0, s, P, x->keys_b, x->seg_start, x->dscal);
+    // stable radix sort on the voxel id alone: points enter in order j, so each voxel's run stays in order
+    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, sval_b, (size_t)P, 0, vid_bits));
+    BSC_TRY(compact_heads_u32(x, skey_b, P, x->seg_start_s[set], x->bscal_s[set]));
+    // rgb chain + top-down map on the side stream: sequential-latency bound, so it overlaps the
+    // HBM-bound dense reduce of this call and whatever the caller enqueues next (the next batch's encoder)
+    BSC_HIP(hipEventRecord(x->ev_ready[set], s));
+    BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
     const dim3 wgrid(256 * 8);
-    hipLaunchKernelGGL(k_chain, wgrid, block, 0, s, P, x->keys_b, x->dscal, x->seg_start, x->p_rgbv, x->p_alpha,
-                       x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last, x->c.grid_size, x->order_base);
-    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, s, x->dscal, x->keys_b, x->seg_start, x->seg_last, x->rgb_pos, x->hmap,
-                       x->p_rgbv, x->cv_map, x->c.grid_size, x->order_base);
-    if (x->c.mode != BSC_MODE_EXACT) {
-        stat_begin(x, 0);
-        if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, P, tokens);
-        else launch_dense<BSC_MODE_MAX>(x, P, tokens);
-        stat_end(x, 0, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, points)
-        hipLaunchKernelGGL(k_rmw_count, dim3(1), dim3(64), 0, s, x->dscal);
-    }
+    hipLaunchKernelGGL(k_chain, wgrid, block, 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rgbv, p_alpha,
+                       x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size, x->order_base);
+    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], skey_b, x->seg_start_s[set],
+                       x->seg_last_s[set], x->rgb_pos, x->hmap, p_rgbv, x->cv_map, x->c.grid_size, x->order_base);
+    BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
+    x->ev_done_valid[set] = true;
+    if (x->c.mode != BSC_MODE_EXACT) BSC_TRY(dense_reduce_batch(x, tokens, n_frames));
     BSC_HIP(hipGetLastError());
     x->order_base += P;
     if (x->c.mode == BSC_MODE_EXACT) {

@@ -5,6 +5,9 @@
 #include <rocprim/rocprim.hpp>
 
 namespace {
+// small inputs (the pair list, ~1e5) would otherwise take rocPRIM's merge-sort path (~0.3 ms); onesweep is faster
+using onesweep_always = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::default_config, 2048>;
 struct max_i32 {
     __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; }
 };
@@ -17,6 +20,12 @@ size_t prim_workspace_bytes(size_t n)
     best = b > best ? b : best;
     rocprim::radix_sort_pairs(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, n, 0, 64, (hipStream_t)0);
+    best = b > best ? b : best;
+    rocprim::radix_sort_pairs<onesweep_always>(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const uint32_t *)nullptr,
+                                               (uint32_t *)nullptr, n, 0, 64, (hipStream_t)0);
+    best = b > best ? b : best;
+    rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                              (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0);
     best = b > best ? b : best;
     rocprim::exclusive_scan(nullptr, b, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, n,
                             rocprim::plus<int64_t>(), (hipStream_t)0);
@@ -48,6 +57,22 @@ bsc_status prim_sort_keys(bsc_ctx *x, const u64 *in, u64 *out, size_t n, int b0,
 
 bsc_status prim_sort_pairs(bsc_ctx *x, const u64 *kin, u64 *kout, const uint32_t *vin, uint32_t *vout, size_t n, int b0,
                            int b1)
+{
+    if (n == 0) return BSC_OK;
+    PRIM_CALL(rocprim::radix_sort_pairs(x->prim_tmp, bytes, kin, kout, vin, vout, n, b0, b1, x->stream));
+    return BSC_OK;
+}
+
+bsc_status prim_sort_pairs_onesweep(bsc_ctx *x, const u64 *kin, u64 *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                                    int b0, int b1)
+{
+    if (n == 0) return BSC_OK;
+    PRIM_CALL(rocprim::radix_sort_pairs<onesweep_always>(x->prim_tmp, bytes, kin, kout, vin, vout, n, b0, b1, x->stream));
+    return BSC_OK;
+}
+
+bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                               size_t n, int b0, int b1)
 {
     if (n == 0) return BSC_OK;
     PRIM_CALL(rocprim::radix_sort_pairs(x->prim_tmp, bytes, kin, kout, vin, vout, n, b0, b1, x->stream));

@@ -93,10 +93,10 @@ class VoxelEngine:
         _lib.check(self.lib.bsc_flush(self.h, self._draw, None))
 
     def counters(self):
-        out = np.zeros(8, np.int64)
+        out = np.zeros(10, np.int64)
         _lib.check(self.lib.bsc_counters(self.h, _hp(out)))
         keys = ["max_id", "iter_id", "store_voxels", "store_tokens", "flushes", "points_passed", "points_seen",
-                "voxel_rmw"]
+                "voxel_rmw", "pairs", "pairs_last_call"]
         return {k: int(v) for k, v in zip(keys, out)}
 
     def geometry(self, depth, transform, sample_idx=None):

@@ -90,8 +90,9 @@ bsc_status bsc_ingest(bsc_ctx *ctx, int32_t n_frames, const float *depth_dev, co
 bsc_status bsc_flush(bsc_ctx *ctx, bsc_draw_fn draw, void *user);
 
 /* counters (host sync): out[0]=max_id out[1]=iter_id out[2]=store voxels out[3]=store tokens
- * out[4]=flushes out[5]=points passed so far out[6]=points seen so far out[7]=voxel-row RMWs (dense) */
-bsc_status bsc_counters(bsc_ctx *ctx, int64_t *out8_host);
+ * out[4]=flushes out[5]=points passed so far out[6]=points seen so far out[7]=voxel-row RMWs (dense)
+ * out[8]=(voxel,frame,patch) pairs reduced so far (dense) out[9]=pairs of the last call */
+bsc_status bsc_counters(bsc_ctx *ctx, int64_t *out10_host);
 
 /* geometry only (utils.py:153-214, memory_2.py:864-875) for one frame, outputs to host; NULL skips.
  * vox is row,col,h before the -min_h shift; flags bit0 depth-valid, bit1 in-range, bit2 patch-in-range */

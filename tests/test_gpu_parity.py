@@ -265,8 +265,8 @@ def test_capacity_error_is_loud(torch_cuda):
     eng = _engine(cfg, mode="mean", voxel_capacity=100)
     T = B.PoseChain().pc_transform(poses[0])
     torch = torch_cuda
-    eng.ingest(torch.from_numpy(depth[:1]).cuda(), torch.from_numpy(rgb[:1]).cuda(), torch.from_numpy(tokens[:1]).cuda(),
-               T[None])
-    with pytest.raises(B._lib.BscError):
+    with pytest.raises(B._lib.BscError, match="capacity"):
+        eng.ingest(torch.from_numpy(depth[:1]).cuda(), torch.from_numpy(rgb[:1]).cuda(),
+                   torch.from_numpy(tokens[:1]).cuda(), T[None])
         eng.counters()
     eng.close()
