@@ -163,7 +163,11 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
         BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
     }
-    BSC_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // rgb chain: latency-bound, give it the highest priority the device offers
+        BSC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BSC_HIP(hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, hi));
+    }
     if (c.mode != BSC_MODE_EXACT) {
         x->pair_cap = np;
         ALLOC(x->pair_key_a, np); ALLOC(x->pair_key_b, np); ALLOC(x->pair_cnt_a, np); ALLOC(x->pair_cnt_b, np);

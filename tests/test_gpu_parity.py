@@ -270,3 +270,60 @@ def test_capacity_error_is_loud(torch_cuda):
                    torch.from_numpy(tokens[:1]).cuda(), T[None])
         eng.counters()
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["mean", "max"])
+def test_two_shard_merge_on_one_gpu_equals_single_map(torch_cuda, mode):
+    """The multi-GPU merge (dist.merge_dense_maps) uses bsc_dense_gather / bsc_dense_replace; exercise the same
+    calls with two engines on one GPU standing in for two ranks: union of keys, rows in union order, reduce,
+    replace — and compare with one engine that ingested every frame."""
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dist as bd
+    torch = torch_cuda
+    z = gu.load("g2_mini_s1")
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    N = cfg["H"] * cfg["W"]
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    d, c, t = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    full = _engine(cfg, mode=mode, max_points=N * cfg["F"], voxel_capacity=200000)
+    full.ingest(d, c, t, Ts)
+    half = cfg["F"] // 2
+    shards = []
+    for a, b in ((0, half), (half, cfg["F"])):
+        e = _engine(cfg, mode=mode, max_points=N * cfg["F"], voxel_capacity=200000)
+        e.ingest(d[a:b].contiguous(), c[a:b].contiguous(), t[a:b].contiguous(), Ts[a:b])
+        shards.append(e)
+    codes = [bd.pack_keys(e.keys_tensor()) for e in shards]
+    union = torch.unique(torch.cat(codes))
+    ukeys = bd.unpack_keys(union)
+    rows = [e.dense_gather(ukeys) for e in shards]
+    if mode == "max":
+        acc = torch.maximum(rows[0][0], rows[1][0])
+    else:
+        acc = rows[0][0] + rows[1][0]
+    cnt = rows[0][1] + rows[1][1]
+    shards[0].dense_replace(ukeys, acc, cnt)                     # "rank 0" now holds the merged map
+    macc, mcnt = shards[0].export_dense()
+    mpos = shards[0].export_rgb()[0]
+    facc, fcnt = full.export_dense()
+    fpos = full.export_rgb()[0]
+    order_m = np.lexsort((mpos[:, 2], mpos[:, 1], mpos[:, 0]))
+    order_f = np.lexsort((fpos[:, 2], fpos[:, 1], fpos[:, 0]))
+    assert np.array_equal(mpos[order_m], fpos[order_f])          # same voxel set
+    assert np.array_equal(mcnt[order_m], fcnt[order_f])          # counts exact
+    if mode == "max":
+        assert np.array_equal(macc[order_m], facc[order_f])
+    else:
+        np.testing.assert_allclose(macc[order_m], facc[order_f], rtol=1e-3, atol=1e-3)
+    # the merged map answers queries like the single map (scores 5e-6, ties in name order)
+    q = torch.from_numpy(gu.synth.make_query_tokens(9, 1, 4, cfg["D"])[0, :1]).cuda()
+    p1, s1, n1 = shards[0].localize(q, K=40)
+    p2, s2, n2 = full.localize(q, K=40)
+    gu.assert_topk_matches(p1[0, :n1[0]], s1[0, :n1[0]], p2[0, :n2[0]], s2[0, :n2[0]], tol=5e-6)
+    # sentinel (padding) keys of the union give neutral rows
+    pad = torch.tensor([[-1, -1, -1]], dtype=torch.int32, device="cuda")
+    a0, c0 = shards[1].dense_gather(pad)
+    assert int(c0[0]) == 0 and (torch.isinf(a0).all() if mode == "max" else (a0 == 0).all())
+    for e in shards + [full]:
+        e.close()
