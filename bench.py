@@ -28,6 +28,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+def pmc_traffic():
+    """HBM bytes per k_dense_reduce launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_ingest_kernels.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- gfx950 FETCH_SIZE counts wide
+    coalesced reads at half (MI355X_MICROARCH.md, HBM).  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_ingest_kernels.json")) as f:
+            k = json.load(f)["kernels"]["void k_dense_reduce<3, 1>"]
+        return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,7 +58,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap encoder(s+1) with ingest(s)")
     ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
     ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
-    ap.add_argument("--localize", action="store_true", help="also time localize top-K (reported in extra)")
+    ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurement")
     return ap.parse_args()
 
 
@@ -177,7 +189,7 @@ def main():
         ms = ks["ms"] / launches
         achieved = alg / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_dense_reduce", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                            "bytes_per_launch": alg, "ms_per_launch": ms, "voxel_rows_per_launch": U,
                            "points_per_launch": P_pass, "pairs_per_launch": n_pairs}
         # stage split
@@ -197,19 +209,36 @@ def main():
         out["stages"] = {"encoder_ms_per_step": enc_ms, "ingest_ms_per_step": ing_ms,
                          "encoder_tflops": vit.flops_per_frame() * a.batch / (enc_ms * 1e-3) / 1e12,
                          "voxels": c1["max_id"]}
-        if a.localize:
-            q = torch.randn(1, D, device="cuda")
-            eng.localize(q, K=100)
-            eng.kernel_stats(1, reset=True)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(10):
-                eng.localize(q, K=100)
-            torch.cuda.synchronize()
-            lat = (time.perf_counter() - t) / 10
-            ls = eng.kernel_stats(1)
-            out["localize"] = {"latency_ms": lat * 1e3, "cosine_ms": ls["ms"] / max(1, ls["launches"]),
-                               "cosine_GBs": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9, "voxels": c1["max_id"]}
+        if not a.no_localize:
+            # second half of the metric: localize top-K latency over a 2^20-voxel x D map (BASELINE configs[3]/[4] size)
+            V = 1 << 20
+            gL = 512
+            engL = B.VoxelEngine(H, W, gL, cs, -gL * cs / 2, gL * cs / 2, g, D, mode="mean", voxel_capacity=V + 8,
+                                 max_points=1024, device=local_rank)
+            gen = torch.Generator(device="cuda").manual_seed(5)
+            codes = torch.randperm(gL ** 3, device="cuda", generator=gen)[:V]
+            keys = torch.stack([codes // (gL * gL), (codes // gL) % gL, codes % gL], dim=1).to(torch.int32).contiguous()
+            rows = torch.randn((V, D), device="cuda", generator=gen)
+            engL.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
+            del rows
+            loc = {"voxels": V, "dim": D, "K": 100}
+            for Q in (1, 8):
+                q = torch.randn(Q, D, device="cuda", generator=gen)
+                engL.localize(q, K=100)
+                engL.kernel_stats(1, reset=True)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    engL.localize(q, K=100)
+                torch.cuda.synchronize()
+                lat = (time.perf_counter() - t) / reps
+                ls = engL.kernel_stats(1)
+                loc[f"q{Q}"] = {"latency_ms": lat * 1e3, "cosine_ms": ls["ms"] / max(1, ls["launches"]),
+                                "cosine_GBs": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9,
+                                "cosine_frac_of_hbm_peak": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["localize"] = loc
+            engL.close()
     # ---- CPU baseline: the plain-C oracle (port of the reference loop) on a bounded sample ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc

@@ -218,23 +218,33 @@ bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, 
     return compact_heads<u64>(x, keys, n, shift, ~0ull, out, count_dev);
 }
 
+// four runs at a time: all token-row loads (4 x NV x 16 B per lane) are in flight before the first FMA, so a voxel
+// with many (frame, patch) pairs pays the L2 / Infinity-Cache latency once per four rows instead of once per row
 template <int NV, int MODE>
-__device__ __forceinline__ void apply_run(float4 (&a)[NV], uint32_t code, uint32_t cnt, const float *__restrict__ tokens,
-                                          int g2, int D, int D4, int lane, int pb)
+__device__ __forceinline__ void apply_runs4(float4 (&a)[NV], const uint32_t (&code)[4], const uint32_t (&cnt)[4],
+                                            const float *__restrict__ tokens, int g2, int D, int D4, int lane, int pb)
 {
-    const float mult = (float)cnt;
-    const float4 *row = (const float4 *)(tokens + ((int64_t)(code >> pb) * g2 + (code & ((1u << pb) - 1u))) * D);
+    float4 xv[4][NV];
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        const int v = lane + 64 * t;
-        if (v < D4) {
-            const float4 xv = row[v];
-            if (MODE == BSC_MODE_MAX) {
-                a[t].x = fmaxf(a[t].x, xv.x); a[t].y = fmaxf(a[t].y, xv.y);
-                a[t].z = fmaxf(a[t].z, xv.z); a[t].w = fmaxf(a[t].w, xv.w);
-            } else {
-                a[t].x = fmaf(mult, xv.x, a[t].x); a[t].y = fmaf(mult, xv.y, a[t].y);
-                a[t].z = fmaf(mult, xv.z, a[t].z); a[t].w = fmaf(mult, xv.w, a[t].w);
+    for (int r = 0; r < 4; ++r) {
+        const float4 *row = (const float4 *)(tokens + ((int64_t)(code[r] >> pb) * g2 + (code[r] & ((1u << pb) - 1u))) * D);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            xv[r][t] = (v < D4) ? row[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mult = (float)cnt[r];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (MODE == BSC_MODE_MAX) {     // padding runs repeat run 0: max is idempotent
+                a[t].x = fmaxf(a[t].x, xv[r][t].x); a[t].y = fmaxf(a[t].y, xv[r][t].y);
+                a[t].z = fmaxf(a[t].z, xv[r][t].z); a[t].w = fmaxf(a[t].w, xv[r][t].w);
+            } else {                        // padding runs have multiplicity 0
+                a[t].x = fmaf(mult, xv[r][t].x, a[t].x); a[t].y = fmaf(mult, xv[r][t].y, a[t].y);
+                a[t].z = fmaf(mult, xv[r][t].z, a[t].z); a[t].w = fmaf(mult, xv[r][t].w, a[t].w);
             }
         }
     }
@@ -257,13 +267,23 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
     for (int64_t s = wave; s < nseg; s += nwaves) {
         const int64_t i0 = seg_start[s];
         const uint32_t vid = (uint32_t)(pkey[i0] >> cb);
+        // the accumulator row is fetched first so that its HBM latency hides behind the pair walk
+        const bool is_new = (int64_t)vid >= max_id_prev;
+        float4 *dst = (float4 *)(acc + (int64_t)vid * D);
+        float4 old[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            old[t] = (!is_new && v < D4) ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int32_t old_cnt = (!is_new && lane == 0) ? acnt[vid] : 0;
         float4 a[NV];
 #pragma unroll
         for (int t = 0; t < NV; ++t)
             a[t] = (MODE == BSC_MODE_MAX) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t total = 0;
-        uint32_t pend_code = 0xffffffffu, pend_cnt = 0;     // run still open (may continue in the next 64 pairs)
+        uint32_t pend_code = 0, pend_cnt = 0;               // run still open (may continue in the next 64 pairs)
         for (int64_t base = i0;; base += 64) {
             const int64_t k = base + lane;
             const u64 key = (k < n_pairs) ? pkey[k] : ~0ull;
@@ -280,43 +300,75 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
             const uint32_t prev = __shfl_up(code, 1);
             const bool head = inseg && (lane == 0 || code != prev);
             u64 hm = __ballot(head);
-            while (hm) {
-                const int b = __ffsll((long long)hm) - 1;
-                hm &= hm - 1;
-                const int e = hm ? (__ffsll((long long)hm) - 1) : n;
-                const uint32_t run = __shfl(ps, e - 1) - (b > 0 ? __shfl(ps, b - 1) : 0u);
-                const uint32_t cc = __shfl(code, b);
-                if (cc == pend_code) {
-                    pend_cnt += run;
+            // multiplicity of the run that starts at this lane (equal codes are adjacent after the sort)
+            const u64 above = (lane == 63) ? 0ull : (hm & (~0ull << (lane + 1)));
+            int e = above ? (__ffsll((long long)above) - 1) : n;
+            e = e < 1 ? 1 : e;
+            const uint32_t upto = __shfl(ps, e - 1);
+            uint32_t before = __shfl_up(ps, 1);
+            if (lane == 0) before = 0;
+            uint32_t run_cnt = head ? (upto - before) : 0u;
+            if (pend_cnt) {
+                const uint32_t c0 = __shfl(code, 0);
+                if (n > 0 && c0 == pend_code) {
+                    if (lane == 0) run_cnt += pend_cnt;     // the open run continues in this chunk
                 } else {
-                    if (pend_cnt) apply_run<NV, MODE>(a, pend_code, pend_cnt, tokens, g2, D, D4, lane, pb);
-                    pend_code = cc;
-                    pend_cnt = run;
+                    const uint32_t cc[4] = {pend_code, pend_code, pend_code, pend_code};
+                    const uint32_t rc[4] = {pend_cnt, 0u, 0u, 0u};
+                    apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
                 }
+                pend_cnt = 0;
+            }
+            if (n == 64) {                                   // the last run of a full chunk may continue
+                const int lh = 63 - __clzll((long long)hm);
+                pend_code = __shfl(code, lh);
+                pend_cnt = __shfl(run_cnt, lh);
+                hm &= ~(1ull << lh);
+            }
+            while (hm) {
+                uint32_t cc[4], rc[4];
+                int b = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                cc[0] = __shfl(code, b);
+                rc[0] = __shfl(run_cnt, b);
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    if (hm) {
+                        b = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        cc[r] = __shfl(code, b);
+                        rc[r] = __shfl(run_cnt, b);
+                    } else {
+                        cc[r] = cc[0];
+                        rc[r] = 0u;
+                    }
+                }
+                apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
             }
             if (n > 0) total += __shfl(ps, n - 1);
             if (n < 64) break;
         }
-        if (pend_cnt) apply_run<NV, MODE>(a, pend_code, pend_cnt, tokens, g2, D, D4, lane, pb);
-        const bool is_new = (int64_t)vid >= max_id_prev;
-        float4 *dst = (float4 *)(acc + (int64_t)vid * D);
+        if (pend_cnt) {
+            const uint32_t cc[4] = {pend_code, pend_code, pend_code, pend_code};
+            const uint32_t rc[4] = {pend_cnt, 0u, 0u, 0u};
+            apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
+        }
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int v = lane + 64 * t;
             if (v < D4) {
                 float4 o = a[t];
                 if (!is_new) {
-                    const float4 old = dst[v];
                     if (MODE == BSC_MODE_MAX) {
-                        o.x = fmaxf(o.x, old.x); o.y = fmaxf(o.y, old.y); o.z = fmaxf(o.z, old.z); o.w = fmaxf(o.w, old.w);
+                        o.x = fmaxf(o.x, old[t].x); o.y = fmaxf(o.y, old[t].y); o.z = fmaxf(o.z, old[t].z); o.w = fmaxf(o.w, old[t].w);
                     } else {
-                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                        o.x += old[t].x; o.y += old[t].y; o.z += old[t].z; o.w += old[t].w;
                     }
                 }
                 dst[v] = o;
             }
         }
-        if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)total;
+        if (lane == 0) acnt[vid] = old_cnt + (int32_t)total;
     }
 }
 
