@@ -69,11 +69,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU")
+    backend = os.environ.get("BSC_BENCH_BACKEND", "nccl")      # "gloo" only to exercise the N>1 path on a 1-GPU box
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import bsc_nav_amd as B
     from bsc_nav_amd import synthetic, encoder, dist as bdist
 
@@ -139,6 +145,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    bdist.warmup_collectives(torch.device("cuda", local_rank))
     for b in range(NBUF):
         tok_free[b].record(main_stream)
     for s in range(a.warmup):
@@ -155,7 +162,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ks = eng.kernel_stats(0)

@@ -51,20 +51,31 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _all_gather(t, group=None):
+    """dist.all_gather -> list of tensors; gloo has no device all_gather, so device tensors are staged through the
+    host there (gloo is only used by the CPU / single-GPU tests, RCCL takes the direct path)."""
+    rank, world = _world(group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        bufs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(bufs, h, group=group)
+        return [b.to(t.device) for b in bufs]
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t, group=group)
+    return bufs
+
+
 def all_gather_ragged(t, group=None):
     """All-gather of 1-D tensors of different lengths -> list of tensors (one per rank)."""
     rank, world = _world(group)
     if world == 1:
         return [t]
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(s.item()) for s in _all_gather(n, group)]
     m = max(sizes + [1])
     pad = torch.zeros(m, dtype=t.dtype, device=t.device)
     pad[:t.numel()] = t
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
+    bufs = _all_gather(pad, group)
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
@@ -88,8 +99,8 @@ def reduce_scatter_rows(rows, op, per, group=None):
         return rows
     out = torch.empty((per,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     backend = dist.get_backend(group)
-    if backend == "gloo":                           # CPU test path: gloo has no reduce_scatter
-        full = rows.clone()
+    if backend == "gloo":                           # test path: gloo has no reduce_scatter (and no int32 max on device)
+        full = rows.cpu().clone()
         dist.all_reduce(full, op=op, group=group)
         out.copy_(full[rank * per:(rank + 1) * per])
     else:
@@ -141,10 +152,8 @@ def localize_sharded(engine, q, K=100, radius=None, curr=None, floor=None, group
     rec[..., :3] = torch.from_numpy(pos.astype(np.float64)).to(dev)
     rec[..., 3] = torch.from_numpy(sim.astype(np.float64)).to(dev)
     n = torch.from_numpy(cnt.astype(np.int64)).to(dev)
-    recs = [torch.empty_like(rec) for _ in range(world)]
-    ns = [torch.empty_like(n) for _ in range(world)]
-    dist.all_gather(recs, rec, group=group)
-    dist.all_gather(ns, n, group=group)
+    recs = _all_gather(rec, group)
+    ns = _all_gather(n, group)
     out_p, out_s = [], []
     for qi in range(Q):
         pl, sl = [], []
@@ -157,6 +166,21 @@ def localize_sharded(engine, q, K=100, radius=None, curr=None, floor=None, group
         out_p.append(p)
         out_s.append(s)
     return out_p, out_s
+
+
+def warmup_collectives(device, group=None):
+    """Run every collective merge_dense_maps / localize_sharded use once on small buffers, so that RCCL's
+    communicator and protocol setup (seconds on first use) is not charged to the first real merge."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    all_gather_ragged(torch.arange(rank + 1, dtype=torch.int64, device=device), group)
+    for dt in (torch.float32, torch.int32):
+        rows = torch.ones((world * 4, 8), dtype=dt, device=device)
+        reduce_scatter_rows(rows, dist.ReduceOp.SUM, 4, group)
+    reduce_scatter_rows(torch.ones((world * 4, 8), dtype=torch.float32, device=device), dist.ReduceOp.MAX, 4, group)
+    _all_gather(torch.zeros((2, 4), dtype=torch.float64, device=device), group)
+    _all_gather(torch.zeros(2, dtype=torch.int64, device=device), group)
 
 
 def shard_frames(n_frames, group=None):

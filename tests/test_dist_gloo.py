@@ -64,6 +64,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bsc_nav_amd import dist as bd
     D = 8
+    bd.warmup_collectives(torch.device("cpu"))      # the collectives bench.py warms up before its clock starts
     keys, acc, cnt = _make_rank_map(rank, D, mode)
     eng = DictEngine(mode, D, keys, acc, cnt)
     info = bd.merge_dense_maps(eng)
