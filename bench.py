@@ -43,9 +43,9 @@ def pmc_traffic():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step (per rank)")
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (per rank); 16 steps x 64 = 1024 frames")
     ap.add_argument("--kind", default="room", choices=["room", "iid"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")
@@ -90,7 +90,7 @@ def main():
     N = H * W
     n_steps = a.steps + a.warmup
     n_frames = n_steps * a.batch
-    vcap = 3_000_000 if a.kind == "room" else min(60_000_000, max(3_000_000, n_frames * N // 2))
+    vcap = 3_000_000 if a.kind == "room" else min(gs ** 3, max(3_000_000, n_frames * N))
     # the ingest is the latency-critical stage of the pipeline: its stream (and the library's side stream) are
     # high priority, the MFMA-bound encoder fills the rest of the machine from a normal-priority stream
     ing_stream = torch.cuda.Stream(priority=-1 if a.priority else 0)
@@ -252,7 +252,7 @@ def main():
         oc = orc.make_config(H, W, gs, cs, -half, half, g, D, mode=1 if a.mode == "mean" else 2)
         om = orc.OracleMemory(oc, voxel_capacity=2_000_000)
         host = []
-        for s in range(min(n_steps, 16)):               # up to 256 frames staged on the host, outside the CPU clock
+        for s in range(min(n_steps, 4)):                # up to 256 frames staged on the host, outside the CPU clock
             host.append((vit.patch_tokens(rgbs[s]).cpu().numpy(), rgbs[s].cpu().numpy(), depths[s].cpu().numpy()))
         nf, cdt = 0, 0.0
         for s, (tok_h, rgb_h, dep_h) in enumerate(host):

@@ -9,7 +9,7 @@ final-LayerNorm'd patch tokens, reshaped (g, g, D) and indexed [py, px].
 trunc_normal(0.02) weights.  Its dense GEMMs run on MFMA through PyTorch-ROCm (hipBLASLt) in bf16;
 outputs are returned in fp32 for the voxel kernels.
 """
-import math
+import ctypes as C
 
 import torch
 import torch.nn as nn
@@ -36,18 +36,24 @@ class _Block(nn.Module):
         self.fc1 = nn.Linear(width, mlp)
         self.fc2 = nn.Linear(mlp, width)
 
-    def forward(self, x):
-        B, T, C = x.shape
-        qkv = self.qkv(self.ln1(x)).reshape(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+    def attn(self, y):
+        B, T, C = y.shape
+        qkv = self.qkv(y).reshape(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-        x = x + self.proj(a.transpose(1, 2).reshape(B, T, C))
-        x = x + self.fc2(F.gelu(self.fc1(self.ln2(x))))
-        return x
+        return self.proj(a.transpose(1, 2).reshape(B, T, C))
+
+    def mlp(self, y, fuse_gelu):
+        if fuse_gelu:       # bias + GELU(tanh) in the GEMM epilogue (hipBLASLt)
+            B, T, C = y.shape
+            h = torch._addmm_activation(self.fc1.bias, y.reshape(B * T, C), self.fc1.weight.t(), use_gelu=True)
+            return self.fc2(h).reshape(B, T, C)
+        return self.fc2(F.gelu(self.fc1(y), approximate="tanh"))
 
 
 class RandomViT(nn.Module):
-    def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16):
+    def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16, fused=True):
         super().__init__()
+        self.fused = fused
         s = VIT_SHAPES[arch]
         self.arch, self.image_size, self.patch = arch, image_size, s["patch"]
         self.grid = image_size // s["patch"]
@@ -93,12 +99,38 @@ class RandomViT(nn.Module):
         t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
         if self.reg is not None:
             t = torch.cat([t[:, :1], self.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
-        for blk in self.blocks:
-            t = blk(t)
-        t = self.norm(t)[:, 1 + self.registers:]
+        # pre-LN transformer with every residual add fused into the LayerNorm that follows it
+        fuse = self.fused and t.is_cuda and t.dtype == torch.bfloat16 and self.width % 256 == 0
+        t = t.contiguous()
+        t, y = self._add_ln(t, None, self.blocks[0].ln1, fuse)
+        for i, blk in enumerate(self.blocks):
+            t, y = self._add_ln(t, blk.attn(y), blk.ln2, fuse)
+            nxt = self.blocks[i + 1].ln1 if i + 1 < len(self.blocks) else self.norm
+            t, y = self._add_ln(t, blk.mlp(y, fuse), nxt, fuse)
+        t = y[:, 1 + self.registers:]
         if self.head is not None:
             t = self.head(t)
         return {"x_norm_patchtokens": t.float()}
+
+    def _add_ln(self, x, delta, ln, fuse):
+        """(x + delta, LayerNorm(x + delta)); one HIP kernel (bsc_enc_add_layernorm) when `fuse`."""
+        if not fuse:
+            if delta is not None:
+                x = x + delta
+            return x, ln(x)
+        from . import _lib
+        lib = _lib.load()
+        B, T, Cw = x.shape
+        y = torch.empty_like(x)
+        xout = torch.empty_like(x) if delta is not None else x
+        if delta is not None:
+            delta = delta.contiguous()
+        _lib.check(lib.bsc_enc_add_layernorm(
+            C.c_void_p(x.data_ptr()), None if delta is None else C.c_void_p(delta.data_ptr()),
+            C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()),
+            None if delta is None else C.c_void_p(xout.data_ptr()), C.c_void_p(y.data_ptr()), B * T, Cw,
+            float(ln.eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return xout, y
 
     @torch.no_grad()
     def patch_tokens(self, rgb):

@@ -137,6 +137,12 @@ bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, c
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
 bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
 
+/* Encoder helper (stateless, bf16): s = x + delta ; y = LayerNorm(s)*gamma + beta, one pass over the (rows,width)
+ * token matrix.  delta/xout may be NULL (plain LayerNorm).  Fuses the residual add and the LayerNorm that sit
+ * between the library GEMMs of the ViT patch-feature provider (memory_2.py:738).  width % 256 == 0, <= 2048. */
+bsc_status bsc_enc_add_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev, const void *beta_dev,
+                                 void *xout_dev, void *y_dev, int64_t rows, int32_t width, float eps, void *hip_stream);
+
 /* HIP-event timing of the dominant kernel of each path, recorded on the ctx stream around every launch
  * (which 0: dense feature reduce of bsc_ingest, 1: cosine scan of bsc_localize).
  * out[0]=ms summed over the covered launches, out[1]=launches covered (ring of 512), out[2]=algorithmic

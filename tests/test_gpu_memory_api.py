@@ -103,3 +103,34 @@ def test_dataset_loop_with_random_vit(tmp_path):
     # second call finds the directories and loads instead of rebuilding (create_memory_for_dataset.py:103)
     out2 = dataset.create_memory_for_dataset(args, scenes, vit, feature_mode="mean", voxel_capacity=200000)
     assert out2 == out
+
+
+def test_fused_encoder_ops_match_pytorch():
+    """bsc_enc_add_layernorm (+ GELU in the GEMM epilogue) against the same ViT evaluated with plain PyTorch ops."""
+    import torch
+    from bsc_nav_amd import encoder
+    torch.manual_seed(0)
+    vit = encoder.RandomViT("vit_b16", seed=3).cuda()
+    for ln in [m for m in vit.modules() if isinstance(m, torch.nn.LayerNorm)]:   # non-trivial affine parameters
+        ln.weight.data = (1 + 0.1 * torch.randn_like(ln.weight.float())).to(ln.weight.dtype)
+        ln.bias.data = (0.1 * torch.randn_like(ln.bias.float())).to(ln.bias.dtype)
+    rgb = torch.randint(0, 255, (3, 96, 128, 4), dtype=torch.uint8, device="cuda")
+    vit.fused = True
+    a = vit.patch_tokens(rgb)
+    vit.fused = False
+    b = vit.patch_tokens(rgb)
+    assert a.shape == (3, 14, 14, 768) and torch.isfinite(a).all()
+    # bf16 activations: agreement to bf16 resolution of O(1) LayerNorm outputs
+    assert (a - b).abs().max().item() < 0.15
+    assert (a - b).abs().mean().item() < 0.01
+    # the kernel alone, against torch in fp32, is tight
+    x = torch.randn(1000, 768, device="cuda").bfloat16()
+    d = torch.randn(1000, 768, device="cuda").bfloat16()
+    ln = torch.nn.LayerNorm(768, eps=1e-6).cuda().bfloat16()
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.uniform_(-0.5, 0.5)
+    xo, y = vit._add_ln(x.view(1, 1000, 768), d.view(1, 1000, 768), ln, True)
+    s_ref = (x + d)
+    y_ref = torch.nn.functional.layer_norm(s_ref.float(), (768,), ln.weight.float(), ln.bias.float(), 1e-6)
+    assert torch.equal(xo.view(1000, 768), s_ref)
+    assert (y.view(1000, 768).float() - y_ref).abs().max().item() < 0.02     # one bf16 rounding of |y| <~ 4
