@@ -429,19 +429,14 @@ bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixel
 bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames)
 {
     hipStream_t s = x->stream;
-    BSC_TRY(read_scalars(x));                     // number of pairs of this call (one small readback)
-    if (x->hscal[DS_ERROR]) {
-        bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
-        return BSC_E_CAPACITY;
-    }
-    const int64_t n_pairs = x->hscal[DS_B_NPAIR];
+    const int64_t n_pairs = x->hscal[DS_B_NPAIR];   // read back by ingest_batch after the front end
     if (n_pairs > x->pair_cap) {
         bsc_set_error("pair list overflow (%lld > %lld)", (long long)n_pairs, (long long)x->pair_cap);
         return BSC_E_CAPACITY;
     }
     if (n_pairs == 0) return BSC_OK;
     const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
-    const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
+    const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 1);
     BSC_TRY(prim_sort_pairs_onesweep(x, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, (size_t)n_pairs, 0,
                                      cb + vid_bits));
     BSC_TRY(compact_heads_u64(x, x->pair_key_b, n_pairs, cb, x->pseg_start, x->dscal + DS_B_NPSEG));

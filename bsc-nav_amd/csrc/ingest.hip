@@ -335,7 +335,15 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity,
                        x->bscal_s[set]);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr));
-    const int vid_bits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 1);
+    // one small readback per call: voxel count (sort width), pair count (dense modes), passing points (exact mode),
+    // capacity flag.  Everything enqueued so far is the call's front end; the back end is sized from these numbers.
+    BSC_TRY(read_scalars(x));
+    if (x->hscal[DS_ERROR]) {
+        bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
+        return BSC_E_CAPACITY;
+    }
+    // ids in use are < max_id; invalid points carry 0xffffffff, which must still sort last under the bit mask
+    const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     // stable radix sort on the voxel id alone: points enter in order j, so each voxel's run stays in order
     BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, sval_b, (size_t)P, 0, vid_bits));
     BSC_TRY(compact_heads_u32(x, skey_b, P, x->seg_start_s[set], x->bscal_s[set]));
@@ -356,11 +364,6 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (x->c.mode == BSC_MODE_EXACT) {
         // memory_2.py:880-886: rows fill the cache in order; the point that finds it full triggers the
         // flush and loses its own token.
-        BSC_TRY(read_scalars(x));
-        if (x->hscal[DS_ERROR]) {
-            bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
-            return BSC_E_CAPACITY;
-        }
         int64_t remaining = x->hscal[DS_B_NPASS], q = 0;
         while (remaining > 0) {
             const int64_t room = x->c.iter_size - x->iter_id;

@@ -7,7 +7,8 @@
 //                  for all Q queries of the call (HBM-bound)                  (:656)
 //   k_candidates   per voxel: region / floor filters, max over its <= cache_size tokens, 64-bit
 //                  rank key (similarity descending, then name order)                         (:624-663)
-//   radix sort     of the rank keys; the first K are the reference's stable-sort top-K       (:665-667)
+//   k_block_topk   rounds of per-1024 bitonic selections shrink the candidates to the K smallest rank keys =
+//                  the reference's stable-sort top-K (device-wide radix sort only for K > 512)  (:665-667)
 #include "bsc_internal.h"
 
 #include <math.h>
@@ -212,6 +213,68 @@ __global__ __launch_bounds__(TPB) void k_gather_topk(int K, int n_cand, int max_
     out_sim[i] = s;
 }
 
+// K smallest rank keys of each 1024-element slice: bitonic sort in LDS (keys are unique: similarity key | name rank).
+// Rounds of this kernel shrink n candidates to K without a device-wide sort: n -> ceil(n/1024)*K -> ... -> K.
+#define TK_N 1024
+__global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
+                                                    int64_t n, int K, u64 *__restrict__ out_keys,
+                                                    uint32_t *__restrict__ out_vals)
+{
+    __shared__ u64 sk[TK_N];
+    __shared__ uint32_t sv[TK_N];
+    const int64_t base = (int64_t)blockIdx.x * TK_N;
+    for (int i = threadIdx.x; i < TK_N; i += TPB) {
+        const int64_t g = base + i;
+        sk[i] = g < n ? in_keys[g] : ~0ull;
+        sv[i] = g < n ? in_vals[g] : 0u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= TK_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < TK_N / 2; t += TPB) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // lower index of the pair
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const u64 a = sk[i], b = sk[l];
+                if ((a > b) == up) {
+                    sk[i] = b; sk[l] = a;
+                    const uint32_t va = sv[i]; sv[i] = sv[l]; sv[l] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += TPB) {
+        out_keys[(int64_t)blockIdx.x * K + i] = sk[i];
+        out_vals[(int64_t)blockIdx.x * K + i] = sv[i];
+    }
+}
+
+// after the rounds the K winners sit sorted in (keys, vals)[0..K)
+static bsc_status select_topk(bsc_ctx *x, int64_t n, int K)
+{
+    u64 *ka = x->l_key_a, *kb = x->l_key_b;
+    uint32_t *va = x->l_val_a, *vb = x->l_val_b;
+    if (K > TK_N / 2) {                     // large K: device-wide sort
+        BSC_TRY(prim_sort_pairs(x, ka, kb, va, vb, (size_t)n, 0, 64));
+        return BSC_OK;
+    }
+    for (;;) {
+        const int64_t nb = (n + TK_N - 1) / TK_N;
+        hipLaunchKernelGGL(k_block_topk, dim3((unsigned)nb), dim3(TPB), 0, x->stream, ka, va, n, K, kb, vb);
+        n = nb * K;
+        if (nb == 1) break;
+        u64 *tk = ka; ka = kb; kb = tk;
+        uint32_t *tv = va; va = vb; vb = tv;
+    }
+    if (kb != x->l_key_b) {                 // winners must end in the *_b buffers
+        BSC_HIP(hipMemcpyAsync(x->l_key_b, kb, sizeof(u64) * K, hipMemcpyDeviceToDevice, x->stream));
+        BSC_HIP(hipMemcpyAsync(x->l_val_b, vb, sizeof(uint32_t) * K, hipMemcpyDeviceToDevice, x->stream));
+    }
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
 bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out)
 {
     hipLaunchKernelGGL(k_pool_query, dim3((D + TPB - 1) / TPB), dim3(TPB), 0, x->stream, tokens, B, T, D, out);
@@ -280,7 +343,7 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
                            x->c.cache_size, exact ? 1 : 0, x->l_sims + (int64_t)qi * n_rows, x->l_name_rank, r2,
                            radius >= 0 ? 1 : 0, curr ? curr[0] : 0, curr ? curr[1] : 0, curr ? curr[2] : 0, floor_lo,
                            floor_hi, x->l_key_a, x->l_val_a);
-        BSC_TRY(prim_sort_pairs(x, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b, (size_t)n_cand, 0, 64));
+        BSC_TRY(select_topk(x, n_cand, K));
         hipLaunchKernelGGL(k_gather_topk, dim3((K + TPB - 1) / TPB), block, 0, s, K, n_cand, max_id, vcap, x->l_key_b,
                            x->l_val_b, x->rgb_pos, x->l_out_pos + (int64_t)qi * K * 3, x->l_out_sim + (int64_t)qi * K);
     }
