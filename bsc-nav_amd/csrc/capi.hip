@@ -152,7 +152,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         ALLOC(x->acnt, vcap + 1);
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
-    ALLOC(x->p_scan_in, np); ALLOC(x->p_scan_out, np);
+    ALLOC(x->p_scan_in, np / 1024 + 16); ALLOC(x->p_scan_out, np / 1024 + 16);   // per-block (first << 32 | pass) totals
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);

@@ -106,3 +106,83 @@ extern "C" bsc_status bsc_enc_add_layernorm(const void *x, const void *delta, co
     BSC_HIP(hipGetLastError());
     return BSC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame pre-processing of the patch-feature provider (memory_2.py:733-736 + transform_ :71-74) in one pass:
+//   u8 (B,H,W,C) -> /255 -> antialiased bilinear resize to (S,S) -> ImageNet normalise -> bf16 patch matrix
+//   (B, g*g, 3*p*p), i.e. already unfolded for the patch-embedding GEMM.
+// Resize = the separable triangle filter PyTorch's F.interpolate(mode="bilinear", antialias=True) uses:
+// support = scale (when down-sampling), taps [int(c - support + .5), int(c + support + .5)), weights
+// max(0, 1 - |i + .5 - c| / scale) normalised to 1.
+#define PP_TAPS 12
+__device__ __forceinline__ void aa_taps(int o, float scale, int in_size, int &lo, int &n, float (&w)[PP_TAPS])
+{
+    const float support = scale >= 1.f ? scale : 1.f;
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    const float center = scale * ((float)o + 0.5f);
+    lo = max((int)(center - support + 0.5f), 0);
+    const int hi = min((int)(center + support + 0.5f), in_size);
+    n = min(hi - lo, PP_TAPS);
+    float tot = 0.f;
+    for (int i = 0; i < PP_TAPS; ++i) {
+        float v = 0.f;
+        if (i < n) {
+            const float x = ((float)(i + lo) - center + 0.5f) * invscale;
+            v = fmaxf(0.f, 1.f - fabsf(x));
+        }
+        w[i] = v;
+        tot += v;
+    }
+    const float inv = tot != 0.f ? 1.f / tot : 0.f;
+    for (int i = 0; i < PP_TAPS; ++i) w[i] *= inv;
+}
+
+__global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__restrict__ rgb, int B, int H, int W, int C,
+                                                            int S, int p, uint16_t *__restrict__ out, float m0, float m1,
+                                                            float m2, float s0, float s1, float s2)
+{
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= (int64_t)B * S * S) return;
+    const int x = (int)(idx % S), y = (int)((idx / S) % S), b = (int)(idx / ((int64_t)S * S));
+    float wy[PP_TAPS], wx[PP_TAPS];
+    int ylo, yn, xlo, xn;
+    aa_taps(y, (float)H / (float)S, H, ylo, yn, wy);
+    aa_taps(x, (float)W / (float)S, W, xlo, xn, wx);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const uint8_t *img = rgb + (int64_t)b * H * W * C;
+    for (int i = 0; i < yn; ++i) {
+        const uint8_t *row = img + ((int64_t)(ylo + i) * W + xlo) * C;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int k = 0; k < xn; ++k) {
+            r0 += wx[k] * (float)row[k * C + 0];
+            r1 += wx[k] * (float)row[k * C + 1];
+            r2 += wx[k] * (float)row[k * C + 2];
+        }
+        a0 += wy[i] * r0; a1 += wy[i] * r1; a2 += wy[i] * r2;
+    }
+    const int g = S / p, gy = y / p, gx = x / p, py = y - gy * p, px = x - gx * p;
+    uint16_t *dst = out + ((int64_t)b * g * g + (int64_t)gy * g + gx) * (3 * p * p) + py * p + px;
+    dst[0] = f2bf((a0 * (1.f / 255.f) - m0) / s0);
+    dst[p * p] = f2bf((a1 * (1.f / 255.f) - m1) / s1);
+    dst[2 * p * p] = f2bf((a2 * (1.f / 255.f) - m2) / s2);
+}
+
+extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C,
+                                                 int32_t S, int32_t patch, void *out_dev, const float *mean3_host,
+                                                 const float *std3_host, void *hip_stream)
+{
+    if (!rgb_dev || !out_dev || !mean3_host || !std3_host || B < 1 || C < 3 || patch < 1 || S % patch != 0) {
+        bsc_set_error("bsc_enc_preprocess_patches: invalid argument");
+        return BSC_E_INVALID;
+    }
+    if ((float)H / S > (PP_TAPS - 1) / 2.0f || (float)W / S > (PP_TAPS - 1) / 2.0f) {
+        bsc_set_error("bsc_enc_preprocess_patches: down-scale factor above %g not supported", (PP_TAPS - 1) / 2.0);
+        return BSC_E_INVALID;
+    }
+    const int64_t n = (int64_t)B * S * S;
+    hipLaunchKernelGGL(k_preprocess_patches, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)hip_stream,
+                       (const uint8_t *)rgb_dev, B, H, W, C, S, patch, (uint16_t *)out_dev, mean3_host[0], mean3_host[1],
+                       mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}

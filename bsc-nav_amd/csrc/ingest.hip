@@ -6,7 +6,7 @@
 //
 //   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
 //               first toucher of every still-empty cell                         (1 thread / point)
-//   k_flags + exclusive scan + k_assign      first-touch points get ids max_id + rank in order
+//   k_flags + scan of block totals + k_assign  first-touch points get ids max_id + rank in order
 //   k_keys_pairs (dense.hip) sort key = voxel id, value = j; LDS aggregation of (voxel, frame, patch) pairs
 //   radix sort  (stable, on the voxel id bits only) groups the points of a voxel in order; the segment
 //               starts are compacted deterministically (block counts + scan)
@@ -95,51 +95,88 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     if (occ[cell] < 0) atomicMin(&occ[cell], INT_MIN + (int32_t)j);
 }
 
-__global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
-                                               const int32_t *__restrict__ occ, int64_t *__restrict__ scan_in)
+// ---- first-touch ranks without a per-point scan -----------------------------------------------------------------
+// Blocks of FB consecutive points count their passing / first-touch points (k_flags); an exclusive scan over the
+// ~P/1024 block totals gives every block its base; k_assign recomputes the flags and ranks its points inside the
+// block in order j with wave ballots.  Same ranks as a scan over all P points, at a third of the traffic.
+#define FB 1024
+__device__ __forceinline__ int point_flags(int64_t j, int64_t P, const int32_t *__restrict__ p_cell,
+                                           const int32_t *__restrict__ occ, int32_t &cell)
 {
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= P) return;
-    const int32_t c = p_cell[j];
-    int64_t v = 0;
-    if (c >= 0) {
-        v = 1;
-        if (occ[c] == INT_MIN + (int32_t)j) v |= (1ll << 32);
+    cell = -1;
+    if (j >= P) return 0;
+    cell = p_cell[j];
+    if (cell < 0) return 0;
+    return (occ[cell] == INT_MIN + (int32_t)j) ? 3 : 1;     // bit0 passes, bit1 first toucher of its voxel
+}
+
+__global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
+                                               const int32_t *__restrict__ occ, int64_t *__restrict__ blk_tot)
+{
+    __shared__ int s_pass, s_first;
+    if (threadIdx.x == 0) { s_pass = 0; s_first = 0; }
+    __syncthreads();
+    int np = 0, nf = 0;
+    for (int r = 0; r < FB / TPB; ++r) {
+        int32_t c;
+        const int f = point_flags((int64_t)blockIdx.x * FB + r * TPB + threadIdx.x, P, p_cell, occ, c);
+        np += f & 1;
+        nf += f >> 1;
     }
-    scan_in[j] = v;
+    for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o); nf += __shfl_xor(nf, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_pass, np); atomicAdd(&s_first, nf); }
+    __syncthreads();
+    if (threadIdx.x == 0) blk_tot[blockIdx.x] = ((int64_t)s_first << 32) | (int64_t)s_pass;
 }
 
 __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__restrict__ p_cell, int32_t *occ,
-                                                const int64_t *__restrict__ scan_in,
-                                                const int64_t *__restrict__ scan_out, int64_t *dscal, int vcap, int gs,
+                                                const int64_t *__restrict__ blk_off, int64_t *dscal, int vcap, int gs,
                                                 int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list)
 {
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= P) return;
-    const int64_t in = scan_in[j];
-    if (!(in & 1)) return;
-    const int64_t ex = scan_out[j];
-    pass_list[(uint32_t)ex] = (int32_t)j;
-    if (in >> 32) {
-        const int64_t id = dscal[DS_MAX_ID] + (ex >> 32);
-        const int32_t c = p_cell[j];
-        if (id >= vcap) {
-            dscal[DS_ERROR] = 1;        // capacity: the cell keeps its provisional (negative) value
-            return;
+    __shared__ int w_pass[TPB / 64], w_first[TPB / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t base = blk_off[blockIdx.x];
+    int64_t pass_base = base & 0xffffffffll, first_base = base >> 32;
+    const int64_t max_id = dscal[DS_MAX_ID];
+    for (int r = 0; r < FB / TPB; ++r) {            // rounds keep the order j: round, then wave, then lane
+        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+        int32_t c;
+        const int f = point_flags(j, P, p_cell, occ, c);
+        const u64 mp = __ballot(f & 1), mf = __ballot(f & 2);
+        if (lane == 0) { w_pass[wid] = __popcll(mp); w_first[wid] = __popcll(mf); }
+        __syncthreads();
+        int bp = 0, bf = 0, tp = 0, tf = 0;
+        for (int w = 0; w < TPB / 64; ++w) {
+            if (w < wid) { bp += w_pass[w]; bf += w_first[w]; }
+            tp += w_pass[w]; tf += w_first[w];
         }
-        occ[c] = (int32_t)id;           // memory_2.py:890
-        const int32_t h = c % nh, rc = c / nh;
-        rgb_pos[3 * id + 0] = rc / gs;  // memory_2.py:893
-        rgb_pos[3 * id + 1] = rc % gs;
-        rgb_pos[3 * id + 2] = h;
+        const u64 lt = (1ull << lane) - 1ull;
+        if (f & 1) {
+            if (pass_list) pass_list[pass_base + bp + __popcll(mp & lt)] = (int32_t)j;
+            if (f & 2) {
+                const int64_t id = max_id + first_base + bf + __popcll(mf & lt);
+                if (id >= vcap) {
+                    dscal[DS_ERROR] = 1;        // capacity: the cell keeps its provisional (negative) value
+                } else {
+                    occ[c] = (int32_t)id;           // memory_2.py:890
+                    const int32_t h = c % nh, rc = c / nh;
+                    rgb_pos[3 * id + 0] = rc / gs;  // memory_2.py:893
+                    rgb_pos[3 * id + 1] = rc % gs;
+                    rgb_pos[3 * id + 2] = h;
+                }
+            }
+        }
+        pass_base += tp;
+        first_base += tf;
+        __syncthreads();
     }
 }
 
-__global__ void k_totals(int64_t P, const int64_t *scan_in, const int64_t *scan_out, int64_t *dscal, int vcap,
+__global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const int64_t *blk_off, int64_t *dscal, int vcap,
                          int64_t *bscal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int64_t tot = scan_out[P - 1] + scan_in[P - 1];
+    const int64_t tot = blk_off[nblk - 1] + blk_tot[nblk - 1];
     const int64_t npass = tot & 0xffffffffll, nfirst = tot >> 32;
     dscal[DS_B_NPASS] = npass;
     dscal[DS_B_NFIRST] = nfirst;
@@ -328,12 +365,16 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     GeomConst gc = make_geom_const(x);
     hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
                        alpha, P, x->occ, x->p_cell, x->p_patf, p_rgbv, x->p_r2f, p_alpha);
-    hipLaunchKernelGGL(k_flags, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
-    BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)P));
-    hipLaunchKernelGGL(k_assign, grid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->p_scan_out, x->dscal,
-                       x->c.voxel_capacity, x->c.grid_size, x->nh, x->rgb_pos, x->pass_list);
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, x->p_scan_in, x->p_scan_out, x->dscal, x->c.voxel_capacity,
-                       x->bscal_s[set]);
+    const int64_t nblk = (P + FB - 1) / FB;
+    const dim3 fgrid((unsigned)nblk);
+    hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
+    BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)nblk));
+    // k_assign reads occ while other blocks overwrite claimed cells with ids: a claim INT_MIN + j can only be
+    // replaced by the id of that same point j, so the flags of every other point are unaffected
+    hipLaunchKernelGGL(k_assign, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_out, x->dscal, x->c.voxel_capacity,
+                       x->c.grid_size, x->nh, x->rgb_pos, x->c.mode == BSC_MODE_EXACT ? x->pass_list : (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->p_scan_in, x->p_scan_out, x->dscal,
+                       x->c.voxel_capacity, x->bscal_s[set]);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr));
     // one small readback per call: voxel count (sort width), pair count (dense modes), passing points (exact mode),
     // capacity flag.  Everything enqueued so far is the call's front end; the back end is sized from these numbers.

@@ -95,6 +95,12 @@ class RandomViT(nn.Module):
         B, g, p = x.shape[0], self.grid, self.patch
         x = x.to(self.compute_dtype)
         t = x.reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * p * p)
+        return self._forward_patches(t)
+
+    @torch.no_grad()
+    def _forward_patches(self, t):
+        """(B, g*g, 3*p*p) unfolded, normalised patches -> {'x_norm_patchtokens': (B, g*g, D)}."""
+        B = t.shape[0]
         t = self.patch_embed(t)
         t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
         if self.reg is not None:
@@ -135,7 +141,19 @@ class RandomViT(nn.Module):
     @torch.no_grad()
     def patch_tokens(self, rgb):
         """rgb (B,H,W,C) u8 on the device -> (B, g, g, D) fp32 contiguous."""
-        t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
+        if self.fused and rgb.is_cuda and self.compute_dtype == torch.bfloat16 and rgb.is_contiguous():
+            from . import _lib
+            B, H, W, Cc = rgb.shape
+            g, p = self.grid, self.patch
+            patches = torch.empty((B, g * g, 3 * p * p), dtype=torch.bfloat16, device=rgb.device)
+            mean = (C.c_float * 3)(*IMAGENET_MEAN)
+            std = (C.c_float * 3)(*IMAGENET_STD)
+            _lib.check(_lib.load().bsc_enc_preprocess_patches(
+                C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mean, std,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            t = self._forward_patches(patches)["x_norm_patchtokens"]
+        else:
+            t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
         return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()
 
     def flops_per_frame(self):

@@ -143,6 +143,13 @@ bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id)
 bsc_status bsc_enc_add_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev, const void *beta_dev,
                                  void *xout_dev, void *y_dev, int64_t rows, int32_t width, float eps, void *hip_stream);
 
+/* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
+ * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM
+ * (memory_2.py:733-736 and transform_, :71-74, fused into one pass). */
+bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C, int32_t S,
+                                      int32_t patch, void *out_dev, const float *mean3_host, const float *std3_host,
+                                      void *hip_stream);
+
 /* HIP-event timing of the dominant kernel of each path, recorded on the ctx stream around every launch
  * (which 0: dense feature reduce of bsc_ingest, 1: cosine scan of bsc_localize).
  * out[0]=ms summed over the covered launches, out[1]=launches covered (ring of 512), out[2]=algorithmic

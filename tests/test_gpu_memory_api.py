@@ -134,3 +134,27 @@ def test_fused_encoder_ops_match_pytorch():
     y_ref = torch.nn.functional.layer_norm(s_ref.float(), (768,), ln.weight.float(), ln.bias.float(), 1e-6)
     assert torch.equal(xo.view(1000, 768), s_ref)
     assert (y.view(1000, 768).float() - y_ref).abs().max().item() < 0.02     # one bf16 rounding of |y| <~ 4
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (240, 320), (680, 680), (224, 224)])
+def test_fused_preprocess_matches_torch_interpolate(hw):
+    """bsc_enc_preprocess_patches == /255 -> F.interpolate(bilinear, antialias) -> normalise -> unfold (bf16 rounding)."""
+    import ctypes as C
+    import torch
+    from bsc_nav_amd import _lib, encoder
+    H, W = hw
+    vit = encoder.RandomViT("vit_tiny_test").cuda()
+    rgb = torch.randint(0, 255, (2, H, W, 4), dtype=torch.uint8, device="cuda")
+    ref = vit.preprocess(rgb)                                              # (B,3,224,224) float
+    g, p = vit.grid, vit.patch
+    ref = ref.reshape(2, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(2, g * g, 3 * p * p)
+    out = torch.empty((2, g * g, 3 * p * p), dtype=torch.bfloat16, device="cuda")
+    mean = (C.c_float * 3)(*encoder.IMAGENET_MEAN)
+    std = (C.c_float * 3)(*encoder.IMAGENET_STD)
+    _lib.check(_lib.load().bsc_enc_preprocess_patches(C.c_void_p(rgb.data_ptr()), 2, H, W, 4, 224, p,
+                                                      C.c_void_p(out.data_ptr()), mean, std,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    assert err.max().item() < 0.02, err.max().item()       # bf16 rounding of values up to ~2.6
+    assert err.mean().item() < 0.004
