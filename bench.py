@@ -43,9 +43,9 @@ def pmc_traffic():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (per rank); 16 steps x 64 = 1024 frames")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step (per rank); 8 steps x 128 = 1024 frames")
     ap.add_argument("--kind", default="room", choices=["room", "iid"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")
@@ -252,7 +252,7 @@ def main():
         oc = orc.make_config(H, W, gs, cs, -half, half, g, D, mode=1 if a.mode == "mean" else 2)
         om = orc.OracleMemory(oc, voxel_capacity=2_000_000)
         host = []
-        for s in range(min(n_steps, 4)):                # up to 256 frames staged on the host, outside the CPU clock
+        for s in range(min(n_steps, 2)):                # up to 256 frames staged on the host, outside the CPU clock
             host.append((vit.patch_tokens(rgbs[s]).cpu().numpy(), rgbs[s].cpu().numpy(), depths[s].cpu().numpy()))
         nf, cdt = 0, 0.0
         for s, (tok_h, rgb_h, dep_h) in enumerate(host):
