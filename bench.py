@@ -229,7 +229,7 @@ def main():
             engL.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
             del rows
             loc = {"voxels": V, "dim": D, "K": 100}
-            for Q in (1, 8):
+            for Q in (1, 8, 256):
                 q = torch.randn(Q, D, device="cuda", generator=gen)
                 engL.localize(q, K=100)
                 engL.kernel_stats(1, reset=True)
@@ -244,6 +244,10 @@ def main():
                 loc[f"q{Q}"] = {"latency_ms": lat * 1e3, "cosine_ms": ls["ms"] / max(1, ls["launches"]),
                                 "cosine_GBs": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9,
                                 "cosine_frac_of_hbm_peak": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if Q >= 16:     # fp32-MFMA GEMM path: price it against the 157.3 TFLOP/s fp32 matrix peak instead
+                    tf = 2.0 * V * D * Q / max(1e-9, ls["ms"] / max(1, ls["launches"]) * 1e-3) / 1e12
+                    loc[f"q{Q}"].update({"cosine_TFLOPs": tf, "cosine_frac_of_f32_mfma_peak": tf / 157.3})
+                    loc[f"q{Q}"].pop("cosine_GBs"), loc[f"q{Q}"].pop("cosine_frac_of_hbm_peak")
             out["localize"] = loc
             engL.close()
     # ---- CPU baseline: the plain-C oracle (port of the reference loop) on a bounded sample ----

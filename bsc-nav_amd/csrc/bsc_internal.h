@@ -101,6 +101,11 @@ struct bsc_ctx {
     uint32_t *l_val_a, *l_val_b;
     uint32_t *l_name_rank;
     float *l_q;          // normalised queries
+    u64 *l_sel_key[2];   // batched top-K selection rounds (grown on demand)
+    uint32_t *l_sel_val[2];
+    u64 *l_sel_thr;      // per-query threshold keys of the sample selection
+    int32_t *l_sel_cnt;  // per-query survivor counts
+    int64_t l_sel_cap[6];
     int32_t *l_out_pos;
     float *l_out_sim;
     bool names_dirty;
@@ -160,6 +165,7 @@ bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_
 bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev);
 bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, double radius, const int32_t *curr,
                          int32_t floor_lo, int32_t floor_hi, int32_t *out_pos, float *out_sim, int32_t *out_count);
+int64_t sims_row_stride(int64_t n_rows);
 bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out);
 bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the main stream)
 bsc_status sync_all(bsc_ctx *x);     // main + side stream

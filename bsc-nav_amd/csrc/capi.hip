@@ -214,7 +214,8 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
-                    x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->prim_tmp};
+                    x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
+                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
@@ -614,7 +615,7 @@ extern "C" bsc_status bsc_localize(bsc_ctx *x, const float *q_dev, int32_t nq, i
     BSC_HIP(hipSetDevice(x->device));
     BSC_TRY(read_scalars(x));
     const int64_t n_rows = x->c.mode == BSC_MODE_EXACT ? x->hscal[DS_POOL_N] : x->hscal[DS_MAX_ID];
-    const int64_t need = (int64_t)nq * (n_rows > 0 ? n_rows : 1);
+    const int64_t need = (int64_t)nq * sims_row_stride(n_rows > 0 ? n_rows : 1);
     // scratch grows on demand (similarities for every query x row, top-K staging)
     struct grow { static bsc_status run(void **p, int64_t *cap, int64_t need_bytes) {
         if (*cap >= need_bytes) return BSC_OK;

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void k_normalize_q(const float *__restrict__ q,
 // One wavefront per row (grid-stride), NV float4 per lane; the row is loaded once and reused for QT queries.
 template <int NV, int QT>
 __global__ __launch_bounds__(TPB) void k_cosine(const float *__restrict__ rows, int64_t n_rows, int D,
-                                                const float *__restrict__ qn, int q0, float *__restrict__ sims)
+                                                const float *__restrict__ qn, int q0, float *__restrict__ sims,
+                                                int64_t sims_stride)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
@@ -123,8 +124,97 @@ __global__ __launch_bounds__(TPB) void k_cosine(const float *__restrict__ rows, 
             for (int t = 0; t < NV; ++t)
                 dsum += xv[t].x * qv[qi][t].x + xv[t].y * qv[qi][t].y + xv[t].z * qv[qi][t].z + xv[t].w * qv[qi][t].w;
             dsum = wave_sum(dsum);
-            if (lane == 0) sims[(int64_t)(q0 + qi) * n_rows + r] = dsum * inv;
+            if (lane == 0) sims[(int64_t)(q0 + qi) * sims_stride + r] = dsum * inv;
         }
+    }
+}
+
+// ---- batched queries on the matrix cores -----------------------------------------------------------------------
+// S^T tile (32 queries x 32 rows) = Qn (32 x D) . X^T (D x 32) with v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate,
+// bit-for-bit an fmaf chain (no TF32 on gfx950), 64 cycles per instruction.  One workgroup = 4 waves = 128 rows;
+// each wave owns 32 rows and NT 32-query tiles (16 accumulator registers each).  K is walked in chunks of 32 staged
+// through LDS (row stride 33 floats: conflict-free ds_read_b32 for the 32-lane operand groups), double-buffered
+// with register prefetch of the next chunk.  The squared row norms fall out of the B operands the lanes already hold.
+// Queries sit on the M axis so that the accumulator columns are rows of X: stores are 128-byte row runs per query.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MF_KC 32
+#define MF_LD 33
+template <int NT>
+__global__ __launch_bounds__(TPB) void k_cosine_mfma(const float *__restrict__ X, int64_t n_rows, int D,
+                                                     const float *__restrict__ qn, int q0, int q_valid,
+                                                     float *__restrict__ sims, int64_t sims_stride)
+{
+    __shared__ float Xs[2][128 * MF_LD];
+    __shared__ float Qs[2][NT * 32 * MF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int nchunks = D / MF_KC;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float nrm = 0.f;
+    float4 xr[4], qr[NT];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + TPB * i, r = idx >> 3, c4 = idx & 7;
+            const int64_t gr = row0 + r;
+            xr[i] = gr < n_rows ? *(const float4 *)(X + gr * D + c * MF_KC + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int idx = tid + TPB * i, r = idx >> 3, c4 = idx & 7;
+            qr[i] = *(const float4 *)(qn + (int64_t)(q0 + r) * D + c * MF_KC + c4 * 4);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + TPB * i, r = idx >> 3, c4 = idx & 7;
+            float *d = &Xs[buf][r * MF_LD + c4 * 4];
+            d[0] = xr[i].x; d[1] = xr[i].y; d[2] = xr[i].z; d[3] = xr[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int idx = tid + TPB * i, r = idx >> 3, c4 = idx & 7;
+            float *d = &Qs[buf][r * MF_LD + c4 * 4];
+            d[0] = qr[i].x; d[1] = qr[i].y; d[2] = qr[i].z; d[3] = qr[i].w;
+        }
+    };
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const float *xb = &Xs[buf][(w * 32 + (lane & 31)) * MF_LD + (lane >> 5)];
+        const float *qb = &Qs[buf][(lane & 31) * MF_LD + (lane >> 5)];
+#pragma unroll 4
+        for (int kk = 0; kk < MF_KC; kk += 2) {
+            const float b = xb[kk];
+            nrm = fmaf(b, b, nrm);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float a = qb[t * 32 * MF_LD + kk];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    nrm += __shfl_xor(nrm, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(nrm), 1e-8f);
+    const int64_t row = row0 + w * 32 + (lane & 31);
+    if (row < n_rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (q < q_valid) sims[(int64_t)q * sims_stride + row] = acc[t][r] * inv;
+            }
     }
 }
 
@@ -157,48 +247,68 @@ __global__ __launch_bounds__(TPB) void k_name_rank(int n_cand, const uint32_t *_
     rank[sorted_vals[i]] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(TPB) void k_candidates(int n_cand, int max_id, int vcap, const int32_t *__restrict__ rgb_pos,
-                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ store_rows,
-                                                    int cache_size, int exact, const float *__restrict__ sims,
-                                                    const uint32_t *__restrict__ name_rank, double radius2, int use_radius,
-                                                    int c0, int c1, int c2, int floor_lo, int floor_hi,
-                                                    u64 *__restrict__ keys, uint32_t *__restrict__ vals)
+struct CandArgs {
+    int n_cand, max_id, vcap, cache_size, exact, use_radius, c0, c1, c2, floor_lo, floor_hi;
+    double radius2;
+    const int32_t *rgb_pos, *cnt, *store_rows;
+    const uint32_t *name_rank;
+};
+
+// similarity part of the rank key of candidate c for one query (0xffffffff: filtered out / empty):
+// region / floor filters, max over the voxel's tokens
+__device__ __forceinline__ uint32_t cand_simkey(const CandArgs &a, int c, const float *__restrict__ sims)
+{
+    if (c >= a.n_cand) return 0xffffffffu;
+    const int e = (c == a.max_id) ? a.vcap : c;
+    const int m = a.cnt[e];
+    if (m <= 0) return 0xffffffffu;
+    if (a.use_radius || a.floor_lo <= a.floor_hi) {
+        int r = 0, cc = 0, h = 0;
+        if (c != a.max_id) { r = a.rgb_pos[3 * e]; cc = a.rgb_pos[3 * e + 1]; h = a.rgb_pos[3 * e + 2]; }
+        if (a.use_radius) {   // memory_2.py:624-629 (integer squared distance compared with radius**2)
+            const double dx = r - a.c0, dy = cc - a.c1, dz = h - a.c2;
+            if (!((dx * dx + dy * dy + dz * dz) <= a.radius2)) return 0xffffffffu;
+        }
+        if (a.floor_lo <= a.floor_hi && !((a.floor_lo <= h) && (h <= a.floor_hi))) return 0xffffffffu;   // :633-640
+    }
+    float best = -INFINITY;
+    if (a.exact) {
+        for (int k = 0; k < m; ++k) best = fmaxf(best, sims[a.store_rows[(int64_t)e * a.cache_size + k]]);   // :661
+    } else {
+        best = sims[e];
+    }
+    const uint32_t sk = float_desc_key(best);
+    return sk == 0xffffffffu ? 0xfffffffeu : sk;     // keep the all-ones pattern for "no candidate"
+}
+
+// full rank key: similarity descending, ties in HDF5 name order
+__device__ __forceinline__ u64 cand_key(const CandArgs &a, int c, const float *__restrict__ sims)
+{
+    const uint32_t sk = cand_simkey(a, c, sims);
+    if (sk == 0xffffffffu) return ~0ull;
+    return ((u64)sk << 32) | (u64)a.name_rank[c];
+}
+
+__global__ __launch_bounds__(TPB) void k_candidates(CandArgs a, const float *__restrict__ sims, u64 *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals)
 {
     const int c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= n_cand) return;
-    const int e = (c == max_id) ? vcap : c;
-    u64 key = ~0ull;
-    const int m = cnt[e];
-    if (m > 0) {
-        int r = 0, cc = 0, h = 0;
-        if (c != max_id) { r = rgb_pos[3 * e]; cc = rgb_pos[3 * e + 1]; h = rgb_pos[3 * e + 2]; }
-        bool ok = true;
-        if (use_radius) {   // memory_2.py:624-629 (integer squared distance compared with radius**2)
-            const double dx = r - c0, dy = cc - c1, dz = h - c2;
-            ok = (dx * dx + dy * dy + dz * dz) <= radius2;
-        }
-        if (floor_lo <= floor_hi) ok = ok && (floor_lo <= h) && (h <= floor_hi);   // :633-640
-        if (ok) {
-            float best = -INFINITY;
-            if (exact) {
-                for (int k = 0; k < m; ++k) best = fmaxf(best, sims[store_rows[(int64_t)e * cache_size + k]]);   // :661
-            } else {
-                best = sims[e];
-            }
-            key = ((u64)float_desc_key(best) << 32) | (u64)name_rank[c];
-        }
-    }
-    keys[c] = key;
+    if (c >= a.n_cand) return;
+    keys[c] = cand_key(a, c, sims);
     vals[c] = (uint32_t)c;
 }
 
 __global__ __launch_bounds__(TPB) void k_gather_topk(int K, int n_cand, int max_id, int vcap,
                                                      const u64 *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     const int32_t *__restrict__ rgb_pos, int32_t *__restrict__ out_pos,
-                                                     float *__restrict__ out_sim)
+                                                     int64_t in_stride, const int32_t *__restrict__ rgb_pos,
+                                                     int32_t *__restrict__ out_pos, float *__restrict__ out_sim)
 {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= K) return;
+    keys += (int64_t)blockIdx.y * in_stride;
+    vals += (int64_t)blockIdx.y * in_stride;
+    out_pos += (int64_t)blockIdx.y * K * 3;
+    out_sim += (int64_t)blockIdx.y * K;
     int32_t r = -1, c = -1, h = -1;
     float s = -INFINITY;
     if (i < n_cand && keys[i] != ~0ull) {
@@ -216,19 +326,8 @@ __global__ __launch_bounds__(TPB) void k_gather_topk(int K, int n_cand, int max_
 // K smallest rank keys of each 1024-element slice: bitonic sort in LDS (keys are unique: similarity key | name rank).
 // Rounds of this kernel shrink n candidates to K without a device-wide sort: n -> ceil(n/1024)*K -> ... -> K.
 #define TK_N 1024
-__global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
-                                                    int64_t n, int K, u64 *__restrict__ out_keys,
-                                                    uint32_t *__restrict__ out_vals)
+__device__ __forceinline__ void bitonic_1024(u64 *sk, uint32_t *sv)
 {
-    __shared__ u64 sk[TK_N];
-    __shared__ uint32_t sv[TK_N];
-    const int64_t base = (int64_t)blockIdx.x * TK_N;
-    for (int i = threadIdx.x; i < TK_N; i += TPB) {
-        const int64_t g = base + i;
-        sk[i] = g < n ? in_keys[g] : ~0ull;
-        sv[i] = g < n ? in_vals[g] : 0u;
-    }
-    __syncthreads();
     for (int k = 2; k <= TK_N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < TK_N / 2; t += TPB) {
@@ -244,34 +343,211 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
             __syncthreads();
         }
     }
+}
+
+// first round, fused with the candidate scan: block (b, q) ranks candidates [1024 b, 1024 b + 1024) of query q
+__global__ __launch_bounds__(TPB) void k_cand_topk(CandArgs a, const float *__restrict__ sims, int64_t sims_stride, int K,
+                                                   u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
+                                                   int64_t out_stride)
+{
+    __shared__ u64 sk[TK_N];
+    __shared__ uint32_t sv[TK_N];
+    const float *qs = sims + (int64_t)blockIdx.y * sims_stride;
+    for (int i = threadIdx.x; i < TK_N; i += TPB) {
+        const int c = blockIdx.x * TK_N + i;
+        sk[i] = cand_key(a, c, qs);
+        sv[i] = (uint32_t)c;
+    }
+    __syncthreads();
+    bitonic_1024(sk, sv);
     for (int i = threadIdx.x; i < K; i += TPB) {
-        out_keys[(int64_t)blockIdx.x * K + i] = sk[i];
-        out_vals[(int64_t)blockIdx.x * K + i] = sv[i];
+        out_keys[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sk[i];
+        out_vals[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sv[i];
     }
 }
 
-// after the rounds the K winners sit sorted in (keys, vals)[0..K)
-static bsc_status select_topk(bsc_ctx *x, int64_t n, int K)
+__global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
+                                                    int64_t n, const int32_t *__restrict__ n_per_q, int64_t in_stride, int K,
+                                                    u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
+                                                    int64_t out_stride)
 {
-    u64 *ka = x->l_key_a, *kb = x->l_key_b;
-    uint32_t *va = x->l_val_a, *vb = x->l_val_b;
-    if (K > TK_N / 2) {                     // large K: device-wide sort
-        BSC_TRY(prim_sort_pairs(x, ka, kb, va, vb, (size_t)n, 0, 64));
-        return BSC_OK;
+    __shared__ u64 sk[TK_N];
+    __shared__ uint32_t sv[TK_N];
+    if (n_per_q) n = min((int64_t)n_per_q[blockIdx.y], n);
+    const int64_t base = (int64_t)blockIdx.x * TK_N;
+    for (int i = threadIdx.x; i < TK_N; i += TPB) {
+        const int64_t g = base + i;
+        sk[i] = g < n ? in_keys[(int64_t)blockIdx.y * in_stride + g] : ~0ull;
+        sv[i] = g < n ? in_vals[(int64_t)blockIdx.y * in_stride + g] : 0u;
     }
-    for (;;) {
+    __syncthreads();
+    bitonic_1024(sk, sv);
+    for (int i = threadIdx.x; i < K; i += TPB) {
+        out_keys[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sk[i];
+        out_vals[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sv[i];
+    }
+}
+
+// (persistent 1-D grid: 16 k workgroups walking the (query, chunk) items measured 2x faster than one short-lived
+//  workgroup per item, see profiles/README.md)
+// threshold filter: the K-th best key of a SAMPLE of the candidates bounds the K-th best of all of them from above,
+// so only candidates at least that good can be in the answer; they are appended (unordered) to a short survivor list
+#define FILT_PER_BLOCK 4096
+#define FILT_G (FILT_PER_BLOCK / (4 * TPB))
+__global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__restrict__ sims, int64_t sims_stride,
+                                                     const u64 *__restrict__ thr_keys, int K, int cap,
+                                                     u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
+                                                     int32_t *__restrict__ counts, int nbf, int nq)
+{
+  for (int wi = blockIdx.x; wi < nbf * nq; wi += gridDim.x) {
+    const int q = wi / nbf, bx = wi - q * nbf;
+    const u64 thr = thr_keys[q];
+    const uint32_t thr_hi = (uint32_t)(thr >> 32);
+    const float *qs = sims + (int64_t)q * sims_stride;
+    const int lane = threadIdx.x & 63;
+    // dense maps without region / floor filter: candidate c is row c, so similarities and counts stream as 16-byte loads
+    const bool fast = !a.exact && !a.use_radius && !(a.floor_lo <= a.floor_hi) && (sims_stride % 4 == 0);
+    uint32_t sk[FILT_G][4];
+    // phase 1: every load of the block's 4096 candidates is in flight before anything is consumed
+#pragma unroll
+    for (int g = 0; g < FILT_G; ++g) {
+        const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
+        if (fast && c0 + 3 < a.max_id) {
+            const float4 sv = *(const float4 *)(qs + c0);
+            const int4 cv = *(const int4 *)(a.cnt + c0);
+            sk[g][0] = cv.x > 0 ? float_desc_key(sv.x) : 0xffffffffu;
+            sk[g][1] = cv.y > 0 ? float_desc_key(sv.y) : 0xffffffffu;
+            sk[g][2] = cv.z > 0 ? float_desc_key(sv.z) : 0xffffffffu;
+            sk[g][3] = cv.w > 0 ? float_desc_key(sv.w) : 0xffffffffu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sk[g][k] = cand_simkey(a, c0 + k, qs);
+        }
+    }
+    // phase 2: almost every wave has nothing to keep -> one ballot per wave decides
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < FILT_G; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any = any || (sk[g][k] <= thr_hi && sk[g][k] != 0xffffffffu);
+    if (!__ballot(any)) continue;
+#pragma unroll
+    for (int g = 0; g < FILT_G; ++g) {
+        const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            u64 key = ~0ull;
+            if (sk[g][k] != 0xffffffffu && sk[g][k] <= thr_hi) key = ((u64)sk[g][k] << 32) | (u64)a.name_rank[c];
+            const bool keep = key != ~0ull && key <= thr;
+            const u64 m = __ballot(keep);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&counts[q], __popcll(m));
+                base = __shfl(base, leader);
+                if (keep) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) {
+                        out_keys[(int64_t)q * cap + pos] = key;
+                        out_vals[(int64_t)q * cap + pos] = (uint32_t)c;
+                    }
+                }
+            }
+        }
+    }
+  }
+}
+
+// thresholds of the sample selection: K-th key of every query's winners -> thr[q]; also clears the survivor counters
+__global__ void k_sel_thresholds(const u64 *__restrict__ win_keys, int64_t stride, int K, int nq, u64 *__restrict__ thr,
+                                 int32_t *__restrict__ counts)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    thr[q] = win_keys[(int64_t)q * stride + (K - 1)];
+    counts[q] = 0;
+}
+
+// the filter is exact unless a survivor list overflowed or the sample held fewer than K valid candidates
+__global__ void k_sel_check(const u64 *__restrict__ thr, const int32_t *__restrict__ counts, int nq, int cap, int32_t *flag)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    if (counts[q] > cap || thr[q] == ~0ull) *flag = 1;
+}
+
+static bsc_status grow_dev(void **p, int64_t *cap, int64_t need_bytes)
+{
+    if (*cap >= need_bytes) return BSC_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(p, (size_t)need_bytes);
+    if (e != hipSuccess) { bsc_set_error("bsc_localize scratch (%lld bytes): %s", (long long)need_bytes, hipGetErrorString(e)); return BSC_E_HIP; }
+    *cap = need_bytes;
+    return BSC_OK;
+}
+
+// K <= 512, all queries at once, no device-wide sort:
+//   small candidate sets: rounds of 1024-key bitonic selections (round 1 fused with the candidate scan);
+//   large sets: selection over a sample of 64 blocks gives a per-query threshold, one streaming filter pass keeps the
+//   few candidates that beat it, rounds over the survivors finish.  *overflow is set when the host must fall back.
+#define SEL_SAMPLE_BLOCKS 64
+#define SEL_SURVIVOR_CAP 32768
+static bsc_status bitonic_rounds(bsc_ctx *x, int nq, int64_t n, const int32_t *n_per_q, int K, int64_t stride, int *cur)
+{
+    bool first = true;
+    while (n > K || first) {
         const int64_t nb = (n + TK_N - 1) / TK_N;
-        hipLaunchKernelGGL(k_block_topk, dim3((unsigned)nb), dim3(TPB), 0, x->stream, ka, va, n, K, kb, vb);
+        hipLaunchKernelGGL(k_block_topk, dim3((unsigned)nb, (unsigned)nq), dim3(TPB), 0, x->stream, x->l_sel_key[*cur],
+                           x->l_sel_val[*cur], n, first ? n_per_q : (const int32_t *)nullptr, stride, K,
+                           x->l_sel_key[*cur ^ 1], x->l_sel_val[*cur ^ 1], stride);
+        *cur ^= 1;
         n = nb * K;
+        first = false;
         if (nb == 1) break;
-        u64 *tk = ka; ka = kb; kb = tk;
-        uint32_t *tv = va; va = vb; vb = tv;
     }
-    if (kb != x->l_key_b) {                 // winners must end in the *_b buffers
-        BSC_HIP(hipMemcpyAsync(x->l_key_b, kb, sizeof(u64) * K, hipMemcpyDeviceToDevice, x->stream));
-        BSC_HIP(hipMemcpyAsync(x->l_val_b, vb, sizeof(uint32_t) * K, hipMemcpyDeviceToDevice, x->stream));
+    return BSC_OK;
+}
+
+static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, int64_t sims_stride, int K, bool allow_filter,
+                                      u64 **win_keys, uint32_t **win_vals, int64_t *win_stride, bool *filtered)
+{
+    const int64_t nb1 = ((int64_t)ca.n_cand + TK_N - 1) / TK_N;
+    const bool use_filter = allow_filter && nb1 > 4 * SEL_SAMPLE_BLOCKS;
+    const int64_t nbs = use_filter ? SEL_SAMPLE_BLOCKS : nb1;
+    int64_t stride = nbs * K;
+    if (use_filter && stride < SEL_SURVIVOR_CAP) stride = SEL_SURVIVOR_CAP;
+    BSC_TRY(grow_dev((void **)&x->l_sel_key[0], &x->l_sel_cap[0], sizeof(u64) * stride * nq));
+    BSC_TRY(grow_dev((void **)&x->l_sel_key[1], &x->l_sel_cap[1], sizeof(u64) * stride * nq));
+    BSC_TRY(grow_dev((void **)&x->l_sel_val[0], &x->l_sel_cap[2], sizeof(uint32_t) * stride * nq));
+    BSC_TRY(grow_dev((void **)&x->l_sel_val[1], &x->l_sel_cap[3], sizeof(uint32_t) * stride * nq));
+    BSC_TRY(grow_dev((void **)&x->l_sel_thr, &x->l_sel_cap[4], sizeof(u64) * (int64_t)(nq + 1)));
+    BSC_TRY(grow_dev((void **)&x->l_sel_cnt, &x->l_sel_cap[5], sizeof(int32_t) * nq));
+    int cur = 0;
+    // round 1 over the sample (or over everything), fused with the candidate keys
+    hipLaunchKernelGGL(k_cand_topk, dim3((unsigned)nbs, (unsigned)nq), dim3(TPB), 0, x->stream, ca, x->l_sims, sims_stride, K,
+                       x->l_sel_key[0], x->l_sel_val[0], stride);
+    if (nbs > 1) BSC_TRY(bitonic_rounds(x, nq, nbs * K, nullptr, K, stride, &cur));
+    *filtered = false;
+    if (use_filter) {
+        // per-query threshold = K-th key of the sample winners (kept aside: the selection buffers are reused)
+        hipLaunchKernelGGL(k_sel_thresholds, dim3((nq + 255) / 256), dim3(256), 0, x->stream, x->l_sel_key[cur], stride, K, nq,
+                           x->l_sel_thr, x->l_sel_cnt);
+        cur = 0;
+        const unsigned nbf = (unsigned)(((int64_t)ca.n_cand + FILT_PER_BLOCK - 1) / FILT_PER_BLOCK);
+        hipLaunchKernelGGL(k_cand_filter, dim3(nbf * (unsigned)nq < 16384u ? nbf * (unsigned)nq : 16384u), dim3(TPB), 0, x->stream, ca, x->l_sims,
+                           sims_stride, x->l_sel_thr, K, SEL_SURVIVOR_CAP, x->l_sel_key[0], x->l_sel_val[0],
+                           x->l_sel_cnt, (int)nbf, nq);
+        // survivors of query q sit at [q * CAP, q * CAP + count); the rounds use stride CAP for them
+        BSC_TRY(bitonic_rounds(x, nq, SEL_SURVIVOR_CAP, x->l_sel_cnt, K, SEL_SURVIVOR_CAP, &cur));
+        stride = SEL_SURVIVOR_CAP;
+        *filtered = true;
     }
     BSC_HIP(hipGetLastError());
+    *win_keys = x->l_sel_key[cur];
+    *win_vals = x->l_sel_val[cur];
+    *win_stride = stride;
     return BSC_OK;
 }
 
@@ -282,6 +558,11 @@ bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T
     return BSC_OK;
 }
 
+// similarity rows of consecutive queries must not sit a power of two apart: a 2^22-byte stride puts the rows that
+// are read concurrently (8+ queries in flight) on the same HBM channel / bank set and the candidate passes drop to
+// 0.4 TB/s.  Rows are padded to a multiple of 64 floats plus an odd number of 256-byte units.
+int64_t sims_row_stride(int64_t n_rows) { return ((n_rows + 63) & ~(int64_t)63) + 64 * 33; }
+
 template <int QT>
 static void launch_cosine(bsc_ctx *x, const float *rows, int64_t n_rows, int q0)
 {
@@ -291,7 +572,7 @@ static void launch_cosine(bsc_ctx *x, const float *rows, int64_t n_rows, int q0)
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks), block(TPB);
-#define LC(NV) hipLaunchKernelGGL((k_cosine<NV, QT>), grid, block, 0, x->stream, rows, n_rows, D, x->l_q, q0, x->l_sims)
+#define LC(NV) hipLaunchKernelGGL((k_cosine<NV, QT>), grid, block, 0, x->stream, rows, n_rows, D, x->l_q, q0, x->l_sims, sims_row_stride(n_rows))
     if (nv <= 1) LC(1);
     else if (nv == 2) LC(2);
     else if (nv == 3) LC(3);
@@ -325,10 +606,27 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         hipLaunchKernelGGL(k_name_rank, cgrid, block, 0, s, n_cand, x->l_val_b, x->l_name_rank);
         x->names_dirty = false;
     }
+    {   // the MFMA path reads whole query tiles: zero-pad up to the next multiple of 256 (l_q holds 1024 rows)
+        const int padded = ((nq + 255) / 256) * 256;
+        BSC_HIP(hipMemsetAsync(x->l_q, 0, sizeof(float) * (size_t)(padded > 1024 ? 1024 : padded) * D, s));
+    }
     hipLaunchKernelGGL(k_normalize_q, dim3(nq), dim3(64), 0, s, q_dev, D, x->l_q);
     // dense acnt has no slot for the grid_0_0_0 group: k_candidates reads cnt[vcap]; acnt is allocated vcap+1
     int done = 0;
     stat_begin(x, 1);
+    const int64_t sstride = sims_row_stride(n_rows);
+    if (nq >= 16 && D % MF_KC == 0 && n_rows > 0) {
+        // batched queries: fp32 MFMA GEMM, 32-query tiles (l_q is zero-padded to a multiple of 32 rows)
+        const dim3 mgrid((unsigned)((n_rows + 127) / 128));
+        while (done < nq) {
+            const int left = nq - done;
+            if (left > 128) { hipLaunchKernelGGL((k_cosine_mfma<8>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 256; }
+            else if (left > 64) { hipLaunchKernelGGL((k_cosine_mfma<4>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 128; }
+            else if (left > 32) { hipLaunchKernelGGL((k_cosine_mfma<2>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 64; }
+            else { hipLaunchKernelGGL((k_cosine_mfma<1>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 32; }
+        }
+        done = nq;
+    }
     while (done < nq && n_rows > 0) {      // the row matrix is streamed once per group of up to 8 queries
         const int left = nq - done;
         if (left >= 8) { launch_cosine<8>(x, rows, n_rows, done); done += 8; }
@@ -337,15 +635,37 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         else { launch_cosine<1>(x, rows, n_rows, done); done += 1; }
     }
     stat_end(x, 1, (double)n_rows * D * 4.0 * ((nq + 7) / 8) + (double)nq * n_rows * 4.0);
-    const double r2 = radius * radius;
-    for (int qi = 0; qi < nq; ++qi) {
-        hipLaunchKernelGGL(k_candidates, cgrid, block, 0, s, n_cand, max_id, vcap, x->rgb_pos, cnt, x->store_rows,
-                           x->c.cache_size, exact ? 1 : 0, x->l_sims + (int64_t)qi * n_rows, x->l_name_rank, r2,
-                           radius >= 0 ? 1 : 0, curr ? curr[0] : 0, curr ? curr[1] : 0, curr ? curr[2] : 0, floor_lo,
-                           floor_hi, x->l_key_a, x->l_val_a);
-        BSC_TRY(select_topk(x, n_cand, K));
-        hipLaunchKernelGGL(k_gather_topk, dim3((K + TPB - 1) / TPB), block, 0, s, K, n_cand, max_id, vcap, x->l_key_b,
-                           x->l_val_b, x->rgb_pos, x->l_out_pos + (int64_t)qi * K * 3, x->l_out_sim + (int64_t)qi * K);
+    CandArgs ca;
+    ca.n_cand = n_cand; ca.max_id = max_id; ca.vcap = vcap; ca.cache_size = x->c.cache_size; ca.exact = exact ? 1 : 0;
+    ca.use_radius = radius >= 0 ? 1 : 0;
+    ca.c0 = curr ? curr[0] : 0; ca.c1 = curr ? curr[1] : 0; ca.c2 = curr ? curr[2] : 0;
+    ca.floor_lo = floor_lo; ca.floor_hi = floor_hi; ca.radius2 = radius * radius;
+    ca.rgb_pos = x->rgb_pos; ca.cnt = cnt; ca.store_rows = x->store_rows; ca.name_rank = x->l_name_rank;
+    bool filtered = false;
+    if (K <= TK_N / 2) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            u64 *wk; uint32_t *wv; int64_t ws;
+            BSC_TRY(select_topk_batched(x, ca, nq, sstride, K, attempt == 0 && nq >= 16, &wk, &wv, &ws, &filtered));
+            hipLaunchKernelGGL(k_gather_topk, dim3((K + TPB - 1) / TPB, (unsigned)nq), block, 0, s, K, /*entries*/ K, max_id,
+                               vcap, wk, wv, ws, x->rgb_pos, x->l_out_pos, x->l_out_sim);
+            if (!filtered) break;
+            int32_t *flag = (int32_t *)(x->l_sel_thr + nq);      // spare slot behind the thresholds
+            BSC_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_sel_check, dim3((nq + 255) / 256), dim3(256), 0, s, x->l_sel_thr, x->l_sel_cnt, nq,
+                               SEL_SURVIVOR_CAP, flag);
+            int32_t redo = 0;
+            BSC_HIP(hipMemcpyAsync(&redo, flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            BSC_HIP(hipStreamSynchronize(s));
+            if (!redo) break;
+        }
+    } else {                                   // large K: device-wide sort per query
+        for (int qi = 0; qi < nq; ++qi) {
+            hipLaunchKernelGGL(k_candidates, cgrid, block, 0, s, ca, x->l_sims + (int64_t)qi * sstride, x->l_key_a, x->l_val_a);
+            BSC_TRY(prim_sort_pairs(x, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b, (size_t)n_cand, 0, 64));
+            hipLaunchKernelGGL(k_gather_topk, dim3((K + TPB - 1) / TPB), block, 0, s, K, n_cand, max_id, vcap, x->l_key_b,
+                               x->l_val_b, (int64_t)0, x->rgb_pos, x->l_out_pos + (int64_t)qi * K * 3,
+                               x->l_out_sim + (int64_t)qi * K);
+        }
     }
     BSC_HIP(hipGetLastError());
     BSC_HIP(hipMemcpyAsync(out_pos, x->l_out_pos, sizeof(int32_t) * (size_t)nq * K * 3, hipMemcpyDeviceToHost, s));

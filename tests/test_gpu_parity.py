@@ -327,3 +327,51 @@ def test_two_shard_merge_on_one_gpu_equals_single_map(torch_cuda, mode):
     assert int(c0[0]) == 0 and (torch.isinf(a0).all() if mode == "max" else (a0 == 0).all())
     for e in shards + [full]:
         e.close()
+
+
+def test_mfma_batched_queries_match_single_query_path(torch_cuda):
+    """Q >= 16 takes the fp32-MFMA GEMM kernel (k_cosine_mfma); Q < 16 the wavefront-per-row kernel.  Same
+    similarities within fp32 summation-order noise, same top-K (ties in name order)."""
+    torch = torch_cuda
+    z = gu.load("g2_c1_s50_iid")            # D = 32: one K chunk of the MFMA kernel, ~11k voxels, tie-heavy tokens
+    cfg, eng, _ = _run_engine(torch, z)
+    eng.flush()
+    rs = np.random.RandomState(4)
+    for Q in (16, 40, 70, 130):
+        Qm = rs.standard_normal((Q, cfg["D"])).astype(np.float32)
+        pb, sb, nb = eng.localize(torch.from_numpy(Qm).cuda(), K=64)
+        for i in (0, 7, Q - 1):
+            p1, s1, n1 = eng.localize(torch.from_numpy(Qm[i:i + 1]).cuda(), K=64)
+            assert nb[i] == n1[0]
+            gu.assert_topk_matches(pb[i, :nb[i]], sb[i, :nb[i]], p1[0, :n1[0]], s1[0, :n1[0]], tol=2e-6)
+    eng.close()
+
+
+def test_large_map_localize_filter_path_matches_numpy(torch_cuda):
+    """> 256 k candidates take the sample-threshold filter; compare with a NumPy top-K on the same map, incl. an
+    adversarial layout (best rows last) that forces the fallback."""
+    import bsc_nav_amd as B
+    torch = torch_cuda
+    V, D, gs = 300_000, 32, 128
+    eng = B.VoxelEngine(48, 64, gs, 0.1, -6.4, 6.4, 16, D, mode="mean", voxel_capacity=V + 8, max_points=4096)
+    rs = np.random.RandomState(0)
+    codes = rs.permutation(gs ** 3)[:V]
+    keys = np.stack([codes // (gs * gs), (codes // gs) % gs, codes % gs], 1).astype(np.int32)
+    rows = rs.standard_normal((V, D)).astype(np.float32)
+    q = rs.standard_normal((20, D)).astype(np.float32)      # >= 16 queries: MFMA cosine + filtered selection
+    for adversarial in (False, True):
+        if adversarial:      # similarity to q[0] ascending with the index: the sample threshold is useless
+            order = np.argsort(rows @ q[0] / np.linalg.norm(rows, axis=1))
+            rows = rows[order]
+        eng.dense_replace(torch.from_numpy(keys).cuda(), torch.from_numpy(rows).cuda(),
+                          torch.ones(V, dtype=torch.int32, device="cuda"))
+        pos, sim, n = eng.localize(torch.from_numpy(q).cuda(), K=100)
+        rn = rows / np.maximum(np.linalg.norm(rows, axis=1, keepdims=True), 1e-8)
+        qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+        ref = qn @ rn.T
+        for i in range(len(q)):
+            top = np.argsort(-ref[i], kind="stable")[:100]
+            assert n[i] == 100
+            np.testing.assert_allclose(sim[i], ref[i][top], rtol=0, atol=3e-6)
+            assert set(map(tuple, pos[i].tolist())) == set(map(tuple, keys[top].tolist()))
+    eng.close()
