@@ -348,43 +348,51 @@ __device__ __forceinline__ void bitonic_1024(u64 *sk, uint32_t *sv)
 // first round, fused with the candidate scan: block (b, q) ranks candidates [1024 b, 1024 b + 1024) of query q
 __global__ __launch_bounds__(TPB) void k_cand_topk(CandArgs a, const float *__restrict__ sims, int64_t sims_stride, int K,
                                                    u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
-                                                   int64_t out_stride)
+                                                   int64_t out_stride, int nb, int nq)
 {
     __shared__ u64 sk[TK_N];
     __shared__ uint32_t sv[TK_N];
-    const float *qs = sims + (int64_t)blockIdx.y * sims_stride;
-    for (int i = threadIdx.x; i < TK_N; i += TPB) {
-        const int c = blockIdx.x * TK_N + i;
-        sk[i] = cand_key(a, c, qs);
-        sv[i] = (uint32_t)c;
-    }
-    __syncthreads();
-    bitonic_1024(sk, sv);
-    for (int i = threadIdx.x; i < K; i += TPB) {
-        out_keys[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sk[i];
-        out_vals[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sv[i];
+    for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
+        const int q = wi / nb, bx = wi - q * nb;
+        const float *qs = sims + (int64_t)q * sims_stride;
+        for (int i = threadIdx.x; i < TK_N; i += TPB) {
+            const int c = bx * TK_N + i;
+            sk[i] = cand_key(a, c, qs);
+            sv[i] = (uint32_t)c;
+        }
+        __syncthreads();
+        bitonic_1024(sk, sv);
+        for (int i = threadIdx.x; i < K; i += TPB) {
+            out_keys[(int64_t)q * out_stride + (int64_t)bx * K + i] = sk[i];
+            out_vals[(int64_t)q * out_stride + (int64_t)bx * K + i] = sv[i];
+        }
+        __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_keys, const uint32_t *__restrict__ in_vals,
                                                     int64_t n, const int32_t *__restrict__ n_per_q, int64_t in_stride, int K,
                                                     u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
-                                                    int64_t out_stride)
+                                                    int64_t out_stride, int nb, int nq)
 {
     __shared__ u64 sk[TK_N];
     __shared__ uint32_t sv[TK_N];
-    if (n_per_q) n = min((int64_t)n_per_q[blockIdx.y], n);
-    const int64_t base = (int64_t)blockIdx.x * TK_N;
-    for (int i = threadIdx.x; i < TK_N; i += TPB) {
-        const int64_t g = base + i;
-        sk[i] = g < n ? in_keys[(int64_t)blockIdx.y * in_stride + g] : ~0ull;
-        sv[i] = g < n ? in_vals[(int64_t)blockIdx.y * in_stride + g] : 0u;
-    }
-    __syncthreads();
-    bitonic_1024(sk, sv);
-    for (int i = threadIdx.x; i < K; i += TPB) {
-        out_keys[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sk[i];
-        out_vals[(int64_t)blockIdx.y * out_stride + (int64_t)blockIdx.x * K + i] = sv[i];
+    for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
+        const int q = wi / nb, bx = wi - q * nb;
+        const int64_t nn = n_per_q ? min((int64_t)n_per_q[q], n) : n;
+        const int64_t base = (int64_t)bx * TK_N;
+        for (int i = threadIdx.x; i < TK_N; i += TPB) {
+            const int64_t g = base + i;
+            sk[i] = g < nn ? in_keys[(int64_t)q * in_stride + g] : ~0ull;
+            sv[i] = g < nn ? in_vals[(int64_t)q * in_stride + g] : 0u;
+        }
+        __syncthreads();
+        bitonic_1024(sk, sv);
+        for (int i = threadIdx.x; i < K; i += TPB) {
+            out_keys[(int64_t)q * out_stride + (int64_t)bx * K + i] = sk[i];
+            out_vals[(int64_t)q * out_stride + (int64_t)bx * K + i] = sv[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -499,9 +507,10 @@ static bsc_status bitonic_rounds(bsc_ctx *x, int nq, int64_t n, const int32_t *n
     bool first = true;
     while (n > K || first) {
         const int64_t nb = (n + TK_N - 1) / TK_N;
-        hipLaunchKernelGGL(k_block_topk, dim3((unsigned)nb, (unsigned)nq), dim3(TPB), 0, x->stream, x->l_sel_key[*cur],
-                           x->l_sel_val[*cur], n, first ? n_per_q : (const int32_t *)nullptr, stride, K,
-                           x->l_sel_key[*cur ^ 1], x->l_sel_val[*cur ^ 1], stride);
+        const int64_t items = nb * nq;
+        hipLaunchKernelGGL(k_block_topk, dim3((unsigned)(items < 4096 ? items : 4096)), dim3(TPB), 0, x->stream,
+                           x->l_sel_key[*cur], x->l_sel_val[*cur], n, first ? n_per_q : (const int32_t *)nullptr, stride, K,
+                           x->l_sel_key[*cur ^ 1], x->l_sel_val[*cur ^ 1], stride, (int)nb, nq);
         *cur ^= 1;
         n = nb * K;
         first = false;
@@ -526,8 +535,8 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
     BSC_TRY(grow_dev((void **)&x->l_sel_cnt, &x->l_sel_cap[5], sizeof(int32_t) * nq));
     int cur = 0;
     // round 1 over the sample (or over everything), fused with the candidate keys
-    hipLaunchKernelGGL(k_cand_topk, dim3((unsigned)nbs, (unsigned)nq), dim3(TPB), 0, x->stream, ca, x->l_sims, sims_stride, K,
-                       x->l_sel_key[0], x->l_sel_val[0], stride);
+    hipLaunchKernelGGL(k_cand_topk, dim3((unsigned)(nbs * nq < 4096 ? nbs * nq : 4096)), dim3(TPB), 0, x->stream, ca, x->l_sims,
+                       sims_stride, K, x->l_sel_key[0], x->l_sel_val[0], stride, (int)nbs, nq);
     if (nbs > 1) BSC_TRY(bitonic_rounds(x, nq, nbs * K, nullptr, K, stride, &cur));
     *filtered = false;
     if (use_filter) {
