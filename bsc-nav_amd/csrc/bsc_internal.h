@@ -109,6 +109,8 @@ struct bsc_ctx {
     int32_t *l_out_pos;
     float *l_out_sim;
     bool names_dirty;
+    int last_nq, last_K;            // shape of the last bsc_localize call (its top-K stays resident for clustering)
+    int32_t last_counts[1024];
     // primitives workspace
     void *prim_tmp;
     size_t prim_tmp_bytes;

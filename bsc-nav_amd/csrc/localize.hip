@@ -684,6 +684,9 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         int n = 0;
         while (n < K && out_pos[((int64_t)qi * K + n) * 3] >= 0) ++n;
         out_count[qi] = n;
+        x->last_counts[qi] = n;
     }
+    x->last_nq = nq;
+    x->last_K = K;
     return BSC_OK;
 }

@@ -186,6 +186,19 @@ class VoxelEngine:
                                          lo, hi, _hp(pos), _hp(sim), _hp(cnt)))
         return pos, sim, cnt
 
+    def cluster_centers(self, pos=None, sim=None, K=None, query_index=0, eps=10.0, min_samples=5):
+        """BSCAgent.weighted_cluster_centers on the GPU -> (centers (n,3) f64, labels (K,) int, sizes list).
+        pos/sim None: cluster the first K results of query `query_index` of the last localize call (no host copy)."""
+        if pos is not None:
+            pos = np.ascontiguousarray(pos, np.int32)
+            sim = np.ascontiguousarray(sim, np.float32)
+            K = len(pos)
+        centers, labels, sizes = np.zeros((K, 3), np.float64), np.zeros(K, np.int32), np.zeros(K, np.int32)
+        n = np.zeros(1, np.int32)
+        _lib.check(self.lib.bsc_cluster_centers(self.h, query_index, K, _hp(pos), _hp(sim), float(eps), int(min_samples),
+                                                _hp(centers), _hp(labels), _hp(sizes), _hp(n)))
+        return centers[:n[0]], labels.astype(np.int64), [int(v) for v in sizes[:n[0]]]
+
     def kernel_stats(self, which=0, reset=False):
         """HIP-event time of the dominant kernel: dict(ms, launches, bytes, launches_since_reset)."""
         out = np.zeros(4, np.float64)

@@ -268,6 +268,11 @@ class VoxelTokenMemory:
         self._log(f"finish localizing, time:{time.time() - t1}")
         return np.array([top_pos[0]]), top_pos, top_sim
 
+    def weighted_cluster_centers(self, top_k_positions, top_k_similarity, eps=10, min_samples=5):
+        """GESObjectNavRobot.weighted_cluster_centers (BSCAgent.py:479-497) on the GPU: DBSCAN over the top-K voxel
+        positions + similarity-weighted centres -> (cluster_centers (n,3) f64, labels (K,), cluster_sizes)."""
+        return self.engine.cluster_centers(top_k_positions, top_k_similarity, eps=eps, min_samples=min_samples)
+
     def long_memory_filter(self):
         """memory_2.py:693-705."""
         if getattr(self.args, "load_single_floor", False) and hasattr(self, "floor_min_height"):

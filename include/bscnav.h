@@ -127,6 +127,15 @@ bsc_status bsc_localize(bsc_ctx *ctx, const float *q_dev, int32_t n_queries, int
                         const int32_t *curr_host, int32_t floor_lo, int32_t floor_hi, int32_t *out_pos_host,
                         float *out_sim_host, int32_t *out_count_host);
 
+/* GESObjectNavRobot.weighted_cluster_centers (BSCAgent.py:479-497), the consumer of voxel_localized's output:
+ * DBSCAN(eps, min_samples) over K top-ranked positions (scikit-learn semantics), similarity-weighted centres,
+ * clusters ordered by mean similarity (stable, descending).  pos_host (K,3) / sim_host (K) NULL = cluster the first K
+ * results of query `query_index` of the last bsc_localize call, which are still resident in HBM.
+ * centers_host (K,3) f64 (first n_clusters rows valid), labels_host (K) (-1 noise), sizes_host (K).  K <= 1024. */
+bsc_status bsc_cluster_centers(bsc_ctx *ctx, int32_t query_index, int32_t K, const int32_t *pos_host,
+                               const float *sim_host, double eps, int32_t min_samples, double *centers_host,
+                               int32_t *labels_host, int32_t *sizes_host, int32_t *n_clusters_host);
+
 /* multi-GPU merge helpers (dense modes).  The library never calls RCCL: the host
  * moves the buffers with torch.distributed and hands them back.
  *   bsc_dense_gather : rows of the local map for the given voxel keys -> acc_dev (n,D), cnt_dev (n);

@@ -559,3 +559,66 @@ int32_t orc_localize(const orc_mem *m, const float *q, int32_t K, double radius,
     free(cands); free(o); free(qn);
     return n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* BSCAgent.py:479-497 weighted_cluster_centers                               */
+/* ------------------------------------------------------------------------- */
+int32_t orc_cluster_centers(const int32_t *pos, const double *sim, int32_t K, double eps, int32_t min_samples,
+                            double *centers, int32_t *labels, int32_t *sizes)
+{
+    uint8_t *nb = (uint8_t *)calloc((size_t)K * K, 1);
+    uint8_t *core = (uint8_t *)calloc(K, 1);
+    int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * (size_t)K * K + 16);
+    for (int i = 0; i < K; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < K; ++j) {
+            double dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+            if (sqrt(dx * dx + dy * dy + dz * dz) <= eps) { nb[(size_t)i * K + j] = 1; ++cnt; }
+        }
+        core[i] = cnt >= min_samples;           /* the point itself counts (sklearn DBSCAN) */
+        labels[i] = -1;
+    }
+    int32_t label_num = 0;
+    for (int s0 = 0; s0 < K; ++s0) {            /* sklearn.cluster._dbscan_inner.dbscan_inner */
+        if (labels[s0] != -1 || !core[s0]) continue;
+        int64_t sp = 0;
+        int i = s0;
+        for (;;) {
+            if (labels[i] == -1) {
+                labels[i] = label_num;
+                if (core[i])
+                    for (int j = 0; j < K; ++j)
+                        if (nb[(size_t)i * K + j] && labels[j] == -1) stack[sp++] = j;
+            }
+            if (sp == 0) break;
+            i = stack[--sp];
+        }
+        ++label_num;
+    }
+    /* BSCAgent.py:484-491: per cluster np.average(points, weights=sim), np.mean(sim), size */
+    double *avg = (double *)malloc(sizeof(double) * (label_num ? label_num : 1));
+    double *ctr = (double *)malloc(sizeof(double) * 3 * (label_num ? label_num : 1));
+    int32_t *sz = (int32_t *)malloc(sizeof(int32_t) * (label_num ? label_num : 1));
+    for (int l = 0; l < label_num; ++l) {
+        double sw = 0.0, sx = 0.0, sy = 0.0, szz = 0.0;
+        int n = 0;
+        for (int i = 0; i < K; ++i)
+            if (labels[i] == l) {
+                sw += sim[i];
+                sx += pos[3 * i] * sim[i]; sy += pos[3 * i + 1] * sim[i]; szz += pos[3 * i + 2] * sim[i];
+                ++n;
+            }
+        avg[l] = sw / n; sz[l] = n;
+        ctr[3 * l] = sx / sw; ctr[3 * l + 1] = sy / sw; ctr[3 * l + 2] = szz / sw;
+    }
+    /* :493 stable sort by mean similarity, descending */
+    for (int l = 0; l < label_num; ++l) {
+        int rank = 0;
+        for (int m = 0; m < label_num; ++m)
+            if (avg[m] > avg[l] || (avg[m] == avg[l] && m < l)) ++rank;
+        memcpy(centers + 3 * rank, ctr + 3 * l, sizeof(double) * 3);
+        sizes[rank] = sz[l];
+    }
+    free(nb); free(core); free(stack); free(avg); free(ctr); free(sz);
+    return label_num;
+}

@@ -93,6 +93,14 @@ void orc_pool_query(const float *tokens, int32_t B, int32_t T, int32_t D, float 
 int32_t orc_localize(const orc_mem *m, const float *q, int32_t K, double radius, const int32_t *curr,
                      int32_t floor_lo, int32_t floor_hi, int32_t *out_pos /*(K,3)*/, float *out_sim);
 
+/* GESObjectNavRobot.weighted_cluster_centers (BSCAgent.py:479-497): DBSCAN(eps, min_samples) over the top-K voxel
+ * positions (scikit-learn's algorithm restated: brute-force eps-neighbourhoods incl. the point itself, clusters
+ * grown depth-first from unlabelled core points in index order, border points keep the first cluster that reaches
+ * them), similarity-weighted centres, clusters ordered by mean similarity (stable, descending).
+ * centers (K,3) f64, labels (K) i32 (-1 noise), sizes (K) i32; returns the number of clusters. */
+int32_t orc_cluster_centers(const int32_t *pos, const double *sim, int32_t K, double eps, int32_t min_samples,
+                            double *centers, int32_t *labels, int32_t *sizes);
+
 /* name-order key of "grid_r_c_h" (bytewise string order) */
 uint64_t orc_name_key(int32_t r, int32_t c, int32_t h);
 

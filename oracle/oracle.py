@@ -63,6 +63,8 @@ def lib():
         L.orc_localize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p]
         L.orc_geometry.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_void_p] * 9
+        L.orc_cluster_centers.restype = C.c_int32
+        L.orc_cluster_centers.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_name_key.restype = C.c_uint64
         L.orc_name_key.argtypes = [C.c_int32] * 3
         _lib = L
@@ -257,3 +259,13 @@ def geometry(cfg, depth, idx, T):
 
 def name_key(r, c, h):
     return int(lib().orc_name_key(int(r), int(c), int(h)))
+
+
+def cluster_centers(pos, sim, eps=10.0, min_samples=5):
+    """BSCAgent.py:479-497 -> (centers (n,3) f64, labels (K,) i32, sizes (n,) i32)."""
+    pos = np.ascontiguousarray(pos, np.int32)
+    sim = np.ascontiguousarray(sim, np.float64)
+    K = len(pos)
+    centers, labels, sizes = np.zeros((K, 3)), np.zeros(K, np.int32), np.zeros(K, np.int32)
+    n = lib().orc_cluster_centers(_p(pos), _p(sim), K, float(eps), int(min_samples), _p(centers), _p(labels), _p(sizes))
+    return centers[:n], labels, sizes[:n]

@@ -375,3 +375,36 @@ def test_large_map_localize_filter_path_matches_numpy(torch_cuda):
             np.testing.assert_allclose(sim[i], ref[i][top], rtol=0, atol=3e-6)
             assert set(map(tuple, pos[i].tolist())) == set(map(tuple, keys[top].tolist()))
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["c1", "c2", "c3", "c4", "c5", "c6", "c7"])
+def test_cluster_centers_match_reference(torch_cuda, case):
+    """bsc_cluster_centers == GESObjectNavRobot.weighted_cluster_centers (BSCAgent.py:479-497) on the reference's own
+    outputs: DBSCAN labels and sizes exact, centres 1e-12 relative (f64 sums in the same index order)."""
+    import bsc_nav_amd as B
+    z = gu.load("g5_cluster_centers")
+    eng = B.VoxelEngine(48, 64, 64, 0.1, -3.2, 3.2, 16, 16, mode="mean", voxel_capacity=64, max_points=4096)
+    centers, labels, sizes = eng.cluster_centers(z[f"{case}_pos"], z[f"{case}_sim"])
+    assert np.array_equal(labels, z[f"{case}_labels"])
+    assert sizes == [int(v) for v in z[f"{case}_sizes"]]
+    assert centers.shape == z[f"{case}_centers"].shape and centers.dtype == np.float64
+    np.testing.assert_allclose(centers, z[f"{case}_centers"], rtol=1e-12, atol=0)
+    eng.close()
+
+
+def test_cluster_centers_on_resident_topk(torch_cuda):
+    """Clustering straight from the last localize call's device-resident top-K == clustering its host copy."""
+    from oracle import oracle as orc
+    torch = torch_cuda
+    z = gu.load("g2_mini_s1")
+    cfg, eng, _ = _run_engine(torch, z)
+    eng.flush()
+    q = next(x for x in gu.query_specs(z) if x["K"] == 100)
+    pos, sim, n = eng.localize(torch.from_numpy(q["pooled"].reshape(1, -1)).cuda(), K=100)
+    c_dev, l_dev, s_dev = eng.cluster_centers(K=int(n[0]))
+    c_host, l_host, s_host = eng.cluster_centers(pos[0, :n[0]], sim[0, :n[0]])
+    c_orc, l_orc, s_orc = orc.cluster_centers(pos[0, :n[0]], sim[0, :n[0]].astype(np.float64))
+    assert np.array_equal(l_dev, l_host) and np.array_equal(l_dev, l_orc) and s_dev == s_host == list(s_orc)
+    assert np.array_equal(c_dev, c_host)
+    np.testing.assert_allclose(c_dev, c_orc, rtol=1e-12, atol=0)
+    eng.close()

@@ -152,3 +152,14 @@ def test_localize_output_format_matches_reference_exemplars():
     z = gu.load("g2_mini_s1")
     q = next(x for x in gu.query_specs(z) if x["K"] == 100)
     assert q["pos"].shape == (100, 3) and q["pos"].dtype == np.int64 and q["sim"].dtype == np.float64
+
+
+@pytest.mark.parametrize("case", ["c1", "c2", "c3", "c4", "c5", "c6", "c7"])
+def test_cluster_centers_match_reference(case):
+    """weighted_cluster_centers (BSCAgent.py:479-497): labels exact, sizes exact, centres to 1e-12 relative."""
+    z = gu.load("g5_cluster_centers")
+    centers, labels, sizes = orc.cluster_centers(z[f"{case}_pos"], z[f"{case}_sim"])
+    assert np.array_equal(labels, z[f"{case}_labels"])
+    assert np.array_equal(sizes, z[f"{case}_sizes"])
+    assert centers.shape == z[f"{case}_centers"].shape
+    np.testing.assert_allclose(centers, z[f"{case}_centers"], rtol=1e-12, atol=0)
