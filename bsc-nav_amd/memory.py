@@ -365,8 +365,59 @@ class VoxelTokenMemory:
     # ------------------------------------------------------------------------------------------
     # simulator-driven loops: thin restatements over an injected NavEnv-like `Env` (env.py:49-296)
     def long_memory(self, obs):
-        """memory_2.py:905-945 needs the YOLO-World detector; out of scope of the hot path."""
-        return None
+        """memory_2.py:905-945: detector boxes -> depth at the box centre -> voxel location -> {label, loc, confidence}.
+
+        The detector (YOLO-World in the reference) is an injected collaborator: anything whose
+        ``predict(PIL.Image, conf=...)`` returns ``[result]`` with ``result.boxes.{xyxy, conf, cls}``.  The geometry of the
+        box-centre pixels runs through the same fp64 kernel as the voxel path (``bsc_geometry``)."""
+        if self.yolow is None:
+            return None
+        from PIL import Image
+        rgb = np.ascontiguousarray(np.array(obs["rgb"])[:, :, :3])
+        self.yolow_results = self.yolow.predict(Image.fromarray(rgb), conf=getattr(self.args, "detect_conf", 0.55))
+        boxes = self.yolow_results[0].boxes
+        if len(boxes) > 0:
+            depth = np.ascontiguousarray(np.array(obs["depth"]), dtype=np.float32)
+            width = int(getattr(self.args, "width", depth.shape[1]))
+            idx, confs, labels = [], [], []
+            for i in range(len(boxes.conf)):
+                xyxy = boxes.xyxy[i].cpu().numpy()
+                col = int((xyxy[0] + xyxy[2]) / 2)
+                row = int((xyxy[1] + xyxy[3]) / 2)
+                idx.append(row * width + col)                                     # :917-919
+                confs.append(boxes.conf[i].item())
+                labels.append(self.args.detect_classes[int(boxes.cls[i].item())])
+            T = self.chain.tf @ self.chain.base_transform @ self.chain.base2cam_tf   # :930 (pose of the last ingested frame)
+            g = self.engine.geometry(torch.from_numpy(depth).to(self.device), T,
+                                     torch.from_numpy(np.asarray(idx, dtype=np.int32)).to(self.device))
+            for i in range(len(idx)):
+                if not (g["flags"][i] & 1):        # :921 depth mask
+                    continue
+                if not (g["flags"][i] & 2):        # :935 _out_of_range
+                    continue
+                r, c, h = (int(v) for v in g["vox"][i])
+                self.long_memory_dict.append({"label": labels[i], "loc": [r, c, h - self.minh], "confidence": confs[i]})
+        self.long_memory_integration()
+
+    def long_memory_integration(self, threshold=3):
+        """memory_2.py:993-1025: per label, entries within L1 distance `threshold` merge, keeping the most confident."""
+        groups = {}
+        for item in self.long_memory_dict:
+            groups.setdefault(item["label"], []).append(item)
+        final = []
+        for label, items in groups.items():
+            kept = []
+            for itm in items:
+                for f in kept:
+                    if sum(abs(a - b) for a, b in zip(f["loc"], itm["loc"])) <= threshold:
+                        if itm["confidence"] > f["confidence"]:
+                            f["loc"] = itm["loc"]
+                            f["confidence"] = itm["confidence"]
+                        break
+                else:
+                    kept.append(itm)
+            final.extend(kept)
+        self.long_memory_dict = final
 
     def excute(self, obs, actions):
         """memory_2.py:1086-1101."""

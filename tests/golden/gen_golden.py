@@ -322,6 +322,57 @@ def run_geometry(ref_utils, name, H, W, gs, cs, floor_h, map_h, g, seed, n_pick,
     print(f"{name}: {len(pick)} points, pixel-column knife-edge shifts={shifted} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+class _FakeBoxes:
+    def __init__(self, xyxy, conf, cls):
+        import torch
+        self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32), torch.tensor(conf), torch.tensor(cls)
+
+    def __len__(self):
+        return len(self.conf)
+
+
+def fake_detections(seed, f, H, W, n_cls):
+    """Seeded stand-in for YOLO-World output (ultralytics Results[0].boxes): xyxy, conf, cls."""
+    rs = np.random.RandomState(seed * 1000 + f)
+    n = rs.randint(0, 6)
+    x0 = rs.uniform(0, W - 40, size=n); y0 = rs.uniform(0, H - 40, size=n)
+    x1 = x0 + rs.uniform(8, 39, size=n); y1 = y0 + rs.uniform(8, 39, size=n)
+    return np.stack([x0, y0, x1, y1], 1).reshape(n, 4), rs.uniform(0.55, 0.99, size=n), rs.randint(0, n_cls, size=n)
+
+
+def run_long_memory(ref_utils, ref_mem, name, cfg, out_dir):
+    """memory_2.py:905-945,993-1025 — long_memory / long_memory_integration with seeded detections."""
+    seed = cfg["seed"]
+    rgb, depth, poses = synth.make_frames(seed, cfg["F"], cfg["H"], cfg["W"], cfg["kind"])
+    tokens = tag_tokens(synth.make_tokens(seed, cfg["F"], cfg["g"], cfg["D"]))
+    M = make_ref_memory(ref_utils, ref_mem, cfg, tokens, f"mem://{name}")
+    classes = ["chair", "table", "sofa", "plant"]
+    M.args.detect_conf, M.args.detect_classes, M.args.width = 0.55, classes, cfg["W"]
+    M.long_memory_dict = []
+    np.random.seed(seed)
+    random.seed(seed)
+    import io
+    import contextlib
+    sink = io.StringIO()
+    per_frame = []
+    for f in range(cfg["F"]):
+        M._frame = f
+        xyxy, conf, cls = fake_detections(seed, f, cfg["H"], cfg["W"], len(classes))
+        M.yolow = types.SimpleNamespace(predict=lambda img, conf=None, _b=_FakeBoxes(xyxy, conf, cls): [types.SimpleNamespace(boxes=_b)])
+        with contextlib.redirect_stdout(sink):
+            M.obs2voxeltoken({"rgb": rgb[f], "depth": depth[f]}, poses[f])
+            M.long_memory({"rgb": rgb[f], "depth": depth[f]})
+        per_frame.append(len(M.long_memory_dict))
+    lm = M.long_memory_dict
+    np.savez_compressed(os.path.join(out_dir, f"{name}.npz"),
+                        cfg_keys=np.array(sorted(cfg.keys())), cfg_vals=np.array([str(cfg[k]) for k in sorted(cfg.keys())]),
+                        input_sha=np.array(synth.checksum(rgb, depth, poses, tokens)), classes=np.array(classes),
+                        per_frame=np.array(per_frame), label=np.array([classes.index(o["label"]) for o in lm]),
+                        loc=np.array([o["loc"] for o in lm], dtype=np.int64).reshape(-1, 3),
+                        confidence=np.array([o["confidence"] for o in lm], dtype=np.float64))
+    print(f"{name}: {len(lm)} objects after {cfg['F']} frames, per-frame counts {per_frame}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -344,6 +395,8 @@ def main():
                a.out, queries=qs[:3])
     run_ingest(ref_utils, ref_mem, "g2_c1_s1000", dict(base, seed=4, F=12, H=240, W=320, kind="room", g=14, D=32, s=1000),
                a.out, queries=qs[:2])
+    run_long_memory(ref_utils, ref_mem, "g6_long_memory", dict(base, seed=8, F=24, H=240, W=320, kind="room", g=14, D=8, s=1000),
+                    a.out)
     # small token cache: in-loop flushes, dropped trigger tokens, >10 tokens per voxel with random replacement
     run_ingest(ref_utils, ref_mem, "g3_flush_small_cache",
                dict(base, seed=5, F=6, H=48, W=64, kind="room", g=16, D=16, s=1, iter_size=1500), a.out, queries=qs[:2] + qs[4:5])

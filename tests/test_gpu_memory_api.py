@@ -158,3 +158,50 @@ def test_fused_preprocess_matches_torch_interpolate(hw):
     err = (out.float() - ref).abs()
     assert err.max().item() < 0.02, err.max().item()       # bf16 rounding of values up to ~2.6
     assert err.mean().item() < 0.004
+
+
+def test_long_memory_matches_reference(tmp_path):
+    """long_memory + long_memory_integration (memory_2.py:905-945, 993-1025) with seeded detector boxes: same objects,
+    same voxel locations, same confidences, frame by frame."""
+    import torch
+    import synth
+    z = gu.load("g6_long_memory")
+    cfg = gu.cfg_of(z)
+    rgb, depth, poses = synth.make_frames(cfg["seed"], cfg["F"], cfg["H"], cfg["W"], cfg["kind"])
+    tokens = gu.tag_tokens(synth.make_tokens(cfg["seed"], cfg["F"], cfg["g"], cfg["D"]))
+    assert synth.checksum(rgb, depth, poses, tokens) == str(z["input_sha"])
+    classes = [str(c) for c in z["classes"]]
+    mem, dino, args = _memory(cfg, tokens, tmp_path)
+    args.detect_conf, args.detect_classes = 0.55, classes
+    mem.args = args
+
+    class Boxes:
+        def __init__(self, xyxy, conf, cls):
+            self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32), torch.tensor(conf), torch.tensor(cls)
+
+        def __len__(self):
+            return len(self.conf)
+
+    def detections(f):      # same seeded stand-in as tests/golden/gen_golden.py:fake_detections
+        rs = np.random.RandomState(cfg["seed"] * 1000 + f)
+        n = rs.randint(0, 6)
+        x0 = rs.uniform(0, cfg["W"] - 40, size=n); y0 = rs.uniform(0, cfg["H"] - 40, size=n)
+        x1 = x0 + rs.uniform(8, 39, size=n); y1 = y0 + rs.uniform(8, 39, size=n)
+        return np.stack([x0, y0, x1, y1], 1).reshape(n, 4), rs.uniform(0.55, 0.99, size=n), rs.randint(0, len(classes), size=n)
+
+    np.random.seed(cfg["seed"])
+    random.seed(cfg["seed"])
+    counts = []
+    for f in range(cfg["F"]):
+        dino.frame = f
+        b = Boxes(*detections(f))
+        mem.yolow = types.SimpleNamespace(predict=lambda img, conf=None, _b=b: [types.SimpleNamespace(boxes=_b)])
+        obs = {"rgb": rgb[f], "depth": depth[f]}
+        mem.obs2voxeltoken(obs, poses[f])
+        mem.long_memory(obs)
+        counts.append(len(mem.long_memory_dict))
+    assert counts == [int(v) for v in z["per_frame"]]
+    lm = mem.long_memory_dict
+    assert [classes.index(o["label"]) for o in lm] == [int(v) for v in z["label"]]
+    assert np.array_equal(np.array([o["loc"] for o in lm]), z["loc"])
+    np.testing.assert_allclose([o["confidence"] for o in lm], z["confidence"], rtol=0, atol=0)
