@@ -1,0 +1,144 @@
+"""Edge cases and BASELINE-size properties of the HIP path (empty / ragged inputs, maximum sizes,
+size-independent invariants where the sequential oracle would take minutes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(mode="mean", H=48, W=64, gs=128, D=16, g=16, **kw):
+    import bsc_nav_amd as B
+    return B.VoxelEngine(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=mode, **kw)
+
+
+def _frames(F, H, W, seed=0, kind="room"):
+    import synth
+    return synth.make_frames(seed, F, H, W, kind)
+
+
+@pytest.mark.parametrize("mode", ["mean", "exact"])
+def test_frames_without_a_single_valid_point(mode):
+    import torch
+    import bsc_nav_amd as B
+    H, W, D, g = 48, 64, 16, 16
+    eng = _eng(mode, max_points=4 * H * W)
+    rgb = torch.zeros((2, H, W, 3), dtype=torch.uint8, device="cuda")
+    tok = torch.randn((2, g, g, D), device="cuda")
+    T = np.stack([np.eye(4)] * 2)
+    for depth_val in (0.0, 50.0, float("nan")):            # below min_depth, above max_depth, NaN
+        depth = torch.full((2, H, W), depth_val, device="cuda")
+        eng.ingest(depth, rgb, tok, T)
+    far = torch.full((2, H, W), 9.9, device="cuda")          # valid depth but outside a 12.8 m grid after a big shift
+    Tfar = T.copy(); Tfar[:, 0, 3] = 500.0
+    eng.ingest(far, rgb, tok, Tfar)
+    k = eng.counters()
+    assert k["max_id"] == 0 and k["points_passed"] == 0 and k["points_seen"] == 4 * 2 * H * W
+    if mode == "exact":
+        eng.flush()                                          # zero rows only: the grid_0_0_0 quirk group
+        pos, cnt, feats, dists = eng.export_store()
+        assert pos.tolist() == [[0, 0, 0]] and cnt.tolist() == [10] and not feats.any()
+    p, s, n = eng.localize(torch.randn(1, D, device="cuda"), K=5)
+    assert n[0] == (1 if mode == "exact" else 0)             # the reference would also find only grid_0_0_0
+    eng.close()
+
+
+def test_ragged_batch_with_empty_and_single_point_frames():
+    import torch
+    import bsc_nav_amd as B
+    from oracle import oracle as orc
+    H, W, D, g, F = 48, 64, 16, 16, 4
+    rgb, depth, poses = _frames(F, H, W, seed=3)
+    import synth
+    tokens = synth.make_tokens(3, F, g, D)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    rs = np.random.RandomState(0)
+    idxs = [rs.permutation(H * W)[:300].astype(np.int32), np.zeros(0, np.int32), rs.permutation(H * W)[:1].astype(np.int32),
+            rs.permutation(H * W)[:777].astype(np.int32)]
+    off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
+    eng = _eng("mean", max_points=4096)
+    eng.ingest(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(tokens).cuda(), Ts,
+               torch.from_numpy(np.concatenate(idxs)).cuda(), off)
+    oc = orc.make_config(H, W, 128, 0.1, -6.4, 6.4, g, D, mode=1)
+    om = orc.OracleMemory(oc)
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], idxs[f], Ts[f], tokens[f])
+    acc, cnt = eng.export_dense()
+    oacc, ocnt = om.export_dense()
+    assert np.array_equal(eng.export_rgb()[0], om.export_rgb()[0]) and np.array_equal(cnt, ocnt)
+    np.testing.assert_allclose(acc, oacc, rtol=1e-3, atol=1e-3)
+    eng.close()
+
+
+def test_localize_k_larger_than_map_and_large_k():
+    import torch
+    eng = _eng("mean", voxel_capacity=5000, max_points=4096)
+    rs = np.random.RandomState(1)
+    keys = np.unique(rs.randint(0, 128, size=(700, 3)), axis=0).astype(np.int32)
+    rows = rs.standard_normal((len(keys), 16)).astype(np.float32)
+    eng.dense_replace(torch.from_numpy(keys).cuda(), torch.from_numpy(rows).cuda(),
+                      torch.ones(len(keys), dtype=torch.int32, device="cuda"))
+    q = rs.standard_normal((2, 16)).astype(np.float32)
+    ref = (q / np.linalg.norm(q, axis=1, keepdims=True)) @ (rows / np.linalg.norm(rows, axis=1, keepdims=True)).T
+    for K in (5, 600, 1000, 4096):                           # 600 > 512: device-wide sort path; 1000, 4096 > voxels
+        pos, sim, n = eng.localize(torch.from_numpy(q).cuda(), K=K)
+        for i in range(2):
+            m = min(K, len(keys))
+            assert n[i] == m
+            order = np.argsort(-ref[i], kind="stable")[:m]
+            np.testing.assert_allclose(sim[i, :m], ref[i][order], atol=3e-6, rtol=0)
+            assert np.array_equal(pos[i, :m], keys[order]) or set(map(tuple, pos[i, :m].tolist())) == set(map(tuple, keys[order].tolist()))
+    eng.close()
+
+
+def test_full_size_invariants_640x480_d768():
+    """BASELINE configs[1] size (640x480, 768-D, 256^3, every pixel): properties that do not need the sequential oracle."""
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import synthetic
+    H, W, D, g, gs, F = 480, 640, 768, 14, 256, 8
+    poses = synthetic.random_walk_poses(11, F)
+    rgb, depth, _ = synthetic.make_frames(11, F, H, W, "room", poses=poses)
+    tok = torch.randn((F, g, g, D), device="cuda")
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+
+    def build(splits, repeat=1):
+        e = B.VoxelEngine(H, W, gs, 0.1, -12.8, 12.8, g, D, mode="mean", voxel_capacity=400_000, max_points=F * H * W)
+        for _ in range(repeat):
+            for a, b in splits:
+                e.ingest(depth[a:b].contiguous(), rgb[a:b].contiguous(), tok[a:b].contiguous(), Ts[a:b])
+        return e
+
+    one = build([(0, F)])
+    four = build([(0, 2), (2, 4), (4, 6), (6, 8)])
+    twice = build([(0, F)], repeat=2)
+    p1, r1, w1 = one.export_rgb()
+    p4, r4, w4 = four.export_rgb()
+    a1, c1 = one.export_dense()
+    a4, c4 = four.export_dense()
+    a2, c2 = twice.export_dense()
+    k = one.counters()
+    # (1) batching does not change the order-defined state: ids, rgb bytes, weights are identical for 1 call vs 4 calls
+    assert np.array_equal(p1, p4) and np.array_equal(r1, r4) and np.array_equal(w1, w4) and np.array_equal(c1, c4)
+    np.testing.assert_allclose(a1, a4, rtol=1e-3, atol=1e-3)                 # fp32 sums, different association
+    # (2) conservation: every passing point is counted exactly once
+    assert int(c1.astype(np.int64).sum()) == k["points_passed"] and k["points_seen"] == F * H * W
+    assert np.array_equal(one.export_occupied()[p1[:, 0], p1[:, 1], p1[:, 2]], np.arange(len(p1)))
+    # (3) linearity: the same frames twice double counts and sums (sums exactly: x + x)
+    assert np.array_equal(c2, 2 * c1)
+    np.testing.assert_allclose(a2, 2 * a1, rtol=1e-5, atol=1e-4)
+    # (4) the top-down map holds the highest voxel of every column
+    mh, _ = one.export_heightmap()
+    col_max = np.full((gs, gs), -np.inf)
+    np.maximum.at(col_max, (p1[:, 0], p1[:, 1]), p1[:, 2].astype(np.float64))
+    assert np.array_equal(mh, col_max)
+    # (5) a voxel's own mean row localizes to that voxel with similarity 1
+    v = int(np.argmax(c1))
+    q = torch.from_numpy((a1[v] / c1[v]).astype(np.float32)).cuda().reshape(1, -1)
+    pos, sim, n = one.localize(q, K=3)
+    assert abs(sim[0, 0] - 1.0) < 1e-5 and sim[0, 0] >= sim[0, 1]
+    ties = np.isclose(sim[0, :n[0]], sim[0, 0], atol=1e-6)
+    assert any(np.array_equal(pos[0, i], p1[v]) for i in np.nonzero(ties)[0])
+    for e in (one, four, twice):
+        e.close()
