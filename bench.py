@@ -19,11 +19,24 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Library-GEMM selection for the encoder: PyTorch TunableOp picks the fastest hipBLASLt / rocBLAS solution per GEMM
+# shape.  The choices for the default shapes are committed (bsc-nav_amd/tunableop_gfx950.csv); shapes not in the file
+# are tuned during the warm-up steps, before the clock starts.  Must be configured before torch is imported.
+if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+    import shutil
+    import tempfile
+    _src = os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
+    _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.environ.get('LOCAL_RANK', '0')}_{os.getpid()}.csv")
+    if os.path.exists(_src):
+        shutil.copy(_src, _dst)
+    os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=_dst,
+                      PYTORCH_TUNABLEOP_VERBOSE="0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 

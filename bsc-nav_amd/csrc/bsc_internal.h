@@ -7,6 +7,12 @@
 #include "../../include/bscnav.h"
 
 typedef unsigned long long u64;
+// per-point payload of the rgb chain: one 16-byte gather per point instead of an 8-byte and a 4-byte one
+struct alignas(16) PointRec {
+    double alpha;      // exp(-r^2 / 1.2)   (memory_2.py:875)
+    uint32_t rgbv;     // rgb[py, px] packed r | g << 8 | b << 16   (memory_2.py:870)
+    uint32_t pad;
+};
 #define BSC_EV_RING 512
 
 // device scalar block indices (int64 each)
@@ -62,9 +68,8 @@ struct bsc_ctx {
     // ---- per-batch scratch (max_points) ----
     int32_t *p_cell;
     uint32_t *p_patf;
-    uint32_t *p_rgbv_s[2];   // double-buffered: read by the rgb chain on the side stream
+    PointRec *p_rec_s[2];    // double-buffered: read by the rgb chain on the side stream
     float *p_r2f;
-    double *p_alpha_s[2];
     int64_t *p_scan_in, *p_scan_out;
     uint32_t *skey_a, *sval_a;          // point sort: key = voxel id, value = j (stable radix sort keeps j order)
     uint32_t *skey_b_s[2], *sval_b_s[2];

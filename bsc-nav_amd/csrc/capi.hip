@@ -158,7 +158,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
-        ALLOC(x->p_rgbv_s[k], np); ALLOC(x->p_alpha_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
+        ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
         ALLOC(x->seg_start_s[k], np); ALLOC(x->seg_last_s[k], np); ALLOC(x->bscal_s[k], 4);
         BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
         BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
@@ -208,7 +208,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     hipStreamSynchronize(x->stream);
     void *ptrs[] = {x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
-                    x->p_rgbv_s[0], x->p_rgbv_s[1], x->p_r2f, x->p_alpha_s[0], x->p_alpha_s[1], x->p_scan_in, x->p_scan_out,
+                    x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->p_scan_in, x->p_scan_out,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
                     x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_start_s[0], x->seg_start_s[1],
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,

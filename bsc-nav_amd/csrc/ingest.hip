@@ -56,8 +56,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                                                 int n_frames, const double *__restrict__ transforms,
                                                 const double *__restrict__ alpha_in, int64_t P, int32_t *occ,
                                                 int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
-                                                uint32_t *__restrict__ p_rgbv, float *__restrict__ p_r2f,
-                                                double *__restrict__ p_alpha)
+                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= P) return;
@@ -88,9 +87,12 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
     p_cell[j] = cell;
     p_patf[j] = ((uint32_t)f << 16) | (uint32_t)(o.pat[1] * gc.g + o.pat[0]);   // tokens[py, px]
-    p_rgbv[j] = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
     p_r2f[j] = (float)o.r2;                       // memory_2.py:885 grid_feat_dis is float32
-    p_alpha[j] = alpha_in ? alpha_in[j] : o.alpha;
+    PointRec rec;
+    rec.alpha = alpha_in ? alpha_in[j] : o.alpha;
+    rec.rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
+    rec.pad = 0;
+    p_rec[j] = rec;
     // first-touch claim: the smallest j wins an empty cell (ids are handed out in k_assign)
     if (occ[cell] < 0) atomicMin(&occ[cell], INT_MIN + (int32_t)j);
 }
@@ -203,7 +205,7 @@ __global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const 
 __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const uint32_t *__restrict__ skey,
                                                const uint32_t *__restrict__ sval, const int64_t *bscal,
                                                const int32_t *__restrict__ seg_start,
-                                               const uint32_t *__restrict__ p_rgbv, const double *__restrict__ p_alpha,
+                                               const PointRec *__restrict__ p_rec,
                                                const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
                                                float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                                int gs, int64_t order_base)
@@ -230,8 +232,11 @@ __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const uint32_t *__rest
             const int64_t k = base + lane;
             const bool inseg = (k < P) && (skey[k] == vid);
             const uint32_t j = inseg ? sval[k] : 0u;
-            const uint32_t rv = inseg ? p_rgbv[j] : 0u;
-            const double al = inseg ? p_alpha[j] : 0.0;
+            PointRec rec;
+            rec.alpha = 0.0; rec.rgbv = 0u;
+            if (inseg) rec = p_rec[j];
+            const uint32_t rv = rec.rgbv;
+            const double al = rec.alpha;
             const int n = __popcll(__ballot(inseg));
             for (int t = 0; t < n; ++t) {
                 const double a = __shfl(al, t);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(TPB) void k_chain(int64_t P, const uint32_t *__rest
 __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const uint32_t *__restrict__ skey,
                                               const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_last,
                                               const int32_t *__restrict__ rgb_pos, const u64 *__restrict__ hmap,
-                                              const uint32_t *__restrict__ p_rgbv, uint8_t *__restrict__ cv_map, int gs,
+                                              const PointRec *__restrict__ p_rec, uint8_t *__restrict__ cv_map, int gs,
                                               int64_t order_base)
 {
     const int64_t nseg = bscal[0];
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const uint32
         const int64_t rc = (int64_t)row * gs + col;
         const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + last_j);
         if (hmap[rc] == packed) {
-            const uint32_t v = p_rgbv[last_j];
+            const uint32_t v = p_rec[last_j].rgbv;
             cv_map[3 * rc + 0] = (uint8_t)(v & 0xff);
             cv_map[3 * rc + 1] = (uint8_t)((v >> 8) & 0xff);
             cv_map[3 * rc + 2] = (uint8_t)((v >> 16) & 0xff);
@@ -357,14 +362,13 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     const int set = x->cur_set;
     x->cur_set ^= 1;
     if (x->ev_done_valid[set]) BSC_HIP(hipStreamWaitEvent(s, x->ev_done[set], 0));
-    uint32_t *p_rgbv = x->p_rgbv_s[set];
-    double *p_alpha = x->p_alpha_s[set];
+    PointRec *p_rec = x->p_rec_s[set];
     uint32_t *skey_b = x->skey_b_s[set], *sval_b = x->sval_b_s[set];
     if (idx)
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
     GeomConst gc = make_geom_const(x);
     hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
-                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rgbv, x->p_r2f, p_alpha);
+                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rec, x->p_r2f);
     const int64_t nblk = (P + FB - 1) / FB;
     const dim3 fgrid((unsigned)nblk);
     hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
@@ -393,10 +397,10 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     BSC_HIP(hipEventRecord(x->ev_ready[set], s));
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
     const dim3 wgrid(256 * 8);
-    hipLaunchKernelGGL(k_chain, wgrid, block, 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rgbv, p_alpha,
+    hipLaunchKernelGGL(k_chain, wgrid, block, 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rec,
                        x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size, x->order_base);
     hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], skey_b, x->seg_start_s[set],
-                       x->seg_last_s[set], x->rgb_pos, x->hmap, p_rgbv, x->cv_map, x->c.grid_size, x->order_base);
+                       x->seg_last_s[set], x->rgb_pos, x->hmap, p_rec, x->cv_map, x->c.grid_size, x->order_base);
     BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
     x->ev_done_valid[set] = true;
     if (x->c.mode != BSC_MODE_EXACT) BSC_TRY(dense_reduce_batch(x, tokens, n_frames));
