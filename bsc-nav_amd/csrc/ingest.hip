@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
     p_cell[j] = cell;
     p_patf[j] = ((uint32_t)f << 16) | (uint32_t)(o.pat[1] * gc.g + o.pat[0]);   // tokens[py, px]
-    p_r2f[j] = (float)o.r2;                       // memory_2.py:885 grid_feat_dis is float32
+    if (p_r2f) p_r2f[j] = (float)o.r2;            // memory_2.py:885 grid_feat_dis is float32 (token cache only)
     PointRec rec;
     rec.alpha = alpha_in ? alpha_in[j] : o.alpha;
     rec.rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
@@ -368,7 +368,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
     GeomConst gc = make_geom_const(x);
     hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
-                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rec, x->p_r2f);
+                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rec, x->c.mode == BSC_MODE_EXACT ? x->p_r2f : (float *)nullptr);
     const int64_t nblk = (P + FB - 1) / FB;
     const dim3 fgrid((unsigned)nblk);
     hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
