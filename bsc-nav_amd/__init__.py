@@ -7,6 +7,7 @@ from . import _lib
 from .engine import VoxelEngine
 from .geometry import PoseChain, cam_mat_fov, cam_mat_patch, pose_vec2tf, sample_indices
 from .config import MemoryArgs
-from .memory import VoxelTokenMemory
+from .memory import Memory, VoxelTokenMemory
+from .dataset import create_memory_for_dataset
 
-__all__ = ["VoxelEngine", "VoxelTokenMemory", "MemoryArgs", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "_lib"]
+__all__ = ["VoxelEngine", "VoxelTokenMemory", "Memory", "create_memory_for_dataset", "MemoryArgs", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "_lib"]

@@ -457,3 +457,20 @@ class VoxelTokenMemory:
     def create_memory(self):
         raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop; use "
                                   "exploring_create_memory() or feed frames through obs2voxeltoken()")
+
+
+    # ---- BASELINE.json vocabulary (north_star names the entry points Memory.update_* / Memory.localize) -------------
+    def update_from_observation(self, obs, pose):
+        """Alias of obs2voxeltoken (memory_2.py:842)."""
+        return self.obs2voxeltoken(obs, pose)
+
+    def update_from_frames(self, rgb, depth, poses, tokens=None):
+        """Alias of ingest_frames (batched form of obs2voxeltoken)."""
+        return self.ingest_frames(rgb, depth, poses, tokens)
+
+    def localize(self, prompt, K=100, **kw):
+        """Alias of voxel_localized (memory_2.py:563)."""
+        return self.voxel_localized(prompt, K=K, **kw)
+
+
+Memory = VoxelTokenMemory
