@@ -142,3 +142,56 @@ def test_full_size_invariants_640x480_d768():
     assert any(np.array_equal(pos[0, i], p1[v]) for i in np.nonzero(ties)[0])
     for e in (one, four, twice):
         e.close()
+
+
+def test_exact_mode_at_scale_against_oracle():
+    """~1e6 points, 40 frames, a token cache that wraps ~50 times with random replacement: the whole exact-mode state
+    (ids, rgb chain with host alpha, top-down map, token store incl. replacement draws, top-K) equals the sequential oracle."""
+    import random
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    H, W, g, D, gs, F, s, iter_size = 240, 320, 14, 24, 128, 40, 3, 20000
+    rgb, depth, poses = synth.make_frames(21, F, H, W, "room")
+    tokens = synth.make_tokens(21, F, g, D)
+    eng = B.VoxelEngine(H, W, gs, 0.1, -2.0, 4.4, g, D, mode="exact", iter_size=iter_size, voxel_capacity=300_000,
+                        token_capacity=1_500_000, max_points=8 * H * W)
+    oc = orc.make_config(H, W, gs, 0.1, -2.0, 4.4, g, D, iter_size=iter_size)
+    om = orc.OracleMemory(oc, voxel_capacity=300_000)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    np.random.seed(5)
+    idxs = [B.sample_indices(H * W, s) for _ in range(F)]
+    alphas = []
+    for f in range(F):                                   # one alpha array for both sides (libm exp of the oracle's r^2)
+        gm = orc.geometry(oc, depth[f], idxs[f], Ts[f])
+        alphas.append(np.exp(-gm["r2"] / (2 * 0.6)))
+    random.seed(77)
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], idxs[f], Ts[f], tokens[f], alphas[f])
+    om.flush()
+    random.seed(77)                                      # same Python RNG stream for the replacement draws
+    d_depth, d_rgb, d_tok = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    for a in range(0, F, 8):                             # 8 frames per call: several in-call flushes each
+        off = np.concatenate([[0], np.cumsum([len(i) for i in idxs[a:a + 8]])]).astype(np.int64)
+        eng.ingest(d_depth[a:a + 8], d_rgb[a:a + 8], d_tok[a:a + 8], Ts[a:a + 8],
+                   torch.from_numpy(np.concatenate(idxs[a:a + 8])).cuda(), off,
+                   torch.from_numpy(np.concatenate(alphas[a:a + 8])).cuda())
+    eng.flush()
+    k, ok = eng.counters(), om.counters()
+    assert k["flushes"] == ok["flushes"] and k["flushes"] > 40
+    assert (k["max_id"], k["store_voxels"], k["store_tokens"]) == (ok["max_id"], ok["store_voxels"], ok["store_tokens"])
+    for a, b in zip(eng.export_rgb(), om.export_rgb()):
+        assert np.array_equal(a, b)
+    for a, b in zip(eng.export_heightmap(), om.export_heightmap()):
+        assert np.array_equal(a, b)
+    for a, b in zip(eng.export_store(), om.export_store()):
+        assert np.array_equal(a, b)
+    assert (eng.export_store()[1] == 10).sum() > 1000     # thousands of saturated voxels: replacement really happened
+    q = orc.pool_query(synth.make_query_tokens(2, 1, 196, D))
+    p, sim, n = eng.localize(torch.from_numpy(q[None]).cuda(), K=100)
+    op, osim = om.localize(q, K=100)
+    import golden_util as gu
+    gu.assert_topk_matches(p[0, :n[0]], sim[0, :n[0]], op, osim, tol=5e-6)
+    eng.close()
