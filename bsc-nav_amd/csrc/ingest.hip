@@ -191,77 +191,206 @@ __global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const 
     dscal[DS_B_NSEG] = 0;
     bscal[0] = 0;
     bscal[1] = dscal[DS_MAX_ID_PREV];
+    bscal[3] = 0;                       // segment queue of the rgb chain
     dscal[DS_B_NPAIR] = 0;
     dscal[DS_B_NPSEG] = 0;
 }
 
-// memory_2.py:888-903 — one WAVEFRONT per voxel walks that voxel's points of the batch in order.
-// The chain c' = trunc((f32(c*w) + r*a) / (w + a)), w' = f32(w + a) is sequential by definition (truncation
-// and f32 rounding at every step), so parallelism is across voxels; within the wave the 64 lanes prefetch 64
-// points at a time (coalesced keys, gathered rgb / alpha) and the steps run out of registers through
-// wave shuffles, lanes 0..2 carrying the R, G, B channels.  The same wave settles the top-down map:
-// `h >= max_height` in sequential order == max over (h, order), and a voxel's latest point is the last
-// element of its segment, so one atomicMax per voxel replaces one per point.
-__global__ __launch_bounds__(TPB) void k_chain(int64_t P, const uint32_t *__restrict__ skey,
-                                               const uint32_t *__restrict__ sval, const int64_t *bscal,
-                                               const int32_t *__restrict__ seg_start,
-                                               const PointRec *__restrict__ p_rec,
-                                               const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
-                                               float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
-                                               int gs, int64_t order_base)
+// memory_2.py:888-903 — the rgb chain c' = trunc((f32(c*w) + r*a) / (w + a)), w' = f32(w + a) is sequential by
+// definition (truncation and f32 rounding at every step), so the only parallelism is across voxels and channels, and
+// the call's duration is bounded below by its longest voxel run (tens of thousands of points for a wall seen in every
+// frame) times the latency of one step.  What can be minimised is the issue bandwidth the chain takes from the kernels
+// it runs beside (it lives on the side stream):
+//   * a QUAD of lanes per voxel (R, G, B + one spare), 16 voxels per wavefront, so one instruction advances 16 chains;
+//   * quads pull voxel segments from a queue (one atomic per wave and refill), so no quad idles while work remains;
+//   * every quad streams its segment in chunks of 64 points, 16 per lane: the order indices of chunk n+2 and the point
+//     records of chunk n+1 are in flight while chunk n is stepped out of registers through quad-broadcast DPP moves;
+//   * the divide is the hardware's own f64 sequence (v_rcp_f64, two Newton steps, multiply, residual fma, final fma —
+//     what `/` compiles to, without the scale/fixup ops that only act outside the normal range) written out so that
+//     the reciprocal half, which depends on the weights only, stays off the colour's dependency chain.
+// The same quad settles the top-down map: `h >= max_height` in sequential order == max over (h, order), and a voxel's
+// latest point is the last element of its segment, so one atomicMax per voxel replaces one per point.
+#define CQ 16                                   // records per lane per chunk (64 per quad)
+template <int Q> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-    const int ch = lane < 3 ? lane : 2;
-    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, Q * 0x55, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false);
+}
+
+struct ChainRegs {
+    uint32_t rv[CQ];        // rgb bytes | bit 30 = slot holds a point of the segment | bit 31 = its step is still to run
+    uint32_t alo[CQ], ahi[CQ];
+};
+
+// order indices of the chunk starting at sorted position `pos` (0xffffffff = not in this segment).  All loads are
+// unconditional (clamped addresses) so that the 32 of them issue back to back instead of one dependent branch each.
+__device__ __forceinline__ void chain_load_idx(uint32_t (&J)[CQ], bool on, int64_t pos, int q, int64_t P, uint32_t vid,
+                                               const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval)
+{
+    uint32_t key[CQ], val[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        const int64_t k = pos + 4 * i + q;
+        const int64_t kk = k < P ? k : P - 1;
+        key[i] = skey[kk];
+        val[i] = sval[kk];
+    }
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        const int64_t k = pos + 4 * i + q;
+        J[i] = (on && k < P && key[i] == vid) ? val[i] : 0xffffffffu;
+    }
+}
+
+__device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)[CQ], const PointRec *__restrict__ p_rec,
+                                               uint32_t &last_j)
+{
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        const bool valid = J[i] != 0xffffffffu;
+        const uint4 raw = *(const uint4 *)(p_rec + (valid ? J[i] : 0u));       // { alpha lo, alpha hi, rgbv, pad }
+        R.alo[i] = raw.x; R.ahi[i] = raw.y;
+        R.rv[i] = valid ? (raw.z | 0xc0000000u) : 0u;
+        last_j = valid ? J[i] : last_j;                                        // order indices grow along a segment
+    }
+}
+
+#define CHAIN_STEP(i, qq)                                                                          \
+    {                                                                                              \
+        const uint32_t rvb = quad_bcast<qq>(R.rv[i]);                                              \
+        const double a = __hiloint2double((int)quad_bcast<qq>(R.ahi[i]), (int)quad_bcast<qq>(R.alo[i])); \
+        const bool act = (int32_t)rvb < 0;                                                         \
+        const uint32_t r = (rvb >> sh) & 0xffu;                                                    \
+        const double den = (double)w + a;                       /* :896 weight + alpha (f32 + f64) */ \
+        double rd = __builtin_amdgcn_rcp(den);                                                     \
+        double e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);                                        \
+        e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);                                               \
+        const double num = (double)((float)c * w) + (double)r * a;   /* u8*f32 -> f32 ; u8*f64 -> f64 */ \
+        const double q0 = num * rd;                                                                \
+        const double rr = fma(-den, q0, num);                                                      \
+        const double v = fma(rr, rd, q0);                       /* == num / den, correctly rounded */ \
+        c = act ? (uint32_t)v : c;                              /* truncating uint8 store */       \
+        w = act ? (float)den : w;                               /* :899 */                         \
+    }
+
+__global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restrict__ skey,
+                                              const uint32_t *__restrict__ sval, int64_t *bscal,
+                                              const int32_t *__restrict__ seg_start,
+                                              const PointRec *__restrict__ p_rec,
+                                              const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
+                                              float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
+                                              int gs, int64_t order_base)
+{
+    // a handful of long-lived wavefronts beside throughput kernels: take the SIMD's issue slots whenever ready
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    const int q = lane & 3;
+    const int ch = q < 3 ? q : 2;
+    const int sh = 8 * ch;
+    const u64 quads_below = (1ull << (lane & ~3)) - 1ull;
     const int64_t nseg = bscal[0];
     const int64_t max_id_prev = bscal[1];
-    for (int64_t s = wave; s < nseg; s += nwaves) {
-        const int64_t i0 = seg_start[s];
-        const uint32_t vid = skey[i0];
-        const bool is_new = (int64_t)vid >= max_id_prev;
-        float w = 0.f;
-        uint32_t c = 0;
-        if (!is_new) {
-            w = weight[vid];
-            c = rgb[3 * (int64_t)vid + ch];
-        }
-        bool first = is_new;
-        uint32_t last_j = 0;
-        for (int64_t base = i0;; base += 64) {
-            const int64_t k = base + lane;
-            const bool inseg = (k < P) && (skey[k] == vid);
-            const uint32_t j = inseg ? sval[k] : 0u;
-            PointRec rec;
-            rec.alpha = 0.0; rec.rgbv = 0u;
-            if (inseg) rec = p_rec[j];
-            const uint32_t rv = rec.rgbv;
-            const double al = rec.alpha;
-            const int n = __popcll(__ballot(inseg));
-            for (int t = 0; t < n; ++t) {
-                const double a = __shfl(al, t);
-                const uint32_t r = (__shfl(rv, t) >> (8 * ch)) & 0xffu;
-                if (first) {                    // :890-894 new id: rgb = rgb_v, weight = f32(0 + alpha)
-                    c = r;
-                    w = (float)((double)w + a);
-                    first = false;
-                } else {                        // :896-899 u8*f32 -> f32 ; u8*f64 -> f64 ; truncating store
-                    const double den = (double)w + a;
-                    const double v = ((double)((float)c * w) + (double)r * a) / den;
-                    c = (uint32_t)(uint8_t)v;
-                    w = (float)den;
+    unsigned long long *queue = (unsigned long long *)(bscal + 3);
+
+    bool have = false, exhausted = false;
+    int64_t s = 0, pos = 0;
+    uint32_t vid = 0, c = 0, last_j = 0;
+    float w = 0.f;
+    ChainRegs R, Rn;
+    uint32_t Jn[CQ], Jnn[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) { R.rv[i] = Rn.rv[i] = 0u; R.alo[i] = Rn.alo[i] = 0u; R.ahi[i] = Rn.ahi[i] = 0u; Jn[i] = Jnn[i] = 0xffffffffu; }
+
+    for (;;) {
+        // ---- refill idle quads from the segment queue -----------------------------------------------------------
+        const bool need = !have && !exhausted;
+        const u64 mneed = __ballot(need && q == 0);
+        if (mneed) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queue, (unsigned long long)__popcll(mneed));
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            bool fresh = false, is_new = false;
+            if (need) {
+                s = (int64_t)base + __popcll(mneed & quads_below);
+                if (s < nseg) { fresh = true; have = true; } else exhausted = true;
+            }
+            if (fresh) {
+                pos = seg_start[s];
+                vid = skey[pos];
+                is_new = (int64_t)vid >= max_id_prev;
+                w = 0.f; c = 0u; last_j = 0u;
+                if (!is_new) {
+                    w = weight[vid];
+                    c = rgb[3 * (int64_t)vid + ch];
                 }
             }
-            if (n > 0) last_j = __shfl(j, n - 1);
-            if (n < 64) break;
+            uint32_t J0[CQ];
+            chain_load_idx(J0, fresh, pos, q, P, vid, skey, sval);
+            ChainRegs R0;
+            uint32_t lj = last_j;
+            chain_load_rec(R0, J0, p_rec, lj);
+            uint32_t J1[CQ];
+            chain_load_idx(J1, fresh, pos + 64, q, P, vid, skey, sval);
+            // :890-894 a new id takes the colour of its first point and weight f32(0 + alpha); that point is then done
+            const uint32_t rv0 = quad_bcast<0>(R0.rv[0]);
+            const double a0 = __hiloint2double((int)quad_bcast<0>(R0.ahi[0]), (int)quad_bcast<0>(R0.alo[0]));
+            if (fresh) {
+                last_j = lj;
+                if (is_new) {
+                    c = (rv0 >> sh) & 0xffu;
+                    w = (float)((double)0.f + a0);
+                    if (q == 0) R0.rv[0] &= 0x7fffffffu;
+                }
+#pragma unroll
+                for (int i = 0; i < CQ; ++i) { R.rv[i] = R0.rv[i]; R.alo[i] = R0.alo[i]; R.ahi[i] = R0.ahi[i]; Jn[i] = J1[i]; }
+            }
         }
-        if (lane < 3) rgb[3 * (int64_t)vid + lane] = (uint8_t)c;
-        if (lane == 0) {
-            weight[vid] = w;
-            const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
-            const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + last_j);
-            atomicMax(&hmap[(int64_t)row * gs + col], packed);
-            seg_last[s] = (int32_t)last_j;
+        if (!__any(have)) break;
+
+        // ---- prefetch: records of the next chunk, order indices of the one after ----------------------------------
+        chain_load_rec(Rn, Jn, p_rec, last_j);
+        chain_load_idx(Jnn, have, pos + 128, q, P, vid, skey, sval);
+
+        // ---- 64 steps out of registers; a block of 16 is skipped once no quad of the wave has points left in it ----
+        bool go = true;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            go = go && __any((quad_bcast<0>(R.rv[4 * b]) & 0x40000000u) != 0u);
+            if (go) {
+#pragma unroll
+                for (int i = 4 * b; i < 4 * b + 4; ++i) {
+                    CHAIN_STEP(i, 0)
+                    CHAIN_STEP(i, 1)
+                    CHAIN_STEP(i, 2)
+                    CHAIN_STEP(i, 3)
+                }
+            }
+        }
+        // a chunk whose last slot is empty was the segment's last
+        const bool done = have && (quad_bcast<3>(R.rv[CQ - 1]) & 0x40000000u) == 0u;
+        if (done) {
+            uint32_t lj = last_j;
+            lj = max(lj, quad_perm<0xB1>(lj));          // lanes 1,0,3,2
+            lj = max(lj, quad_perm<0x4E>(lj));          // lanes 2,3,0,1
+            if (q < 3) rgb[3 * (int64_t)vid + q] = (uint8_t)c;
+            if (q == 0) {
+                weight[vid] = w;
+                const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
+                const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + lj);
+                atomicMax(&hmap[(int64_t)row * gs + col], packed);
+                seg_last[s] = (int32_t)lj;
+            }
+            have = false;
+        }
+        pos += 64;
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) {
+            R.rv[i] = have ? Rn.rv[i] : 0u; R.alo[i] = Rn.alo[i]; R.ahi[i] = Rn.ahi[i];
+            Jn[i] = have ? Jnn[i] : 0xffffffffu;
         }
     }
 }
@@ -396,8 +525,8 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // HBM-bound dense reduce of this call and whatever the caller enqueues next (the next batch's encoder)
     BSC_HIP(hipEventRecord(x->ev_ready[set], s));
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
-    const dim3 wgrid(256 * 8);
-    hipLaunchKernelGGL(k_chain, wgrid, block, 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rec,
+    // 16 voxels per wavefront, two wavefronts per SIMD at most: the queue keeps them busy
+    hipLaunchKernelGGL(k_chain, dim3(2048), dim3(64), 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rec,
                        x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size, x->order_base);
     hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], skey_b, x->seg_start_s[set],
                        x->seg_last_s[set], x->rgb_pos, x->hmap, p_rec, x->cv_map, x->c.grid_size, x->order_base);
