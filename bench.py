@@ -29,9 +29,10 @@ if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" n
     import shutil
     import tempfile
     _src = os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
-    _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.environ.get('LOCAL_RANK', '0')}_{os.getpid()}.csv")
+    _ord = os.environ.get("LOCAL_RANK", "0")
+    _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.getpid()}_.csv")
     if os.path.exists(_src):
-        shutil.copy(_src, _dst)
+        shutil.copy(_src, _dst[:-4] + _ord + ".csv")      # TunableOp reads/writes <name><device ordinal>.csv
     os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=_dst,
                       PYTORCH_TUNABLEOP_VERBOSE="0")
 

@@ -33,7 +33,8 @@ enum {
     DS_TMP1 = 13,
     DS_B_NPSEG = 14,    // batch: voxel segments of the sorted pair list
     DS_PAIR_TOTAL = 15, // dense: pairs reduced since creation
-    DS_COUNT = 16
+    DS_B_NRUN = 16,     // batch: runs of consecutive points that fall into the same cell
+    DS_COUNT = 17
 };
 
 struct bsc_ctx {
@@ -71,13 +72,21 @@ struct bsc_ctx {
     PointRec *p_rec_s[2];    // double-buffered: read by the rgb chain on the side stream
     float *p_r2f;
     int64_t *p_scan_in, *p_scan_out;
-    uint32_t *skey_a, *sval_a;          // point sort: key = voxel id, value = j (stable radix sort keeps j order)
-    uint32_t *skey_b_s[2], *sval_b_s[2];
+    // Points are ordered per voxel through their RUNS (maximal stretches of consecutive points in one cell; a 10 cm
+    // voxel a few metres away covers ~16 pixels of an image row): the runs are sorted by voxel id (stable radix sort
+    // keeps the order j inside a voxel) and expanded back into the per-voxel point order the rgb chain walks.
+    int32_t *run_j0;                    // first point of run r (runs in order j)
+    uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id, value = r (also scratch of the Morton sort)
+    uint32_t *skey_b_s[2];              // sorted run keys
+    uint32_t *run_val_b;                // sorted run indices
+    int32_t *run_len, *run_off;         // sorted runs: length, exclusive prefix = position in the per-voxel point order
+    int32_t *run_heads;                 // sorted-run index of every voxel's first run (ascending)
+    uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel (read by the rgb chain)
+    int4 *seg_info_s[2];                // per voxel segment: {first k, end k, voxel id, -}
     int32_t *blk_cnt, *blk_off;         // per-block head counts / offsets (deterministic compaction)
     int64_t nblk_cap;
     u64 *f_keys_a, *f_keys_b;  // flush-private sort buffers (iter_size)
     int32_t *pass_list;
-    int32_t *seg_start_s[2];
     int32_t *seg_last_s[2];
     int64_t *bscal_s[2];       // per-set scalars: [0] voxel segments of the batch, [1] max_id before the batch
     int cur_set;

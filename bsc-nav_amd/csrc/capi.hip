@@ -154,12 +154,13 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->p_scan_in, np / 1024 + 16); ALLOC(x->p_scan_out, np / 1024 + 16);   // per-block (first << 32 | pass) totals
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
+    ALLOC(x->run_j0, np + 1); ALLOC(x->run_val_b, np); ALLOC(x->run_len, np); ALLOC(x->run_off, np); ALLOC(x->run_heads, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
         ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
-        ALLOC(x->seg_start_s[k], np); ALLOC(x->seg_last_s[k], np); ALLOC(x->bscal_s[k], 4);
+        ALLOC(x->seg_info_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->seg_last_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->bscal_s[k], 4);
         BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
         BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
     }
@@ -210,7 +211,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
                     x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->p_scan_in, x->p_scan_out,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
-                    x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_start_s[0], x->seg_start_s[1],
+                    x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_info_s[0], x->seg_info_s[1], x->run_j0, x->run_val_b, x->run_len, x->run_off, x->run_heads,
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,

@@ -4,8 +4,7 @@
 // unique (voxel, frame, patch) PAIR with its multiplicity:
 //
 //   k_keys_pairs   one workgroup per tile of 1024 points (32x32 pixel tiles when every pixel is ingested,
-//                  1024 consecutive points otherwise).  Writes the (voxel id << 32 | j) sort key of the rgb
-//                  chain and aggregates the tile's (voxel, frame, patch) codes in an LDS hash table
+//                  1024 consecutive points otherwise).  Aggregates the tile's (voxel, frame, patch) codes in an LDS hash table
 //                  (ds_cmpst_b64 insert + ds_add count); the distinct pairs are appended to a global list.
 //                  A 10 cm voxel 2 m away covers ~16x16 pixels, so a tile collapses 1024 points to a
 //                  handful of pairs.
@@ -35,8 +34,7 @@ __device__ __forceinline__ u64 mix64(u64 x)
 template <bool PAIRS>
 __global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int H, int W, int tx_n, int ty_n,
                                                     const int32_t *__restrict__ p_cell, const int32_t *__restrict__ occ,
-                                                    const uint32_t *__restrict__ p_patf, uint32_t *__restrict__ skey,
-                                                    uint32_t *__restrict__ sval, u64 *__restrict__ pstage_key,
+                                                    const uint32_t *__restrict__ p_patf, u64 *__restrict__ pstage_key,
                                                     uint32_t *__restrict__ pstage_cnt, int32_t *__restrict__ tile_cnt,
                                                     int pb, int cb)
 {
@@ -112,8 +110,6 @@ __global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int 
                 }
             }
         }
-        skey[j] = key;
-        sval[j] = (uint32_t)j;
     }
     if (PAIRS) {
         // the tile's distinct pairs go to its private staging slice (no global same-address atomics);
@@ -150,7 +146,7 @@ __global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int
     if (tile == n_tiles - 1 && threadIdx.x == 0) dscal[DS_B_NPAIR] = off + n;
 }
 
-// ---- deterministic compaction of segment heads: per-block counts, exclusive scan, per-block write --------------
+// ---- deterministic, ORDERED compaction of segment heads: per-block counts, exclusive scan, ranked write ------
 #define HB 1024   // elements per block
 template <typename K>
 __device__ __forceinline__ bool is_head(const K *__restrict__ keys, int64_t i, int64_t n, int shift, K invalid)
@@ -182,16 +178,29 @@ __global__ __launch_bounds__(TPB) void k_head_write(const K *__restrict__ keys, 
                                                     const int32_t *__restrict__ blk_off, int32_t *__restrict__ out,
                                                     int64_t *count_dev)
 {
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
+    // ranks inside the block follow the element order (round, then wave, then lane), so `out` is ascending
+    __shared__ int wcnt[HB / TPB][TPB / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int32_t base = blk_off[blockIdx.x];
+    u64 bal[HB / TPB];
+#pragma unroll
     for (int t = 0; t < HB / TPB; ++t) {
-        const int64_t i = (int64_t)blockIdx.x * HB + t * TPB + threadIdx.x;
-        if (is_head(keys, i, n, shift, invalid)) out[base + atomicAdd(&cnt, 1)] = (int32_t)i;
+        bal[t] = __ballot(is_head(keys, (int64_t)blockIdx.x * HB + t * TPB + threadIdx.x, n, shift, invalid));
+        if (lane == 0) wcnt[t][wid] = __popcll(bal[t]);
     }
     __syncthreads();
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_dev = (int64_t)base + cnt;
+    int run = 0;
+#pragma unroll
+    for (int t = 0; t < HB / TPB; ++t) {
+        int before = run;
+        for (int w = 0; w < TPB / 64; ++w) {
+            if (w < wid) before += wcnt[t][w];
+            run += wcnt[t][w];
+        }
+        if (bal[t] & (1ull << lane))
+            out[base + before + __popcll(bal[t] & ((1ull << lane) - 1ull))] = (int32_t)((int64_t)blockIdx.x * HB + t * TPB + threadIdx.x);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_dev = (int64_t)base + run;
 }
 
 template <typename K>
@@ -442,10 +451,11 @@ static void launch_dense(bsc_ctx *x, int64_t n_pairs, const float *tokens, int p
 #undef LD
 }
 
-// point sort keys (voxel id, j) for every point; in the dense modes also the per-tile (voxel, frame, patch) pairs
+// dense modes: the per-tile (voxel, frame, patch) pairs of the batch
 bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels)
 {
     const bool pairs = x->c.mode != BSC_MODE_EXACT;
+    if (!pairs) return BSC_OK;
     const int H = x->c.height, W = x->c.width;
     const int tx_n = (W + 31) / 32, ty_n = (H + 31) / 32;
     const int64_t tiles = all_pixels ? (int64_t)n_frames * tx_n * ty_n : (P + PT_TILE - 1) / PT_TILE;
@@ -454,15 +464,11 @@ bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixel
     const dim3 grid((unsigned)tiles), block(TPB);
     if (pairs) {
         hipLaunchKernelGGL((k_keys_pairs<true>), grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n,
-                           x->p_cell, x->occ, x->p_patf, x->skey_a, x->sval_a, x->pstage_key, x->pstage_cnt, x->tile_cnt,
+                           x->p_cell, x->occ, x->p_patf, x->pstage_key, x->pstage_cnt, x->tile_cnt,
                            pb, cb);
         BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
         hipLaunchKernelGGL(k_pair_compact, grid, block, 0, x->stream, tiles, x->tile_cnt, x->tile_off, x->pstage_key,
                            x->pstage_cnt, x->pair_key_a, x->pair_cnt_a, x->pair_cap, x->dscal);
-    } else {
-        hipLaunchKernelGGL((k_keys_pairs<false>), grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n,
-                           x->p_cell, x->occ, x->p_patf, x->skey_a, x->sval_a, (u64 *)nullptr, (uint32_t *)nullptr,
-                           (int32_t *)nullptr, pb, cb);
     }
     BSC_HIP(hipGetLastError());
     return BSC_OK;

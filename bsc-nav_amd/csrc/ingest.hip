@@ -6,12 +6,13 @@
 //
 //   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
 //               first toucher of every still-empty cell                         (1 thread / point)
-//   k_flags + scan of block totals + k_assign  first-touch points get ids max_id + rank in order
-//   k_keys_pairs (dense.hip) sort key = voxel id, value = j; LDS aggregation of (voxel, frame, patch) pairs
-//   radix sort  (stable, on the voxel id bits only) groups the points of a voxel in order; the segment
-//               starts are compacted deterministically (block counts + scan)
+//   k_flags + scan of block totals + k_assign  first-touch points get ids max_id + rank in order; the same pass
+//               lists the RUNS of the batch (maximal stretches of consecutive points in one cell)
+//   k_keys_pairs (dense.hip) LDS aggregation of (voxel, frame, patch) pairs
+//   radix sort  of the runs (stable, on the voxel id bits only) + k_expand: every voxel's points in order j,
+//               at a fraction of the traffic of sorting the points themselves (a voxel covers ~16 pixels of a row)
 //   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
-//               (h, order of the voxel's latest point)                        (1 wavefront / voxel)
+//               (h, order of the voxel's latest point)                        (1 quad of lanes / voxel)
 //   k_hwin      the winning voxel of each map cell writes its colour
 //   dense.hip   pair sort + k_dense_reduce: multiplicity x token rows -> one RMW of the D-float
 //               accumulator row per voxel                                     (1 wavefront / voxel)
@@ -108,51 +109,60 @@ __device__ __forceinline__ int point_flags(int64_t j, int64_t P, const int32_t *
     cell = -1;
     if (j >= P) return 0;
     cell = p_cell[j];
-    if (cell < 0) return 0;
-    return (occ[cell] == INT_MIN + (int32_t)j) ? 3 : 1;     // bit0 passes, bit1 first toucher of its voxel
+    const int head = (j == 0 || p_cell[j - 1] != cell) ? 4 : 0;     // bit2 first point of a run (any cell, -1 included)
+    if (cell < 0) return head;
+    return head | ((occ[cell] == INT_MIN + (int32_t)j) ? 3 : 1);    // bit0 passes, bit1 first toucher of its voxel
 }
 
 __global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
-                                               const int32_t *__restrict__ occ, int64_t *__restrict__ blk_tot)
+                                               const int32_t *__restrict__ occ, int64_t *__restrict__ blk_tot,
+                                               int32_t *__restrict__ blk_runs)
 {
-    __shared__ int s_pass, s_first;
-    if (threadIdx.x == 0) { s_pass = 0; s_first = 0; }
+    __shared__ int s_pass, s_first, s_head;
+    if (threadIdx.x == 0) { s_pass = 0; s_first = 0; s_head = 0; }
     __syncthreads();
-    int np = 0, nf = 0;
+    int np = 0, nf = 0, nh = 0;
     for (int r = 0; r < FB / TPB; ++r) {
         int32_t c;
         const int f = point_flags((int64_t)blockIdx.x * FB + r * TPB + threadIdx.x, P, p_cell, occ, c);
         np += f & 1;
-        nf += f >> 1;
+        nf += (f >> 1) & 1;
+        nh += f >> 2;
     }
-    for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o); nf += __shfl_xor(nf, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_pass, np); atomicAdd(&s_first, nf); }
+    for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o); nf += __shfl_xor(nf, o); nh += __shfl_xor(nh, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_pass, np); atomicAdd(&s_first, nf); atomicAdd(&s_head, nh); }
     __syncthreads();
-    if (threadIdx.x == 0) blk_tot[blockIdx.x] = ((int64_t)s_first << 32) | (int64_t)s_pass;
+    if (threadIdx.x == 0) {
+        blk_tot[blockIdx.x] = ((int64_t)s_first << 32) | (int64_t)s_pass;
+        blk_runs[blockIdx.x] = s_head;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__restrict__ p_cell, int32_t *occ,
                                                 const int64_t *__restrict__ blk_off, int64_t *dscal, int vcap, int gs,
-                                                int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list)
+                                                int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list,
+                                                const int32_t *__restrict__ blk_run_off, int32_t *__restrict__ run_j0)
 {
-    __shared__ int w_pass[TPB / 64], w_first[TPB / 64];
+    __shared__ int w_pass[TPB / 64], w_first[TPB / 64], w_head[TPB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t base = blk_off[blockIdx.x];
     int64_t pass_base = base & 0xffffffffll, first_base = base >> 32;
+    int32_t head_base = blk_run_off[blockIdx.x];
     const int64_t max_id = dscal[DS_MAX_ID];
     for (int r = 0; r < FB / TPB; ++r) {            // rounds keep the order j: round, then wave, then lane
         const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
         int32_t c;
         const int f = point_flags(j, P, p_cell, occ, c);
-        const u64 mp = __ballot(f & 1), mf = __ballot(f & 2);
-        if (lane == 0) { w_pass[wid] = __popcll(mp); w_first[wid] = __popcll(mf); }
+        const u64 mp = __ballot(f & 1), mf = __ballot(f & 2), mh = __ballot(f & 4);
+        if (lane == 0) { w_pass[wid] = __popcll(mp); w_first[wid] = __popcll(mf); w_head[wid] = __popcll(mh); }
         __syncthreads();
-        int bp = 0, bf = 0, tp = 0, tf = 0;
+        int bp = 0, bf = 0, bh = 0, tp = 0, tf = 0, th = 0;
         for (int w = 0; w < TPB / 64; ++w) {
-            if (w < wid) { bp += w_pass[w]; bf += w_first[w]; }
-            tp += w_pass[w]; tf += w_first[w];
+            if (w < wid) { bp += w_pass[w]; bf += w_first[w]; bh += w_head[w]; }
+            tp += w_pass[w]; tf += w_first[w]; th += w_head[w];
         }
         const u64 lt = (1ull << lane) - 1ull;
+        if (f & 4) run_j0[head_base + bh + __popcll(mh & lt)] = (int32_t)j;     // runs in order j
         if (f & 1) {
             if (pass_list) pass_list[pass_base + bp + __popcll(mp & lt)] = (int32_t)j;
             if (f & 2) {
@@ -170,12 +180,13 @@ __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__rest
         }
         pass_base += tp;
         first_base += tf;
+        head_base += th;
         __syncthreads();
     }
 }
 
 __global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const int64_t *blk_off, int64_t *dscal, int vcap,
-                         int64_t *bscal)
+                         int64_t *bscal, const int32_t *blk_runs, const int32_t *blk_run_off)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int64_t tot = blk_off[nblk - 1] + blk_tot[nblk - 1];
@@ -194,6 +205,7 @@ __global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const 
     bscal[3] = 0;                       // segment queue of the rgb chain
     dscal[DS_B_NPAIR] = 0;
     dscal[DS_B_NPSEG] = 0;
+    dscal[DS_B_NRUN] = (int64_t)blk_run_off[nblk - 1] + blk_runs[nblk - 1];
 }
 
 // memory_2.py:888-903 — the rgb chain c' = trunc((f32(c*w) + r*a) / (w + a)), w' = f32(w + a) is sequential by
@@ -225,23 +237,17 @@ struct ChainRegs {
     uint32_t alo[CQ], ahi[CQ];
 };
 
-// order indices of the chunk starting at sorted position `pos` (0xffffffff = not in this segment).  All loads are
-// unconditional (clamped addresses) so that the 32 of them issue back to back instead of one dependent branch each.
-__device__ __forceinline__ void chain_load_idx(uint32_t (&J)[CQ], bool on, int64_t pos, int q, int64_t P, uint32_t vid,
-                                               const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval)
+// order indices of the chunk starting at position `pos` of the per-voxel point order (0xffffffff = past the segment's
+// end k1).  The loads are unconditional (clamped addresses) so that all of them issue back to back.
+__device__ __forceinline__ void chain_load_idx(uint32_t (&J)[CQ], bool on, int64_t pos, int q, int64_t k1,
+                                               const uint32_t *__restrict__ sj)
 {
-    uint32_t key[CQ], val[CQ];
 #pragma unroll
     for (int i = 0; i < CQ; ++i) {
         const int64_t k = pos + 4 * i + q;
-        const int64_t kk = k < P ? k : P - 1;
-        key[i] = skey[kk];
-        val[i] = sval[kk];
-    }
-#pragma unroll
-    for (int i = 0; i < CQ; ++i) {
-        const int64_t k = pos + 4 * i + q;
-        J[i] = (on && k < P && key[i] == vid) ? val[i] : 0xffffffffu;
+        const bool in = on && k < k1;
+        const uint32_t j = sj[in ? k : 0];
+        J[i] = in ? j : 0xffffffffu;
     }
 }
 
@@ -276,9 +282,8 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
         w = act ? (float)den : w;                               /* :899 */                         \
     }
 
-__global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restrict__ skey,
-                                              const uint32_t *__restrict__ sval, int64_t *bscal,
-                                              const int32_t *__restrict__ seg_start,
+__global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
+                                              const int4 *__restrict__ seg_info,
                                               const PointRec *__restrict__ p_rec,
                                               const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
                                               float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restr
     unsigned long long *queue = (unsigned long long *)(bscal + 3);
 
     bool have = false, exhausted = false;
-    int64_t s = 0, pos = 0;
+    int64_t s = 0, pos = 0, k1 = 0;
     uint32_t vid = 0, c = 0, last_j = 0;
     float w = 0.f;
     ChainRegs R, Rn;
@@ -315,12 +320,13 @@ __global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restr
                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
             bool fresh = false, is_new = false;
             if (need) {
-                s = (int64_t)base + __popcll(mneed & quads_below);
-                if (s < nseg) { fresh = true; have = true; } else exhausted = true;
+                const int64_t turn = (int64_t)base + __popcll(mneed & quads_below);
+                if (turn < nseg) { fresh = true; have = true; s = seg_info[turn].w; } else exhausted = true;
             }
             if (fresh) {
-                pos = seg_start[s];
-                vid = skey[pos];
+                const int4 info = seg_info[s];
+                pos = info.x; k1 = info.y;
+                vid = (uint32_t)info.z;
                 is_new = (int64_t)vid >= max_id_prev;
                 w = 0.f; c = 0u; last_j = 0u;
                 if (!is_new) {
@@ -329,12 +335,12 @@ __global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restr
                 }
             }
             uint32_t J0[CQ];
-            chain_load_idx(J0, fresh, pos, q, P, vid, skey, sval);
+            chain_load_idx(J0, fresh, pos, q, k1, sj);
             ChainRegs R0;
             uint32_t lj = last_j;
             chain_load_rec(R0, J0, p_rec, lj);
             uint32_t J1[CQ];
-            chain_load_idx(J1, fresh, pos + 64, q, P, vid, skey, sval);
+            chain_load_idx(J1, fresh, pos + 64, q, k1, sj);
             // :890-894 a new id takes the colour of its first point and weight f32(0 + alpha); that point is then done
             const uint32_t rv0 = quad_bcast<0>(R0.rv[0]);
             const double a0 = __hiloint2double((int)quad_bcast<0>(R0.ahi[0]), (int)quad_bcast<0>(R0.alo[0]));
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restr
 
         // ---- prefetch: records of the next chunk, order indices of the one after ----------------------------------
         chain_load_rec(Rn, Jn, p_rec, last_j);
-        chain_load_idx(Jnn, have, pos + 128, q, P, vid, skey, sval);
+        chain_load_idx(Jnn, have, pos + 128, q, k1, sj);
 
         // ---- 64 steps out of registers; a block of 16 is skipped once no quad of the wave has points left in it ----
         bool go = true;
@@ -395,16 +401,108 @@ __global__ __launch_bounds__(64) void k_chain(int64_t P, const uint32_t *__restr
     }
 }
 
+// ---- runs -> per-voxel point order ---------------------------------------------------------------------------------
+// run r (in order j) -> sort key = voxel id of its cell (0xffffffff: invalid depth / outside the grid / capacity)
+__global__ __launch_bounds__(TPB) void k_run_keys(const int64_t *dscal, const int32_t *__restrict__ run_j0,
+                                                  const int32_t *__restrict__ p_cell, const int32_t *__restrict__ occ,
+                                                  uint32_t *__restrict__ rkey, uint32_t *__restrict__ rval)
+{
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= dscal[DS_B_NRUN]) return;
+    const int32_t c = p_cell[run_j0[r]];
+    int32_t vid = -1;
+    if (c >= 0) vid = occ[c];
+    rkey[r] = vid >= 0 ? (uint32_t)vid : 0xffffffffu;
+    rval[r] = (uint32_t)r;
+}
+
+// sorted run -> its length (0 for the invalid runs, which sort last and take no room in the point order)
+__global__ __launch_bounds__(TPB) void k_run_len(const int64_t *dscal, int64_t P, const uint32_t *__restrict__ rkey_sorted,
+                                                 const uint32_t *__restrict__ rval_sorted,
+                                                 const int32_t *__restrict__ run_j0, int32_t *__restrict__ run_len)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const int64_t R = dscal[DS_B_NRUN];
+    if (i >= R) return;
+    const int64_t r = rval_sorted[i];
+    const int64_t j1 = r + 1 < R ? run_j0[r + 1] : P;
+    run_len[i] = rkey_sorted[i] == 0xffffffffu ? 0 : (int32_t)(j1 - run_j0[r]);
+}
+
+// point order: sj[run_off[i] + t] = j0(i) + t.  One wavefront per 64 sorted runs; the outputs of the 64 runs are
+// contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.
+__global__ __launch_bounds__(TPB) void k_expand(const int64_t *dscal, const uint32_t *__restrict__ rval_sorted,
+                                                const int32_t *__restrict__ run_j0, const int32_t *__restrict__ run_len,
+                                                const int32_t *__restrict__ run_off, uint32_t *__restrict__ sj)
+{
+    __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t R = dscal[DS_B_NRUN];
+    const int64_t i = ((int64_t)blockIdx.x * (TPB / 64) + wid) * 64 + lane;
+    int32_t off = INT_MAX, len = 0, j0 = 0;
+    if (i < R) {
+        off = run_off[i]; len = run_len[i];
+        j0 = run_j0[rval_sorted[i]];
+    }
+    s_off[wid][lane] = off;
+    s_j0[wid][lane] = j0;
+    const int32_t begin = __shfl(off, 0);
+    int32_t end = off == INT_MAX ? 0 : off + len;
+    for (int o = 32; o > 0; o >>= 1) end = max(end, __shfl_xor(end, o));
+    __builtin_amdgcn_wave_barrier();
+    if (begin == INT_MAX) return;
+    for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
+        int lo = 0;                             // largest lo with s_off[lo] <= pnt (offsets ascend; empty runs sort last)
+#pragma unroll
+        for (int stp = 32; stp > 0; stp >>= 1)
+            if (s_off[wid][lo + stp] <= pnt) lo += stp;
+        sj[pnt] = (uint32_t)(s_j0[wid][lo] + (pnt - s_off[wid][lo]));
+    }
+}
+
+// voxel segments of the point order: {first k, end k, voxel id, -} + sort keys that order the segments by length class
+// (longest first).  The chain hands segments to quads in that order, so the 16 quads of a wavefront walk segments of
+// similar length (a wavefront issues for as long as its longest segment lasts) and the longest voxels start first.
+__global__ __launch_bounds__(TPB) void k_seg_bounds(const int64_t *bscal, const int64_t *dscal, int64_t n_bound,
+                                                    const int32_t *__restrict__ run_heads,
+                                                    const uint32_t *__restrict__ rkey_sorted,
+                                                    const int32_t *__restrict__ run_len,
+                                                    const int32_t *__restrict__ run_off, int4 *__restrict__ seg_info,
+                                                    uint32_t *__restrict__ okey, uint32_t *__restrict__ oval)
+{
+    const int64_t nseg = bscal[0], R = dscal[DS_B_NRUN];
+    for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < n_bound; s += (int64_t)gridDim.x * TPB) {
+        uint32_t key = 63u;
+        if (s < nseg) {
+            const int32_t h = run_heads[s];
+            const int32_t k0 = run_off[h];
+            const int32_t k1 = s + 1 < nseg ? run_off[run_heads[s + 1]] : run_off[R - 1] + run_len[R - 1];
+            seg_info[s] = make_int4(k0, k1, (int32_t)rkey_sorted[h], 0);
+            key = (uint32_t)__clz(k1 - k0);          // 2^(31-key) <= length < 2^(32-key)
+        }
+        okey[s] = key;
+        oval[s] = (uint32_t)s;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_seg_order(const int64_t *bscal, const uint32_t *__restrict__ oval_sorted,
+                                                   int4 *__restrict__ seg_info)
+{
+    const int64_t nseg = bscal[0];
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * TPB)
+        seg_info[i].w = (int32_t)oval_sorted[i];
+}
+
 // top-down map colour: the voxel whose (h, order) won the cell writes the rgb of its latest point
-__global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const uint32_t *__restrict__ skey,
-                                              const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_last,
+__global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const int4 *__restrict__ seg_info,
+                                              const int32_t *__restrict__ seg_last,
                                               const int32_t *__restrict__ rgb_pos, const u64 *__restrict__ hmap,
                                               const PointRec *__restrict__ p_rec, uint8_t *__restrict__ cv_map, int gs,
                                               int64_t order_base)
 {
     const int64_t nseg = bscal[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * TPB) {
-        const uint32_t vid = skey[seg_start[s]];
+        const uint32_t vid = (uint32_t)seg_info[s].z;
         const uint32_t last_j = (uint32_t)seg_last[s];
         const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
         const int64_t rc = (int64_t)row * gs + col;
@@ -492,7 +590,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     x->cur_set ^= 1;
     if (x->ev_done_valid[set]) BSC_HIP(hipStreamWaitEvent(s, x->ev_done[set], 0));
     PointRec *p_rec = x->p_rec_s[set];
-    uint32_t *skey_b = x->skey_b_s[set], *sval_b = x->sval_b_s[set];
+    uint32_t *skey_b = x->skey_b_s[set];
     if (idx)
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
     GeomConst gc = make_geom_const(x);
@@ -500,14 +598,16 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                        alpha, P, x->occ, x->p_cell, x->p_patf, p_rec, x->c.mode == BSC_MODE_EXACT ? x->p_r2f : (float *)nullptr);
     const int64_t nblk = (P + FB - 1) / FB;
     const dim3 fgrid((unsigned)nblk);
-    hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in);
+    hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->blk_cnt);
     BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)nblk));
+    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     // k_assign reads occ while other blocks overwrite claimed cells with ids: a claim INT_MIN + j can only be
     // replaced by the id of that same point j, so the flags of every other point are unaffected
     hipLaunchKernelGGL(k_assign, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_out, x->dscal, x->c.voxel_capacity,
-                       x->c.grid_size, x->nh, x->rgb_pos, x->c.mode == BSC_MODE_EXACT ? x->pass_list : (int32_t *)nullptr);
+                       x->c.grid_size, x->nh, x->rgb_pos, x->c.mode == BSC_MODE_EXACT ? x->pass_list : (int32_t *)nullptr,
+                       x->blk_off, x->run_j0);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->p_scan_in, x->p_scan_out, x->dscal,
-                       x->c.voxel_capacity, x->bscal_s[set]);
+                       x->c.voxel_capacity, x->bscal_s[set], x->blk_cnt, x->blk_off);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr));
     // one small readback per call: voxel count (sort width), pair count (dense modes), passing points (exact mode),
     // capacity flag.  Everything enqueued so far is the call's front end; the back end is sized from these numbers.
@@ -518,17 +618,36 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     }
     // ids in use are < max_id; invalid points carry 0xffffffff, which must still sort last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
-    // stable radix sort on the voxel id alone: points enter in order j, so each voxel's run stays in order
-    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, sval_b, (size_t)P, 0, vid_bits));
-    BSC_TRY(compact_heads_u32(x, skey_b, P, x->seg_start_s[set], x->bscal_s[set]));
+    // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
+    // their expansion is the per-voxel point order
+    const int64_t R = x->hscal[DS_B_NRUN];
+    const dim3 rgrid((unsigned)((R + TPB - 1) / TPB));
+    uint32_t *sj = x->sval_b_s[set];
+    hipLaunchKernelGGL(k_run_keys, rgrid, block, 0, s, x->dscal, x->run_j0, x->p_cell, x->occ, x->skey_a, x->sval_a);
+    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits));
+    hipLaunchKernelGGL(k_run_len, rgrid, block, 0, s, x->dscal, P, skey_b, x->run_val_b, x->run_j0, x->run_len);
+    BSC_TRY(prim_exclusive_sum_i32(x, x->run_len, x->run_off, (size_t)R));
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((R + TPB - 1) / TPB)), block, 0, s, x->dscal, x->run_val_b, x->run_j0,
+                       x->run_len, x->run_off, sj);
+    BSC_TRY(compact_heads_u32(x, skey_b, R, x->run_heads, x->bscal_s[set]));
+    const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
+    int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
+    if (n_bound > seg_cap) n_bound = seg_cap;
+    hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, s, x->bscal_s[set], x->dscal, n_bound, x->run_heads, skey_b,
+                       x->run_len, x->run_off, x->seg_info_s[set], x->skey_a, x->sval_a);
+    if (n_bound > 0)
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->run_len, x->sval_a, (uint32_t *)x->run_off, (size_t)n_bound, 0, 6));
+    hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->run_off, x->seg_info_s[set]);
     // rgb chain + top-down map on the side stream: sequential-latency bound, so it overlaps the
     // HBM-bound dense reduce of this call and whatever the caller enqueues next (the next batch's encoder)
     BSC_HIP(hipEventRecord(x->ev_ready[set], s));
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
-    // 16 voxels per wavefront, two wavefronts per SIMD at most: the queue keeps them busy
-    hipLaunchKernelGGL(k_chain, dim3(2048), dim3(64), 0, x->side, P, skey_b, sval_b, x->bscal_s[set], x->seg_start_s[set], p_rec,
+    // 512 wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner (the
+    // longest voxel bounds the kernel) and only take registers and issue slots from the kernels running beside it:
+    // measured with 2048 / 512 wavefronts, chain 4.4 / 3.0 ms, concurrent k_dense_reduce 0.59 / 0.28 ms.
+    hipLaunchKernelGGL(k_chain, dim3(512), dim3(64), 0, x->side, sj, x->bscal_s[set], x->seg_info_s[set], p_rec,
                        x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size, x->order_base);
-    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], skey_b, x->seg_start_s[set],
+    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], x->seg_info_s[set],
                        x->seg_last_s[set], x->rgb_pos, x->hmap, p_rec, x->cv_map, x->c.grid_size, x->order_base);
     BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
     x->ev_done_valid[set] = true;
