@@ -59,7 +59,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step (per rank); 8 steps x 128 = 1024 frames")
+    ap.add_argument("--batch", type=int, default=384, help="frames per step (per rank); 8 steps x 384 = 3072 frames")
+    ap.add_argument("--tokens", choices=["bf16", "f32"], default="f32",
+                    help="dtype the encoder hands to bsc_ingest: f32 like the reference's _get_patch_token, or its "
+                         "native bf16 (bsc_ingest_typed widens it exactly on load)")
     ap.add_argument("--kind", default="room", choices=["room", "iid"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")
@@ -125,9 +128,9 @@ def main():
     # bsc_ingest of batch s (HBM / latency-bound) runs on the main stream; tokens are double-buffered.
     NBUF = a.prefetch + 1   # token buffers: the encoder runs `prefetch` batches ahead of bsc_ingest
     if a.no_graph:
-        encs = [vit.patch_tokens] * NBUF
+        encs = [lambda r: vit.patch_tokens(r, a.tokens == "bf16")] * NBUF
     else:
-        encs = [encoder.GraphedEncoder(vit, a.batch, H, W, 4) for _ in range(NBUF)]
+        encs = [encoder.GraphedEncoder(vit, a.batch, H, W, 4, a.tokens == "bf16") for _ in range(NBUF)]
     enc = encs[0]
     enc_stream = torch.cuda.Stream()
     main_stream = torch.cuda.current_stream()
@@ -188,7 +191,7 @@ def main():
         out = {
             "metric": "RGB-D frames/sec into voxel feature memory", "value": frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry / f32 features",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry / f32 features" + (" (bf16 tokens in)" if a.tokens == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": f"{a.batch * a.steps} synthetic {W}x{H} RGB-D frames per GPU ({a.kind} depth, every "
                                    f"pixel), {a.arch} random weights {D}-D tokens {g}x{g}, {gs}^3 grid of {cs} m cells, "
@@ -200,13 +203,14 @@ def main():
     # ---- per-stage split (untimed extra pass) and roofline of the dominant hand-written kernel ----
     if rank == 0 and world == 1:
         launches = max(1, ks["launches"])
+        tok_bytes = 2 if a.tokens == "bf16" else 4
         U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per launch
         U_new = (c1["max_id"] - c0["max_id"]) / a.steps
         P_pass = (c1["points_passed"] - c0["points_passed"]) / a.steps
         n_pairs = (c1["pairs"] - c0["pairs"]) / a.steps
         # algorithmic bytes of one k_dense_reduce launch: accumulator rows RMW (new rows are
         # written only) + counts + token tile once + the sorted (voxel,frame,patch) pair list (key 8 B + count 4 B)
-        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * 4 + 12 * n_pairs
+        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * tok_bytes + 12 * n_pairs
         ms = ks["ms"] / launches
         achieved = alg / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_dense_reduce", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -232,7 +236,7 @@ def main():
         k = hi - lo
         ksi, ci1 = eng.kernel_stats(0), eng.counters()
         Ui = (ci1["voxel_rmw"] - ci0["voxel_rmw"]) / k
-        alg_i = (2 * Ui - (ci1["max_id"] - ci0["max_id"]) / k) * D * 4 + 8 * Ui + a.batch * g * g * D * 4 \
+        alg_i = (2 * Ui - (ci1["max_id"] - ci0["max_id"]) / k) * D * 4 + 8 * Ui + a.batch * g * g * D * tok_bytes \
             + 12 * (ci1["pairs"] - ci0["pairs"]) / k
         ms_i = ksi["ms"] / max(1, ksi["launches"])
         out["roofline_isolated"] = {"kernel": "k_dense_reduce", "note": "same workload, bsc_ingest running alone",

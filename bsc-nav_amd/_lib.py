@@ -35,6 +35,7 @@ SIGNATURES = {
     "bsc_destroy": (None, [_VP]),
     "bsc_reset": (_I32, [_VP]),
     "bsc_ingest": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, DRAW_FN, _VP]),
+    "bsc_ingest_typed": (_I32, [_VP, _I32, _VP, _VP, _I32, _VP, _I32, _VP, _VP, _VP, _VP, DRAW_FN, _VP]),
     "bsc_flush": (_I32, [_VP, DRAW_FN, _VP]),
     "bsc_counters": (_I32, [_VP, _VP]),
     "bsc_geometry": (_I32, [_VP, _VP, _VP, _VP, _I64] + [_VP] * 8),

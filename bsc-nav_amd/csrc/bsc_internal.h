@@ -169,12 +169,22 @@ bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, s
 bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *idx, int64_t P, uint8_t *flags,
                                  double *pc, double *pg, int32_t *vox, int32_t *pix, int32_t *pat, double *r2,
                                  double *alpha);
+// token rows come as f32 (the reference's DINOv2 output) or as bf16 (what a bf16 encoder emits; widened exactly)
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float4 load_tok4(const float *row, int v) { return ((const float4 *)row)[v]; }
+__device__ __forceinline__ float4 load_tok4(const bf16_t *row, int v)
+{
+    const uint2 raw = ((const uint2 *)row)[v];
+    return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                       __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u));
+}
+
 bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
-                        const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
-                        bsc_draw_fn draw, void *user);
+                        const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
+                        const double *alpha, bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
 bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels);
-bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames);
+bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, int n_frames);
 // list of segment starts of a sorted key array (segments = runs of equal key >> shift; keys == invalid are skipped);
 // the number of segments is written to *count_dev.  Deterministic: per-block counts + exclusive scan.
 bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev);

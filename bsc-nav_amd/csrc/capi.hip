@@ -240,13 +240,13 @@ extern "C" bsc_status bsc_reset(bsc_ctx *x)
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_ingest(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
-                                 int32_t rgb_channels, const float *tokens_dev, const double *transforms_host,
-                                 const int32_t *sample_idx_dev, const int64_t *offsets_host, const double *alpha_dev,
-                                 bsc_draw_fn draw, void *user)
+extern "C" bsc_status bsc_ingest_typed(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
+                                       int32_t rgb_channels, const void *tokens_dev, int32_t token_dtype,
+                                       const double *transforms_host, const int32_t *sample_idx_dev,
+                                       const int64_t *offsets_host, const double *alpha_dev, bsc_draw_fn draw, void *user)
 {
     if (!x || !depth_dev || !rgb_dev || !tokens_dev || !transforms_host || n_frames < 1 || n_frames > x->max_frames ||
-        rgb_channels < 3 || (sample_idx_dev && !offsets_host)) {
+        rgb_channels < 3 || (sample_idx_dev && !offsets_host) || (token_dtype != BSC_TOK_F32 && token_dtype != BSC_TOK_BF16)) {
         bsc_set_error("bsc_ingest: invalid argument");
         return BSC_E_INVALID;
     }
@@ -254,9 +254,18 @@ extern "C" bsc_status bsc_ingest(bsc_ctx *x, int32_t n_frames, const float *dept
     BSC_HIP(hipMemcpyAsync(x->d_transforms, transforms_host, sizeof(double) * 16 * n_frames, hipMemcpyHostToDevice,
                            x->stream));
     x->names_dirty = true;
-    bsc_status st = ingest_batch(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, sample_idx_dev, offsets_host,
-                                 alpha_dev, draw, user);
+    bsc_status st = ingest_batch(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, token_dtype, sample_idx_dev,
+                                 offsets_host, alpha_dev, draw, user);
     return st;
+}
+
+extern "C" bsc_status bsc_ingest(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
+                                 int32_t rgb_channels, const float *tokens_dev, const double *transforms_host,
+                                 const int32_t *sample_idx_dev, const int64_t *offsets_host, const double *alpha_dev,
+                                 bsc_draw_fn draw, void *user)
+{
+    return bsc_ingest_typed(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, BSC_TOK_F32, transforms_host,
+                            sample_idx_dev, offsets_host, alpha_dev, draw, user);
 }
 
 extern "C" bsc_status bsc_flush(bsc_ctx *x, bsc_draw_fn draw, void *user)

@@ -265,18 +265,18 @@ __global__ __launch_bounds__(TPB) void k_seg_morton(int64_t n_bound, const int64
 
 // four runs at a time: all token-row loads (4 x NV x 16 B per lane) are in flight before the first FMA, so a voxel
 // with many (frame, patch) pairs pays the L2 / Infinity-Cache latency once per four rows instead of once per row
-template <int NV, int MODE>
+template <int NV, int MODE, typename TOK>
 __device__ __forceinline__ void apply_runs4(float4 (&a)[NV], const uint32_t (&code)[4], const uint32_t (&cnt)[4],
-                                            const float *__restrict__ tokens, int g2, int D, int D4, int lane, int pb)
+                                            const TOK *__restrict__ tokens, int g2, int D, int D4, int lane, int pb)
 {
     float4 xv[4][NV];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float4 *row = (const float4 *)(tokens + ((int64_t)(code[r] >> pb) * g2 + (code[r] & ((1u << pb) - 1u))) * D);
+        const TOK *row = tokens + ((int64_t)(code[r] >> pb) * g2 + (code[r] & ((1u << pb) - 1u))) * D;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int v = lane + 64 * t;
-            xv[r][t] = (v < D4) ? row[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[r][t] = (v < D4) ? load_tok4(row, v) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
@@ -295,10 +295,10 @@ __device__ __forceinline__ void apply_runs4(float4 (&a)[NV], const uint32_t (&co
     }
 }
 
-template <int NV, int MODE>
+template <int NV, int MODE, typename TOK>
 __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pkey, const uint32_t *__restrict__ pcnt,
                                                       int64_t n_pairs, const uint32_t *__restrict__ seg_start,
-                                                      const int64_t *dscal, const float *__restrict__ tokens, int g2,
+                                                      const int64_t *dscal, const TOK *__restrict__ tokens, int g2,
                                                       int D, float *__restrict__ acc, int32_t *__restrict__ acnt, int pb,
                                                       int cb)
 {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
                 } else {
                     const uint32_t cc[4] = {pend_code, pend_code, pend_code, pend_code};
                     const uint32_t rc[4] = {pend_cnt, 0u, 0u, 0u};
-                    apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
+                    apply_runs4<NV, MODE, TOK>(a, cc, rc, tokens, g2, D, D4, lane, pb);
                 }
                 pend_cnt = 0;
             }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
                         rc[r] = 0u;
                     }
                 }
-                apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
+                apply_runs4<NV, MODE, TOK>(a, cc, rc, tokens, g2, D, D4, lane, pb);
             }
             if (n > 0) total += __shfl(ps, n - 1);
             if (n < 64) break;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
         if (pend_cnt) {
             const uint32_t cc[4] = {pend_code, pend_code, pend_code, pend_code};
             const uint32_t rc[4] = {pend_cnt, 0u, 0u, 0u};
-            apply_runs4<NV, MODE>(a, cc, rc, tokens, g2, D, D4, lane, pb);
+            apply_runs4<NV, MODE, TOK>(a, cc, rc, tokens, g2, D, D4, lane, pb);
         }
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
@@ -434,14 +434,14 @@ __global__ void k_dense_counters(int64_t *dscal)
 static inline int code_patch_bits(const bsc_ctx *x) { return ceil_log2_u64((uint64_t)x->g2); }
 static inline int code_bits(const bsc_ctx *x, int n_frames) { return code_patch_bits(x) + ceil_log2_u64((uint64_t)n_frames); }
 
-template <int MODE>
-static void launch_dense(bsc_ctx *x, int64_t n_pairs, const float *tokens, int pb, int cb)
+template <int MODE, typename TOK>
+static void launch_dense(bsc_ctx *x, int64_t n_pairs, const TOK *tokens, int pb, int cb)
 {
     const int D = x->c.token_dim;
     const int nv = (D / 4 + 63) / 64;
     const dim3 grid(256 * 8), block(TPB);
 #define LD(NV)                                                                                                          \
-    hipLaunchKernelGGL((k_dense_reduce<NV, MODE>), grid, block, 0, x->stream, x->pair_key_b, x->pair_cnt_b, n_pairs,    \
+    hipLaunchKernelGGL((k_dense_reduce<NV, MODE, TOK>), grid, block, 0, x->stream, x->pair_key_b, x->pair_cnt_b, n_pairs,    \
                        (const uint32_t *)x->pseg_start, x->dscal, tokens, x->g2, D, x->acc, x->acnt, pb, cb)
     if (nv <= 1) LD(1);
     else if (nv == 2) LD(2);
@@ -474,7 +474,7 @@ bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixel
     return BSC_OK;
 }
 
-bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames)
+bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, int n_frames)
 {
     hipStream_t s = x->stream;
     const int64_t n_pairs = x->hscal[DS_B_NPAIR];   // read back by ingest_batch after the front end
@@ -495,8 +495,13 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const float *tokens, int n_frames)
                        x->pair_key_b, cb, x->rgb_pos, x->skey_a, x->sval_a);
     BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, x->pair_cnt_a, x->sval_a, (uint32_t *)x->pseg_start, (size_t)n_bound, 0, 30));
     stat_begin(x, 0);
-    if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, tokens, pb, cb);
-    else launch_dense<BSC_MODE_MAX>(x, n_pairs, tokens, pb, cb);
+    if (token_dtype == BSC_TOK_BF16) {
+        if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, (const bf16_t *)tokens, pb, cb);
+        else launch_dense<BSC_MODE_MAX>(x, n_pairs, (const bf16_t *)tokens, pb, cb);
+    } else {
+        if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, (const float *)tokens, pb, cb);
+        else launch_dense<BSC_MODE_MAX>(x, n_pairs, (const float *)tokens, pb, cb);
+    }
     stat_end(x, 0, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, pairs)
     hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);
     BSC_HIP(hipGetLastError());

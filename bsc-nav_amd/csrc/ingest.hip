@@ -517,10 +517,11 @@ __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const int4 *
 }
 
 // exact mode, memory_2.py:882-886: rows [row0, row0+n) of the token cache <- passing points [q0, q0+n)
+template <typename TOK>
 __global__ __launch_bounds__(TPB) void k_append(const int32_t *__restrict__ pass_list, int64_t q0, int64_t n,
                                                 int64_t row0, const int32_t *__restrict__ p_cell,
                                                 const uint32_t *__restrict__ p_patf, const float *__restrict__ p_r2f,
-                                                const float *__restrict__ tokens, int g2, int D, int gs, int nh,
+                                                const TOK *__restrict__ tokens, int g2, int D, int gs, int nh,
                                                 float *__restrict__ cache_f, int32_t *__restrict__ cache_pos,
                                                 float *__restrict__ cache_d)
 {
@@ -529,9 +530,9 @@ __global__ __launch_bounds__(TPB) void k_append(const int32_t *__restrict__ pass
     if (w >= n) return;
     const int32_t j = pass_list[q0 + w];
     const uint32_t cc = p_patf[j];
-    const float4 *src = (const float4 *)(tokens + ((int64_t)(cc >> 16) * g2 + (cc & 0xffffu)) * D);
+    const TOK *src = tokens + ((int64_t)(cc >> 16) * g2 + (cc & 0xffffu)) * D;
     float4 *dst = (float4 *)(cache_f + (row0 + w) * D);
-    for (int v = lane; v < (D >> 2); v += 64) dst[v] = src[v];
+    for (int v = lane; v < (D >> 2); v += 64) dst[v] = load_tok4(src, v);
     if (lane == 0) {
         const int32_t c = p_cell[j];
         const int32_t h = c % nh, rc = c / nh;
@@ -573,8 +574,8 @@ bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *
 }
 
 bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
-                        const float *tokens, const int32_t *idx, const int64_t *offsets_host, const double *alpha,
-                        bsc_draw_fn draw, void *user)
+                        const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
+                        const double *alpha, bsc_draw_fn draw, void *user)
 {
     const int64_t N = (int64_t)x->c.height * x->c.width;
     const int64_t P = idx ? offsets_host[n_frames] : (int64_t)n_frames * N;
@@ -651,7 +652,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                        x->seg_last_s[set], x->rgb_pos, x->hmap, p_rec, x->cv_map, x->c.grid_size, x->order_base);
     BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
     x->ev_done_valid[set] = true;
-    if (x->c.mode != BSC_MODE_EXACT) BSC_TRY(dense_reduce_batch(x, tokens, n_frames));
+    if (x->c.mode != BSC_MODE_EXACT) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
     BSC_HIP(hipGetLastError());
     x->order_base += P;
     if (x->c.mode == BSC_MODE_EXACT) {
@@ -662,9 +663,15 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
             const int64_t room = x->c.iter_size - x->iter_id;
             const int64_t n = remaining < room ? remaining : room;
             if (n > 0) {
-                hipLaunchKernelGGL(k_append, dim3((unsigned)((n * 64 + TPB - 1) / TPB)), block, 0, s, x->pass_list, q, n,
-                                   x->iter_id, x->p_cell, x->p_patf, x->p_r2f, tokens, x->g2, x->c.token_dim,
-                                   x->c.grid_size, x->nh, x->cache_f, x->cache_pos, x->cache_d);
+                const dim3 agrid((unsigned)((n * 64 + TPB - 1) / TPB));
+                if (token_dtype == BSC_TOK_BF16)
+                    hipLaunchKernelGGL(k_append<bf16_t>, agrid, block, 0, s, x->pass_list, q, n, x->iter_id, x->p_cell,
+                                       x->p_patf, x->p_r2f, (const bf16_t *)tokens, x->g2, x->c.token_dim, x->c.grid_size,
+                                       x->nh, x->cache_f, x->cache_pos, x->cache_d);
+                else
+                    hipLaunchKernelGGL(k_append<float>, agrid, block, 0, s, x->pass_list, q, n, x->iter_id, x->p_cell,
+                                       x->p_patf, x->p_r2f, (const float *)tokens, x->g2, x->c.token_dim, x->c.grid_size,
+                                       x->nh, x->cache_f, x->cache_pos, x->cache_d);
                 BSC_HIP(hipGetLastError());
                 x->iter_id += n; q += n; remaining -= n;
             }

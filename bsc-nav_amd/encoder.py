@@ -98,8 +98,8 @@ class RandomViT(nn.Module):
         return self._forward_patches(t)
 
     @torch.no_grad()
-    def _forward_patches(self, t):
-        """(B, g*g, 3*p*p) unfolded, normalised patches -> {'x_norm_patchtokens': (B, g*g, D)}."""
+    def _forward_patches(self, t, keep_dtype=False):
+        """(B, g*g, 3*p*p) unfolded, normalised patches -> {'x_norm_patchtokens': (B, g*g, D)} (f32 unless keep_dtype)."""
         B = t.shape[0]
         t = self.patch_embed(t)
         t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
@@ -116,7 +116,7 @@ class RandomViT(nn.Module):
         t = y[:, 1 + self.registers:]
         if self.head is not None:
             t = self.head(t)
-        return {"x_norm_patchtokens": t.float()}
+        return {"x_norm_patchtokens": t if keep_dtype else t.float()}
 
     def _add_ln(self, x, delta, ln, fuse):
         """(x + delta, LayerNorm(x + delta)); one HIP kernel (bsc_enc_add_layernorm) when `fuse`."""
@@ -139,8 +139,9 @@ class RandomViT(nn.Module):
         return xout, y
 
     @torch.no_grad()
-    def patch_tokens(self, rgb):
-        """rgb (B,H,W,C) u8 on the device -> (B, g, g, D) fp32 contiguous."""
+    def patch_tokens(self, rgb, keep_dtype=False):
+        """rgb (B,H,W,C) u8 on the device -> (B, g, g, D) contiguous: fp32 like the reference's _get_patch_token, or
+        (keep_dtype) the encoder's own bf16, which bsc_ingest_typed widens exactly on load."""
         if self.fused and rgb.is_cuda and self.compute_dtype == torch.bfloat16 and rgb.is_contiguous():
             from . import _lib
             B, H, W, Cc = rgb.shape
@@ -151,7 +152,7 @@ class RandomViT(nn.Module):
             _lib.check(_lib.load().bsc_enc_preprocess_patches(
                 C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mean, std,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            t = self._forward_patches(patches)["x_norm_patchtokens"]
+            t = self._forward_patches(patches, keep_dtype)["x_norm_patchtokens"]
         else:
             t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
         return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()
@@ -167,18 +168,18 @@ class RandomViT(nn.Module):
 class GraphedEncoder:
     """Replays the encoder for a fixed batch shape from a captured HIP graph (launch-bound at small batch)."""
 
-    def __init__(self, vit, batch, H, W, channels=4):
+    def __init__(self, vit, batch, H, W, channels=4, keep_dtype=False):
         self.vit = vit
         self.static_in = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                vit.patch_tokens(self.static_in)
+                vit.patch_tokens(self.static_in, keep_dtype)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = vit.patch_tokens(self.static_in)
+            self.static_out = vit.patch_tokens(self.static_in, keep_dtype)
 
     def __call__(self, rgb):
         self.static_in.copy_(rgb)

@@ -74,11 +74,11 @@ class VoxelEngine:
         _lib.check(self.lib.bsc_reset(self.h))
 
     def ingest(self, depth, rgb, tokens, transforms, sample_idx=None, offsets=None, alpha=None):
-        """depth (F,H,W) f32, rgb (F,H,W,C) u8, tokens (F,g,g,D) f32: contiguous CUDA tensors.
-        transforms (F,4,4) float64 NumPy.  sample_idx int32 CUDA + offsets (F+1) int64 NumPy, or None."""
+        """depth (F,H,W) f32, rgb (F,H,W,C) u8, tokens (F,g,g,D) f32 or bf16 (widened exactly): contiguous CUDA
+        tensors.  transforms (F,4,4) float64 NumPy.  sample_idx int32 CUDA + offsets (F+1) int64 NumPy, or None."""
         F = depth.shape[0] if depth.dim() == 3 else 1
         assert depth.is_cuda and rgb.is_cuda and tokens.is_cuda
-        assert depth.dtype == torch.float32 and rgb.dtype == torch.uint8 and tokens.dtype == torch.float32
+        assert depth.dtype == torch.float32 and rgb.dtype == torch.uint8 and tokens.dtype in (torch.float32, torch.bfloat16)
         assert depth.is_contiguous() and rgb.is_contiguous() and tokens.is_contiguous()
         T = np.ascontiguousarray(np.asarray(transforms, dtype=np.float64).reshape(F, 16))
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
@@ -86,8 +86,9 @@ class VoxelEngine:
             assert sample_idx.is_cuda and sample_idx.dtype == torch.int32 and off is not None and len(off) == F + 1
         if alpha is not None:
             assert alpha.is_cuda and alpha.dtype == torch.float64
-        _lib.check(self.lib.bsc_ingest(self.h, F, _dp(depth), _dp(rgb), rgb.shape[-1], _dp(tokens), _hp(T),
-                                       _dp(sample_idx), _hp(off), _dp(alpha), self._draw, None))
+        _lib.check(self.lib.bsc_ingest_typed(self.h, F, _dp(depth), _dp(rgb), rgb.shape[-1], _dp(tokens),
+                                             1 if tokens.dtype == torch.bfloat16 else 0, _hp(T), _dp(sample_idx),
+                                             _hp(off), _dp(alpha), self._draw, None))
 
     def flush(self):
         _lib.check(self.lib.bsc_flush(self.h, self._draw, None))

@@ -86,6 +86,16 @@ bsc_status bsc_ingest(bsc_ctx *ctx, int32_t n_frames, const float *depth_dev, co
                       const int32_t *sample_idx_dev, const int64_t *offsets_host, const double *alpha_dev,
                       bsc_draw_fn draw, void *user);
 
+/* bsc_ingest for an encoder that emits half-width tokens: tokens_dev is (n_frames,g,g,D) of token_dtype.
+ * BSC_TOK_BF16 rows are widened exactly to f32 on load, so the result equals bsc_ingest on the widened tokens
+ * (memory_2.py:883 stores whatever _get_patch_token returned); accumulators, caches and the store stay f32. */
+#define BSC_TOK_F32 0
+#define BSC_TOK_BF16 1
+bsc_status bsc_ingest_typed(bsc_ctx *ctx, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
+                            int32_t rgb_channels, const void *tokens_dev, int32_t token_dtype,
+                            const double *transforms_host, const int32_t *sample_idx_dev, const int64_t *offsets_host,
+                            const double *alpha_dev, bsc_draw_fn draw, void *user);
+
 /* update_memory_dist_base (memory_2.py:326-358): all iter_size rows incl. the zero rows. */
 bsc_status bsc_flush(bsc_ctx *ctx, bsc_draw_fn draw, void *user);
 

@@ -26,8 +26,8 @@ def breakdown(rows, calls):
     print("sum per call us", tot / calls / 1e3)
 
 
-def timeline(rows):
-    kp = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_points")]
+def timeline(rows, marker="k_points"):
+    kp = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
     a, b = kp[-3], kp[-2]
     t0 = int(rows[a]["Start_Timestamp"])
     for r in rows[a:b]:
@@ -41,4 +41,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "breakdown":
         breakdown(rows, int(sys.argv[3]) if len(sys.argv) > 3 else 8)
     else:
-        timeline(rows)
+        timeline(rows, sys.argv[3] if len(sys.argv) > 3 else "k_points")

@@ -195,3 +195,32 @@ def test_exact_mode_at_scale_against_oracle():
     import golden_util as gu
     gu.assert_topk_matches(p[0, :n[0]], sim[0, :n[0]], op, osim, tol=5e-6)
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["mean", "max", "exact"])
+def test_bf16_tokens_equal_widened_f32_tokens(mode):
+    """bsc_ingest_typed(BSC_TOK_BF16) widens rows exactly: every state array equals the f32 call on the same values."""
+    import torch
+    H, W, D, g, F = 48, 64, 32, 16, 6
+    rgb, depth, poses = _frames(F, H, W, seed=5)
+    import bsc_nav_amd as B
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    tok16 = torch.randn((F, g, g, D), device="cuda").to(torch.bfloat16)
+    tok32 = tok16.float()
+    out = []
+    import random
+    for tok in (tok32, tok16):
+        random.seed(3)                                       # replacement draws of the flush (memory_2.py:352)
+        eng = _eng(mode, D=D, g=g, max_points=F * H * W, iter_size=1000)
+        r, d = torch.as_tensor(rgb).cuda(), torch.as_tensor(depth).cuda()
+        eng.ingest(d[:3].contiguous(), r[:3].contiguous(), tok[:3].contiguous(), Ts[:3])
+        eng.ingest(d[3:].contiguous(), r[3:].contiguous(), tok[3:].contiguous(), Ts[3:])
+        if mode == "exact":
+            eng.flush()
+            out.append(eng.export_store())
+        else:
+            out.append(eng.export_dense())
+        eng.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
