@@ -51,6 +51,9 @@ SIGNATURES = {
     "bsc_pool_query": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "bsc_localize": (_I32, [_VP, _VP, _I32, _I32, _F64, _VP, _I32, _I32, _VP, _VP, _VP]),
     "bsc_cluster_centers": (_I32, [_VP, _I32, _I32, _VP, _VP, _F64, _I32, _VP, _VP, _VP, _VP]),
+    "bsc_frontier_mask": (_I32, [_VP, _VP, _VP]),
+    "bsc_frontier_clusters": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "bsc_import_cv_map": (_I32, [_VP, _VP]),
     "bsc_dense_gather": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_dense_replace": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),

@@ -125,6 +125,11 @@ struct bsc_ctx {
     bool names_dirty;
     int last_nq, last_K;            // shape of the last bsc_localize call (its top-K stays resident for clustering)
     int32_t last_counts[1024];
+    // frontier helpers (allocated on first use, gs*gs each)
+    uint8_t *fr_mask, *fr_in;
+    int32_t *fr_parent, *fr_size, *fr_ord, *fr_roots, *fr_labels, *fr_first, *fr_sizes, *fr_scal;
+    unsigned long long *fr_sumx, *fr_sumy;
+    double *fr_centers, *fr_gains;
     // primitives workspace
     void *prim_tmp;
     size_t prim_tmp_bytes;
@@ -184,6 +189,11 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                         const double *alpha, bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
 bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels);
+bsc_status frontier_mask_impl(bsc_ctx *x, const uint8_t *navigable_host, uint8_t *mask_host);
+bsc_status frontier_clusters_impl(bsc_ctx *x, const uint8_t *frontier_host, int32_t min_cluster_size, int32_t ig_radius,
+                                  int32_t max_clusters, int32_t *n_clusters_host, int32_t *labels_host,
+                                  int32_t *first_host, int32_t *sizes_host, double *centers_host, double *gains_host,
+                                  int32_t *best_host);
 bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, int n_frames);
 // list of segment starts of a sorted key array (segments = runs of equal key >> shift; keys == invalid are skipped);
 // the number of segments is written to *count_dev.  Deterministic: per-block counts + exclusive scan.

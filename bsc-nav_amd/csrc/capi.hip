@@ -216,7 +216,9 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
-                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp};
+                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
+                    x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
+                    x->fr_centers, x->fr_gains};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
@@ -394,6 +396,40 @@ extern "C" bsc_status bsc_export_heightmap(bsc_ctx *x, double *max_height, uint8
     }
     if (cv_map) BSC_HIP(hipMemcpy(cv_map, x->cv_map, 3 * gs2, hipMemcpyDeviceToHost));
     return BSC_OK;
+}
+
+extern "C" bsc_status bsc_import_cv_map(bsc_ctx *x, const uint8_t *cv_map)
+{
+    if (!x || !cv_map) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));
+    const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
+    BSC_HIP(hipMemcpy(x->cv_map, cv_map, 3 * gs2, hipMemcpyHostToDevice));
+    BSC_HIP(hipMemset(x->hmap, 0, sizeof(u64) * gs2));
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_frontier_mask(bsc_ctx *x, const uint8_t *navigable_host, uint8_t *mask_host)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));                   // the top-down map is written on the side stream
+    return frontier_mask_impl(x, navigable_host, mask_host);
+}
+
+extern "C" bsc_status bsc_frontier_clusters(bsc_ctx *x, const uint8_t *frontier_host, int32_t min_cluster_size,
+                                            int32_t ig_radius, int32_t max_clusters, int32_t *n_clusters_host,
+                                            int32_t *labels_host, int32_t *first_host, int32_t *sizes_host,
+                                            double *centers_host, double *gains_host, int32_t *best_host)
+{
+    if (!x || !n_clusters_host || max_clusters < 0 || ig_radius < 0) {
+        bsc_set_error("bsc_frontier_clusters: invalid argument");
+        return BSC_E_INVALID;
+    }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));
+    return frontier_clusters_impl(x, frontier_host, min_cluster_size, ig_radius, max_clusters, n_clusters_host, labels_host,
+                                  first_host, sizes_host, centers_host, gains_host, best_host);
 }
 
 extern "C" bsc_status bsc_export_cache(bsc_ctx *x, float *feat, int32_t *pos, float *dis)

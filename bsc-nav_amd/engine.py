@@ -200,6 +200,36 @@ class VoxelEngine:
                                                 _hp(centers), _hp(labels), _hp(sizes), _hp(n)))
         return centers[:n[0]], labels.astype(np.int64), [int(v) for v in sizes[:n[0]]]
 
+    # ---- FrontierExplorer helpers (memory_2.py:1147-1311) ----------------------------------------------
+    def frontier_mask(self, navigable=None):
+        """(gs,gs) u8: bit0 known (cv_map.sum(-1) != 0), bit1 frontier (known, navigable, an unknown 4-neighbour)."""
+        gs = self.cfg.grid_size
+        nav = None if navigable is None else np.ascontiguousarray(np.asarray(navigable) != 0, np.uint8)
+        mask = np.zeros((gs, gs), np.uint8)
+        _lib.check(self.lib.bsc_frontier_mask(self.h, _hp(nav), _hp(mask)))
+        return mask
+
+    def frontier_clusters(self, frontier=None, min_cluster_size=10, ig_radius=5, max_clusters=4096, labels=True):
+        """4-connected frontier clusters in the reference's order -> dict(n, first, sizes, centers, gains, best, labels).
+        frontier (gs,gs) nonzero = frontier cell; None = the cells of the last frontier_mask call."""
+        gs = self.cfg.grid_size
+        fr = None if frontier is None else np.ascontiguousarray(np.asarray(frontier) != 0, np.uint8)
+        cap = int(max_clusters)
+        n, best = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        lab = np.zeros((gs, gs), np.int32) if labels else None
+        first, sizes = np.zeros((cap, 2), np.int32), np.zeros(cap, np.int32)
+        centers, gains = np.zeros((cap, 2), np.float64), np.zeros(cap, np.float64)
+        _lib.check(self.lib.bsc_frontier_clusters(self.h, _hp(fr), int(min_cluster_size), int(ig_radius), cap, _hp(n),
+                                                  _hp(lab), _hp(first), _hp(sizes), _hp(centers), _hp(gains), _hp(best)))
+        m = min(int(n[0]), cap)
+        return dict(n=int(n[0]), first=first[:m], sizes=sizes[:m], centers=centers[:m], gains=gains[:m],
+                    best=int(best[0]), labels=lab)
+
+    def import_cv_map(self, cv_map):
+        cv = np.ascontiguousarray(cv_map, np.uint8)
+        assert cv.shape == (self.cfg.grid_size, self.cfg.grid_size, 3)
+        _lib.check(self.lib.bsc_import_cv_map(self.h, _hp(cv)))
+
     def kernel_stats(self, which=0, reset=False):
         """HIP-event time of the dominant kernel: dict(ms, launches, bytes, launches_since_reset)."""
         out = np.zeros(4, np.float64)

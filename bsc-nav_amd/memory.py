@@ -459,6 +459,136 @@ class VoxelTokenMemory:
                                   "exploring_create_memory() or feed frames through obs2voxeltoken()")
 
 
+    # ---- FrontierExplorer (memory_2.py:1147-1418) -----------------------------------------------------------------
+    # The per-cell Python loops of the reference run as HIP kernels over the resident top-down map
+    # (csrc/frontier.hip); the simulator only enters through Env.plnner.pathfinder.is_navigable.
+    def grid2loc_2d(self, x, y):
+        """memory_2.py:1148-1158."""
+        ix, iz, iy = self.Env.original_state.position
+        return np.array([ix + (y - self.gs // 2) * self.cs, iz, iy + (x - self.gs // 2) * self.cs])
+
+    def loc2grid_2d(self, x_base, y_base):
+        """memory_2.py:1160-1163."""
+        return int(self.gs / 2 - int(x_base / self.cs)), int(self.gs / 2 - int(y_base / self.cs))
+
+    def in_bounds(self, x, y):
+        return 0 <= x < self.gs and 0 <= y < self.gs
+
+    def is_unknown(self, x, y):
+        """memory_2.py:1165."""
+        return not bool(self.engine.frontier_mask()[x, y] & 1)
+
+    def is_known(self, x, y):
+        return not self.is_unknown(x, y)
+
+    def is_navigabale(self, x, y):
+        """memory_2.py:1171 (the reference's spelling)."""
+        return self.Env.plnner.pathfinder.is_navigable(self.grid2loc_2d(x, y))
+
+    def build_navigable_mask(self):
+        """memory_2.py:1174-1185: known cells the simulator calls navigable (only known cells are asked)."""
+        known = (self.engine.frontier_mask() & 1).astype(bool)
+        mask = np.zeros((self.gs, self.gs), dtype=bool)
+        for x, y in np.argwhere(known):
+            mask[x, y] = bool(self.is_navigabale(int(x), int(y)))
+        return mask
+
+    def find_frontiers(self, navigable_mask):
+        """memory_2.py:1187-1209 -> [(x, y), ...] row-major."""
+        m = self.engine.frontier_mask(navigable_mask)
+        return [(int(x), int(y)) for x, y in np.argwhere(m & 2)]
+
+    def _frontier_clusters(self, frontiers):
+        fr = np.zeros((self.gs, self.gs), np.uint8)
+        if len(frontiers):
+            f = np.asarray(frontiers, np.int64).reshape(-1, 2)
+            fr[f[:, 0], f[:, 1]] = 1
+        return self.engine.frontier_clusters(fr, getattr(self, "min_cluster_size", 10), getattr(self, "ig_radius", 5),
+                                             max_clusters=self.gs * self.gs)
+
+    def cluster_frontiers(self, frontiers):
+        """memory_2.py:1211-1249 -> list of clusters (lists of (x, y)) with >= min_cluster_size cells, in the reference's
+        order.  Cells inside a cluster are listed row-major (the reference lists them in BFS order; every consumer
+        is order-free: mean, membership)."""
+        if not frontiers:
+            return []
+        r = self._frontier_clusters(frontiers)
+        self._last_clusters = r
+        lab = r["labels"]
+        cells = np.argwhere(lab >= 0)
+        out = [[] for _ in range(r["n"])]
+        for x, y in cells:
+            out[lab[x, y]].append((int(x), int(y)))
+        return out
+
+    def compute_cluster_center(self, cluster):
+        """memory_2.py:1252-1258."""
+        return (sum(p[0] for p in cluster) / len(cluster), sum(p[1] for p in cluster) / len(cluster))
+
+    def compute_information_gain(self, center_x, center_y):
+        """memory_2.py:1260-1280: unknown cells within ig_radius (Chebyshev) of the rounded centre."""
+        known = (self.engine.frontier_mask() & 1).astype(bool)
+        cx, cy, r = int(round(center_x)), int(round(center_y)), getattr(self, "ig_radius", 5)
+        win = known[max(cx - r, 0):max(cx + r + 1, 0), max(cy - r, 0):max(cy + r + 1, 0)]
+        return float(win.size - int(win.sum()))
+
+    def select_best_cluster_center_by_ig(self, frontier_clusters):
+        """memory_2.py:1282-1311: centre of the first cluster with the strictly largest gain > 0, else None."""
+        if not frontier_clusters:
+            return None
+        fr = [c for cl in frontier_clusters for c in cl]
+        r = self._frontier_clusters(fr)
+        # clusters handed in may be a subset / regrouping of the device clusters: match them by first cell
+        if r["n"] == len(frontier_clusters) and all(tuple(r["first"][k]) == min(frontier_clusters[k]) for k in range(r["n"])):
+            return None if r["best"] < 0 else (float(r["centers"][r["best"], 0]), float(r["centers"][r["best"], 1]))
+        best, best_ig = None, 0.0
+        for cl in frontier_clusters:
+            cx, cy = self.compute_cluster_center(cl)
+            ig = self.compute_information_gain(cx, cy)
+            if ig > best_ig:
+                best_ig, best = ig, (cx, cy)
+        return best
+
+    def update_frontier_map(self, frontiers, frontier_clusters, target_center_map, navigable_mask=None):
+        """memory_2.py:1313-1344: black unknown, white known + navigable, grey known, red frontier cells, green target
+        disc (radius 5, drawn like cv2.circle(img, (ty, tx), 5, ..., -1))."""
+        known = (self.engine.frontier_mask() & 1).astype(bool)
+        if navigable_mask is None:
+            navigable_mask = self.build_navigable_mask()
+        img = np.zeros((self.gs, self.gs, 3), np.uint8)
+        img[known] = (100, 100, 100)
+        img[known & np.asarray(navigable_mask, bool)] = (255, 255, 255)
+        for fx, fy in frontiers:
+            img[fx, fy] = (255, 0, 0)
+        if target_center_map is not None:
+            tx, ty = int(round(target_center_map[0])), int(round(target_center_map[1]))
+            if 0 <= tx < self.gs and 0 <= ty < self.gs:
+                xx, yy = np.ogrid[0:self.gs, 0:self.gs]
+                img[(xx - tx) ** 2 + (yy - ty) ** 2 <= 25] = (0, 255, 0)
+        self.FrontierMap = img
+
+    def explore_entire_space(self, max_iterations=30):
+        """memory_2.py:1347-1391: sweep, find frontiers, cluster, go to the most informative cluster, repeat."""
+        self.min_cluster_size, self.ig_radius = 10, 5
+        self.initial_memory()
+        obs = self.Env.sims.get_sensor_observations(0)
+        for _ in range(max_iterations):
+            obs = self.excute(obs, ["turn_left"] * int(360 / self.cfg.turn_left))
+            navigable_mask = self.build_navigable_mask()
+            frontiers = self.find_frontiers(navigable_mask)
+            if not frontiers:
+                break
+            clusters = self.cluster_frontiers(frontiers)
+            if not clusters:
+                break
+            target = self.select_best_cluster_center_by_ig(clusters)
+            if target is None:
+                break
+            self.update_frontier_map(frontiers, clusters, target, navigable_mask)
+            subgoal = self.Env.get_random_navigable_point_near(self.grid2loc_2d(target[0], target[1]))
+            path, goal = self.Env.move2point(subgoal)
+            obs = self.excute(obs, path)
+
     # ---- BASELINE.json vocabulary (north_star names the entry points Memory.update_* / Memory.localize) -------------
     def update_from_observation(self, obs, pose):
         """Alias of obs2voxeltoken (memory_2.py:842)."""

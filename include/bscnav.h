@@ -146,6 +146,26 @@ bsc_status bsc_cluster_centers(bsc_ctx *ctx, int32_t query_index, int32_t K, con
                                const float *sim_host, double eps, int32_t min_samples, double *centers_host,
                                int32_t *labels_host, int32_t *sizes_host, int32_t *n_clusters_host);
 
+/* FrontierExplorer helpers (memory_2.py:1147-1311) on the resident top-down colour map (cv_map, kept by bsc_ingest).
+ *   bsc_frontier_mask     is_unknown / is_known / build_navigable_mask / find_frontiers (:1165-1207):
+ *                         mask_host[x*gs+y] bit0 = known (cv_map[x,y].sum() != 0), bit1 = frontier cell (known, navigable,
+ *                         an in-bounds 4-neighbour unknown).  navigable_host (gs,gs) u8 comes from the simulator's
+ *                         pathfinder (NULL = every cell navigable); the reference's navigable_mask works as well.
+ *   bsc_frontier_clusters cluster_frontiers + compute_cluster_center + compute_information_gain +
+ *                         select_best_cluster_center_by_ig (:1209-1311): 4-connected clusters of the frontier cells
+ *                         (frontier_host (gs,gs) nonzero = frontier; NULL = the cells found by the last bsc_frontier_mask)
+ *                         with >= min_cluster_size cells, in the reference's order (by first cell, row-major);
+ *                         centers_host (n,2) f64 mean cell; gains_host (n) = unknown cells in the clipped (2r+1)^2 window
+ *                         around the centre rounded half-to-even; *best_host = first cluster with the largest gain > 0
+ *                         (-1: none); labels_host (gs,gs) cluster ordinal or -1 (optional); first_host (n,2) first cell.
+ *                         *n_clusters_host = clusters found; at most max_clusters rows are written.
+ *   bsc_import_cv_map     set the colour map (gs,gs,3) u8, e.g. a saved exploration state (heights restart). */
+bsc_status bsc_frontier_mask(bsc_ctx *ctx, const uint8_t *navigable_host, uint8_t *mask_host);
+bsc_status bsc_frontier_clusters(bsc_ctx *ctx, const uint8_t *frontier_host, int32_t min_cluster_size, int32_t ig_radius,
+                                 int32_t max_clusters, int32_t *n_clusters_host, int32_t *labels_host, int32_t *first_host,
+                                 int32_t *sizes_host, double *centers_host, double *gains_host, int32_t *best_host);
+bsc_status bsc_import_cv_map(bsc_ctx *ctx, const uint8_t *cv_map_host);
+
 /* multi-GPU merge helpers (dense modes).  The library never calls RCCL: the host
  * moves the buffers with torch.distributed and hands them back.
  *   bsc_dense_gather : rows of the local map for the given voxel keys -> acc_dev (n,D), cnt_dev (n);

@@ -622,3 +622,81 @@ int32_t orc_cluster_centers(const int32_t *pos, const double *sim, int32_t K, do
     free(nb); free(core); free(stack); free(avg); free(ctr); free(sz);
     return label_num;
 }
+
+/* ---- FrontierExplorer helpers (memory_2.py:1165-1311) -------------------------------------------------------- */
+static int cell_unknown(const uint8_t *cv, int32_t gs, int32_t x, int32_t y)
+{
+    const uint8_t *p = cv + 3 * ((int64_t)x * gs + y);
+    return (int)p[0] + (int)p[1] + (int)p[2] == 0;            /* :1165 cv_map[x, y].sum() == 0 */
+}
+
+void orc_frontier_mask(const uint8_t *cv_map, const uint8_t *navigable, int32_t gs, uint8_t *mask)
+{
+    static const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};   /* :1191 */
+    for (int32_t x = 0; x < gs; ++x)
+        for (int32_t y = 0; y < gs; ++y) {
+            const int64_t i = (int64_t)x * gs + y;
+            const int known = !cell_unknown(cv_map, gs, x, y);
+            uint8_t m = known ? 1 : 0;
+            if (known && (!navigable || navigable[i])) {
+                for (int d = 0; d < 4; ++d) {
+                    const int32_t nx = x + dx[d], ny = y + dy[d];
+                    if (nx >= 0 && nx < gs && ny >= 0 && ny < gs && cell_unknown(cv_map, gs, nx, ny)) { m |= 2; break; }
+                }
+            }
+            mask[i] = m;
+        }
+}
+
+int32_t orc_frontier_clusters(const uint8_t *cv_map, const uint8_t *frontier, int32_t gs, int32_t min_cluster_size,
+                              int32_t ig_radius, int32_t max_clusters, int32_t *labels, int32_t *first, int32_t *sizes,
+                              double *centers, double *gains, int32_t *best)
+{
+    static const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+    const int64_t n = (int64_t)gs * gs;
+    uint8_t *visited = (uint8_t *)calloc((size_t)n, 1);
+    int64_t *queue = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    int32_t kept = 0;
+    double best_ig = 0.0;
+    *best = -1;
+    for (int64_t i = 0; i < n; ++i) labels[i] = -1;
+    for (int64_t f = 0; f < n; ++f) {                         /* :1222 frontiers are listed row-major */
+        if (!frontier[f] || visited[f]) continue;
+        int64_t qh = 0, qt = 0, sx = 0, sy = 0;
+        queue[qt++] = f;
+        visited[f] = 1;
+        while (qh < qt) {                                     /* :1230-1238 breadth-first, 4-neighbourhood */
+            const int64_t c = queue[qh++];
+            const int32_t cx = (int32_t)(c / gs), cy = (int32_t)(c % gs);
+            sx += cx; sy += cy;
+            for (int d = 0; d < 4; ++d) {
+                const int32_t nx = cx + dx[d], ny = cy + dy[d];
+                if (nx < 0 || nx >= gs || ny < 0 || ny >= gs) continue;
+                const int64_t ni = (int64_t)nx * gs + ny;
+                if (frontier[ni] && !visited[ni]) { visited[ni] = 1; queue[qt++] = ni; }
+            }
+        }
+        if (qt < min_cluster_size) continue;                  /* :1245 */
+        const double cx = (double)sx / (double)qt, cy = (double)sy / (double)qt;   /* :1256-1257 */
+        const int32_t rx = (int32_t)rint(cx), ry = (int32_t)rint(cy);             /* :1265 Python round: half to even */
+        int32_t unknown = 0;
+        for (int32_t ddx = -ig_radius; ddx <= ig_radius; ++ddx)
+            for (int32_t ddy = -ig_radius; ddy <= ig_radius; ++ddy) {
+                const int32_t nx = rx + ddx, ny = ry + ddy;
+                if (nx < 0 || nx >= gs || ny < 0 || ny >= gs) continue;
+                if (cell_unknown(cv_map, gs, nx, ny)) ++unknown;
+            }
+        if (kept < max_clusters) {
+            for (int64_t k = 0; k < qt; ++k) labels[queue[k]] = kept;
+            first[2 * kept] = (int32_t)(f / gs); first[2 * kept + 1] = (int32_t)(f % gs);
+            sizes[kept] = (int32_t)qt;
+            centers[2 * kept] = cx; centers[2 * kept + 1] = cy;
+            gains[kept] = (double)unknown;
+            if ((double)unknown > best_ig) { best_ig = (double)unknown; *best = kept; }   /* :1301 strict */
+        }
+        ++kept;
+    }
+    free(visited);
+    free(queue);
+    return kept;
+}

@@ -101,6 +101,20 @@ int32_t orc_localize(const orc_mem *m, const float *q, int32_t K, double radius,
 int32_t orc_cluster_centers(const int32_t *pos, const double *sim, int32_t K, double eps, int32_t min_samples,
                             double *centers, int32_t *labels, int32_t *sizes);
 
+/* FrontierExplorer helpers (memory_2.py:1165-1207): mask[x*gs+y] bit0 = known (cv_map[x,y].sum() != 0, :1165),
+ * bit1 = frontier: known, navigable[x,y] != 0 (NULL: every cell) and at least one in-bounds 4-neighbour unknown. */
+void orc_frontier_mask(const uint8_t *cv_map /*(gs,gs,3)*/, const uint8_t *navigable /*(gs,gs) or NULL*/, int32_t gs,
+                       uint8_t *mask /*(gs,gs)*/);
+/* cluster_frontiers + compute_cluster_center + compute_information_gain + select_best_cluster_center_by_ig
+ * (memory_2.py:1209-1311): 4-connected clusters of the cells with frontier[x*gs+y] != 0, grown breadth-first from
+ * the cells in row-major order, clusters smaller than min_cluster_size dropped; centre = mean cell; gain = unknown
+ * cells of cv_map inside the in-bounds part of the (2r+1)^2 window around the centre rounded half-to-even (Python
+ * round); best = first cluster with the strictly largest gain > 0 (-1: none).  labels (gs,gs): cluster ordinal or -1;
+ * first (n,2): the cluster's first cell; returns the number of clusters kept (at most max_clusters are written). */
+int32_t orc_frontier_clusters(const uint8_t *cv_map, const uint8_t *frontier, int32_t gs, int32_t min_cluster_size,
+                              int32_t ig_radius, int32_t max_clusters, int32_t *labels, int32_t *first, int32_t *sizes,
+                              double *centers /*(n,2)*/, double *gains, int32_t *best);
+
 /* name-order key of "grid_r_c_h" (bytewise string order) */
 uint64_t orc_name_key(int32_t r, int32_t c, int32_t h);
 

@@ -65,6 +65,10 @@ def lib():
         L.orc_geometry.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_void_p] * 9
         L.orc_cluster_centers.restype = C.c_int32
         L.orc_cluster_centers.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_frontier_mask.restype = None
+        L.orc_frontier_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.orc_frontier_clusters.restype = C.c_int32
+        L.orc_frontier_clusters.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
         L.orc_name_key.restype = C.c_uint64
         L.orc_name_key.argtypes = [C.c_int32] * 3
         _lib = L
@@ -269,3 +273,28 @@ def cluster_centers(pos, sim, eps=10.0, min_samples=5):
     centers, labels, sizes = np.zeros((K, 3)), np.zeros(K, np.int32), np.zeros(K, np.int32)
     n = lib().orc_cluster_centers(_p(pos), _p(sim), K, float(eps), int(min_samples), _p(centers), _p(labels), _p(sizes))
     return centers[:n], labels, sizes[:n]
+
+
+def frontier_mask(cv_map, navigable=None):
+    """memory_2.py:1165-1207 -> (gs,gs) u8: bit0 known, bit1 frontier."""
+    cv = np.ascontiguousarray(cv_map, np.uint8)
+    gs = cv.shape[0]
+    nav = None if navigable is None else np.ascontiguousarray(navigable).astype(np.uint8)
+    mask = np.zeros((gs, gs), np.uint8)
+    lib().orc_frontier_mask(_p(cv), _p(nav), gs, _p(mask))
+    return mask
+
+
+def frontier_clusters(cv_map, frontier, min_cluster_size=10, ig_radius=5, max_clusters=None):
+    """memory_2.py:1209-1311 -> dict(labels, first, sizes, centers, gains, best)."""
+    cv = np.ascontiguousarray(cv_map, np.uint8)
+    gs = cv.shape[0]
+    fr = np.ascontiguousarray(frontier).astype(np.uint8)
+    cap = int(max_clusters or gs * gs)
+    labels = np.zeros((gs, gs), np.int32)
+    first, sizes = np.zeros((cap, 2), np.int32), np.zeros(cap, np.int32)
+    centers, gains, best = np.zeros((cap, 2)), np.zeros(cap), np.zeros(1, np.int32)
+    n = lib().orc_frontier_clusters(_p(cv), _p(fr), gs, int(min_cluster_size), int(ig_radius), cap, _p(labels), _p(first),
+                                    _p(sizes), _p(centers), _p(gains), _p(best))
+    m = min(n, cap)
+    return dict(n=n, labels=labels, first=first[:m], sizes=sizes[:m], centers=centers[:m], gains=gains[:m], best=int(best[0]))

@@ -3,9 +3,10 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import bsc_nav_amd as B
 from bsc_nav_amd import synthetic
-H, W, g, D, gs, F = 480, 640, 14, 768, 256, 128
+H, W, g, D, gs = 480, 640, 14, 768, 256
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 sync = (sys.argv[2] != "nosync") if len(sys.argv) > 2 else True
+F = int(sys.argv[3]) if len(sys.argv) > 3 else 384
 poses = synthetic.random_walk_poses(1000, calls * F)
 chain = B.PoseChain()
 Ts = np.stack([chain.pc_transform(p) for p in poses])

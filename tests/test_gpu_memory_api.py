@@ -205,3 +205,57 @@ def test_long_memory_matches_reference(tmp_path):
     assert [classes.index(o["label"]) for o in lm] == [int(v) for v in z["label"]]
     assert np.array_equal(np.array([o["loc"] for o in lm]), z["loc"])
     np.testing.assert_allclose([o["confidence"] for o in lm], z["confidence"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("case", ["f1", "f2", "f3", "f4", "f5", "f6", "f7"])
+def test_frontier_helpers_match_reference(tmp_path, case):
+    """FrontierExplorer helpers (memory_2.py:1147-1311) on the device-resident top-down map vs the reference's goldens:
+    through the C-ABI (engine) and through the drop-in class's own method names."""
+    import bsc_nav_amd as B
+    z = gu.load("g7_frontier")
+    cv, nav = z[f"{case}_cv_map"], z[f"{case}_nav"]
+    gs, min_size, radius = (int(v) for v in z[f"{case}_params"])
+    args = B.MemoryArgs(width=64, height=48, grid_size=gs, cell_size=0.1, floor_height=-1.0, map_height=2.0,
+                        query_width=224, query_height=224, memory_path=str(tmp_path), scene_name="scene", token_dim=16)
+    origin = np.array([1.5, 0.25, -2.0])
+
+    def is_navigable(loc):
+        col = int(round((loc[0] - origin[0]) / 0.1)) + gs // 2
+        row = int(round((loc[2] - origin[2]) / 0.1)) + gs // 2
+        return bool(nav[row, col])
+    env = types.SimpleNamespace(original_state=types.SimpleNamespace(position=origin),
+                                plnner=types.SimpleNamespace(pathfinder=types.SimpleNamespace(is_navigable=is_navigable)))
+    mem = B.VoxelTokenMemory(args, preload_dino=None, need_diffusion=False, env=env, feature_mode="mean")
+    mem.engine.import_cv_map(cv)
+    mem.min_cluster_size, mem.ig_radius = min_size, radius
+    # ---- C-ABI
+    mask = mem.engine.frontier_mask(nav)
+    assert np.array_equal(np.argwhere(mask & 2), z[f"{case}_frontiers"])
+    assert np.array_equal((mask & 1).astype(bool), cv.sum(-1) != 0)
+    r = mem.engine.frontier_clusters(None, min_size, radius, max_clusters=gs * gs)
+    assert r["n"] == len(z[f"{case}_sizes"])
+    assert np.array_equal(r["labels"], z[f"{case}_labels"])
+    assert np.array_equal(r["sizes"], z[f"{case}_sizes"]) and np.array_equal(r["first"], z[f"{case}_first"])
+    assert np.array_equal(r["centers"], z[f"{case}_centers"]) and np.array_equal(r["gains"], z[f"{case}_gains"])
+    want = z[f"{case}_best"]
+    assert (r["best"] == -1) if np.isnan(want[0]) else np.array_equal(r["centers"][r["best"]], want)
+    small = mem.engine.frontier_clusters(None, min_size, radius, max_clusters=2, labels=False)      # truncated output
+    assert small["n"] == r["n"] and np.array_equal(small["sizes"], r["sizes"][:2])
+    # ---- the reference's method names
+    navigable_mask = mem.build_navigable_mask()
+    assert np.array_equal(navigable_mask, z[f"{case}_navigable_mask"])
+    frontiers = mem.find_frontiers(navigable_mask)
+    assert frontiers == [tuple(int(v) for v in f) for f in z[f"{case}_frontiers"]]
+    clusters = mem.cluster_frontiers(frontiers)
+    assert [len(c) for c in clusters] == z[f"{case}_sizes"].tolist()
+    assert [min(c) for c in clusters] == [tuple(int(v) for v in f) for f in z[f"{case}_first"]]
+    for k, c in enumerate(clusters):
+        assert mem.compute_cluster_center(c) == tuple(z[f"{case}_centers"][k])
+        assert mem.compute_information_gain(*mem.compute_cluster_center(c)) == z[f"{case}_gains"][k]
+    best = mem.select_best_cluster_center_by_ig(clusters)
+    assert (best is None) if np.isnan(want[0]) else best == tuple(want)
+    assert np.array_equal(np.stack([mem.grid2loc_2d(3, 7), mem.grid2loc_2d(gs - 1, 0)]), z[f"{case}_loc"])
+    assert [list(mem.loc2grid_2d(0.37, -1.21)), list(mem.loc2grid_2d(-2.05, 0.0))] == z[f"{case}_l2g"].tolist()
+    mem.update_frontier_map(frontiers, clusters, best, navigable_mask)
+    assert mem.FrontierMap.shape == (gs, gs, 3) and (mem.FrontierMap[cv.sum(-1) == 0].sum() == 0 or best is not None)
+    mem.engine.close()

@@ -163,3 +163,25 @@ def test_cluster_centers_match_reference(case):
     assert np.array_equal(sizes, z[f"{case}_sizes"])
     assert centers.shape == z[f"{case}_centers"].shape
     np.testing.assert_allclose(centers, z[f"{case}_centers"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("case", ["f1", "f2", "f3", "f4", "f5", "f6", "f7"])
+def test_frontier_helpers_match_reference(case):
+    """FrontierExplorer helpers (memory_2.py:1165-1311): frontier cells, clusters, centres, gains, selected target."""
+    z = gu.load("g7_frontier")
+    cv, nav = z[f"{case}_cv_map"], z[f"{case}_nav"]
+    gs, min_size, radius = (int(v) for v in z[f"{case}_params"])
+    mask = orc.frontier_mask(cv, nav)
+    assert np.array_equal((mask & 1).astype(bool) & nav, z[f"{case}_navigable_mask"])       # build_navigable_mask
+    assert np.array_equal(np.argwhere(mask & 2), z[f"{case}_frontiers"])                    # find_frontiers, row-major
+    assert np.array_equal(orc.frontier_mask(cv, z[f"{case}_navigable_mask"]), mask)         # either mask form
+    r = orc.frontier_clusters(cv, mask & 2, min_size, radius)
+    assert r["n"] == len(z[f"{case}_sizes"])
+    assert np.array_equal(r["labels"], z[f"{case}_labels"])
+    assert np.array_equal(r["sizes"], z[f"{case}_sizes"]) and np.array_equal(r["first"], z[f"{case}_first"])
+    assert np.array_equal(r["centers"], z[f"{case}_centers"]) and np.array_equal(r["gains"], z[f"{case}_gains"])
+    want = z[f"{case}_best"]
+    if np.isnan(want[0]):
+        assert r["best"] == -1
+    else:
+        assert np.array_equal(r["centers"][r["best"]], want)
