@@ -58,54 +58,48 @@ __global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int 
         x0 = (r % tx_n) * 32;
         jbase = f * (int64_t)H * W;
     }
-    for (int l = tid; l < PT_TILE; l += TPB) {
+    // all loads of the thread's four points are issued before the first dependent use (clamped addresses, no branches)
+    int32_t cell[PT_TILE / TPB];
+    uint32_t patf[PT_TILE / TPB];
+    bool in[PT_TILE / TPB];
+#pragma unroll
+    for (int r = 0; r < PT_TILE / TPB; ++r) {
+        const int l = tid + r * TPB;
         int64_t j;
         if (tiled2d) {
             const int y = y0 + (l >> 5), x = x0 + (l & 31);
-            if (x >= W || y >= H) continue;
+            in[r] = x < W && y < H;
             j = jbase + (int64_t)y * W + x;
         } else {
             j = jbase + l;
-            if (j >= P) continue;
+            in[r] = j < P;
         }
-        const int32_t c = p_cell[j];
-        uint32_t key = 0xffffffffu;
+        if (!in[r]) j = jbase;
+        cell[r] = p_cell[j];
+        patf[r] = p_patf[j];
+    }
+    int32_t vid[PT_TILE / TPB];
+#pragma unroll
+    for (int r = 0; r < PT_TILE / TPB; ++r) vid[r] = occ[cell[r] > 0 ? cell[r] : 0];
+    const int lane = tid & 63;
+#pragma unroll
+    for (int r = 0; r < PT_TILE / TPB; ++r) {
         u64 code = ~0ull;
-        if (c >= 0) {
-            const int32_t vid = occ[c];
-            if (vid >= 0) {
-                key = (uint32_t)vid;
-                if (PAIRS) {
-                    const uint32_t pf = p_patf[j];      // frame << 16 | patch  ->  voxel << cb | frame << pb | patch
-                    code = ((u64)(uint32_t)vid << cb) | ((u64)(pf >> 16) << pb) | (u64)(pf & 0xffffu);
-                }
-            }
-        }
+        if (in[r] && cell[r] >= 0 && vid[r] >= 0)         // frame << 16 | patch  ->  voxel << cb | frame << pb | patch
+            code = ((u64)(uint32_t)vid[r] << cb) | ((u64)(patf[r] >> 16) << pb) | (u64)(patf[r] & 0xffffu);
         if (PAIRS) {
-            // wave-level pre-aggregation: neighbouring pixels share (voxel, frame, patch), so one lane per
-            // distinct code inserts with the group's population instead of 64 conflicting LDS atomics
-            u64 todo = __ballot(code != ~0ull);
-            int rounds = 0;
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const u64 lcode = __shfl(code, leader);
-                const u64 same = __ballot(code == lcode);
-                if ((threadIdx.x & 63) == leader) {
-                    uint32_t h = (uint32_t)mix64(lcode) & (PT_HS - 1);
-                    for (;;) {
-                        const u64 old = atomicCAS(&hkey[h], ~0ull, lcode);
-                        if (old == ~0ull || old == lcode) { atomicAdd(&hcnt[h], (uint32_t)__popcll(same)); break; }
-                        h = (h + 1) & (PT_HS - 1);
-                    }
-                }
-                todo &= ~same;
-                if (++rounds == 8) break;
-            }
-            if (todo & (1ull << (threadIdx.x & 63))) {      // scattered remainder (iid-like input): per-lane insert
+            // neighbouring pixels share (voxel, frame, patch): only the first lane of every stretch of equal codes
+            // inserts, with the stretch's length, instead of 64 conflicting LDS atomics
+            const u64 prev = __shfl_up(code, 1);
+            const bool edge = lane == 0 || code != prev;
+            const u64 em = __ballot(edge);
+            const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
+            const int end = above ? (__ffsll((long long)above) - 1) : 64;
+            if (edge && code != ~0ull) {
                 uint32_t h = (uint32_t)mix64(code) & (PT_HS - 1);
                 for (;;) {
                     const u64 old = atomicCAS(&hkey[h], ~0ull, code);
-                    if (old == ~0ull || old == code) { atomicAdd(&hcnt[h], 1u); break; }
+                    if (old == ~0ull || old == code) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
                     h = (h + 1) & (PT_HS - 1);
                 }
             }

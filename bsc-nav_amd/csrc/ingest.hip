@@ -103,15 +103,37 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
 // ~P/1024 block totals gives every block its base; k_assign recomputes the flags and ranks its points inside the
 // block in order j with wave ballots.  Same ranks as a scan over all P points, at a third of the traffic.
 #define FB 1024
-__device__ __forceinline__ int point_flags(int64_t j, int64_t P, const int32_t *__restrict__ p_cell,
-                                           const int32_t *__restrict__ occ, int32_t &cell)
+// flags of the block's FB points, FB / TPB per thread; every load is issued before its first dependent use
+// (clamped addresses instead of branches): bit0 passes, bit1 first toucher of its voxel, bit2 first point of a run
+// (any cell, -1 included)
+__device__ __forceinline__ void block_flags(int64_t blk, int64_t P, const int32_t *__restrict__ p_cell,
+                                            const int32_t *__restrict__ occ, int (&f)[FB / TPB], int32_t (&cell)[FB / TPB])
 {
-    cell = -1;
-    if (j >= P) return 0;
-    cell = p_cell[j];
-    const int head = (j == 0 || p_cell[j - 1] != cell) ? 4 : 0;     // bit2 first point of a run (any cell, -1 included)
-    if (cell < 0) return head;
-    return head | ((occ[cell] == INT_MIN + (int32_t)j) ? 3 : 1);    // bit0 passes, bit1 first toucher of its voxel
+    int32_t prev[FB / TPB];
+    bool in[FB / TPB];
+#pragma unroll
+    for (int r = 0; r < FB / TPB; ++r) {
+        const int64_t j = blk * FB + r * TPB + threadIdx.x;
+        in[r] = j < P;
+        const int64_t jc = in[r] ? j : P - 1;
+        cell[r] = p_cell[jc];
+        prev[r] = p_cell[jc > 0 ? jc - 1 : 0];
+    }
+    int32_t o[FB / TPB];
+#pragma unroll
+    for (int r = 0; r < FB / TPB; ++r) o[r] = occ[cell[r] > 0 ? cell[r] : 0];
+#pragma unroll
+    for (int r = 0; r < FB / TPB; ++r) {
+        const int64_t j = blk * FB + r * TPB + threadIdx.x;
+        int v = 0;
+        if (in[r]) {
+            if (j == 0 || prev[r] != cell[r]) v = 4;
+            if (cell[r] >= 0) v |= (o[r] == INT_MIN + (int32_t)j) ? 3 : 1;
+        } else {
+            cell[r] = -1;
+        }
+        f[r] = v;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
@@ -121,13 +143,15 @@ __global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restr
     __shared__ int s_pass, s_first, s_head;
     if (threadIdx.x == 0) { s_pass = 0; s_first = 0; s_head = 0; }
     __syncthreads();
+    int f[FB / TPB];
+    int32_t c[FB / TPB];
+    block_flags(blockIdx.x, P, p_cell, occ, f, c);
     int np = 0, nf = 0, nh = 0;
+#pragma unroll
     for (int r = 0; r < FB / TPB; ++r) {
-        int32_t c;
-        const int f = point_flags((int64_t)blockIdx.x * FB + r * TPB + threadIdx.x, P, p_cell, occ, c);
-        np += f & 1;
-        nf += (f >> 1) & 1;
-        nh += f >> 2;
+        np += f[r] & 1;
+        nf += (f[r] >> 1) & 1;
+        nh += f[r] >> 2;
     }
     for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o); nf += __shfl_xor(nf, o); nh += __shfl_xor(nh, o); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_pass, np); atomicAdd(&s_first, nf); atomicAdd(&s_head, nh); }
@@ -143,35 +167,44 @@ __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__rest
                                                 int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list,
                                                 const int32_t *__restrict__ blk_run_off, int32_t *__restrict__ run_j0)
 {
-    __shared__ int w_pass[TPB / 64], w_first[TPB / 64], w_head[TPB / 64];
+    // ranks follow the order j: round, then wave, then lane
+    __shared__ int w_pass[FB / TPB][TPB / 64], w_first[FB / TPB][TPB / 64], w_head[FB / TPB][TPB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t base = blk_off[blockIdx.x];
     int64_t pass_base = base & 0xffffffffll, first_base = base >> 32;
     int32_t head_base = blk_run_off[blockIdx.x];
     const int64_t max_id = dscal[DS_MAX_ID];
-    for (int r = 0; r < FB / TPB; ++r) {            // rounds keep the order j: round, then wave, then lane
+    int f[FB / TPB];
+    int32_t c[FB / TPB];
+    // occ is read here while other blocks overwrite claimed cells with ids: a claim INT_MIN + j can only be replaced by
+    // the id of that same point j, so the flags of every other point are unaffected
+    block_flags(blockIdx.x, P, p_cell, occ, f, c);
+    u64 mp[FB / TPB], mf[FB / TPB], mh[FB / TPB];
+#pragma unroll
+    for (int r = 0; r < FB / TPB; ++r) {
+        mp[r] = __ballot(f[r] & 1); mf[r] = __ballot(f[r] & 2); mh[r] = __ballot(f[r] & 4);
+        if (lane == 0) { w_pass[r][wid] = __popcll(mp[r]); w_first[r][wid] = __popcll(mf[r]); w_head[r][wid] = __popcll(mh[r]); }
+    }
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < FB / TPB; ++r) {
         const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        int32_t c;
-        const int f = point_flags(j, P, p_cell, occ, c);
-        const u64 mp = __ballot(f & 1), mf = __ballot(f & 2), mh = __ballot(f & 4);
-        if (lane == 0) { w_pass[wid] = __popcll(mp); w_first[wid] = __popcll(mf); w_head[wid] = __popcll(mh); }
-        __syncthreads();
         int bp = 0, bf = 0, bh = 0, tp = 0, tf = 0, th = 0;
         for (int w = 0; w < TPB / 64; ++w) {
-            if (w < wid) { bp += w_pass[w]; bf += w_first[w]; bh += w_head[w]; }
-            tp += w_pass[w]; tf += w_first[w]; th += w_head[w];
+            if (w < wid) { bp += w_pass[r][w]; bf += w_first[r][w]; bh += w_head[r][w]; }
+            tp += w_pass[r][w]; tf += w_first[r][w]; th += w_head[r][w];
         }
-        const u64 lt = (1ull << lane) - 1ull;
-        if (f & 4) run_j0[head_base + bh + __popcll(mh & lt)] = (int32_t)j;     // runs in order j
-        if (f & 1) {
-            if (pass_list) pass_list[pass_base + bp + __popcll(mp & lt)] = (int32_t)j;
-            if (f & 2) {
-                const int64_t id = max_id + first_base + bf + __popcll(mf & lt);
+        if (f[r] & 4) run_j0[head_base + bh + __popcll(mh[r] & lt)] = (int32_t)j;     // runs in order j
+        if (f[r] & 1) {
+            if (pass_list) pass_list[pass_base + bp + __popcll(mp[r] & lt)] = (int32_t)j;
+            if (f[r] & 2) {
+                const int64_t id = max_id + first_base + bf + __popcll(mf[r] & lt);
                 if (id >= vcap) {
                     dscal[DS_ERROR] = 1;        // capacity: the cell keeps its provisional (negative) value
                 } else {
-                    occ[c] = (int32_t)id;           // memory_2.py:890
-                    const int32_t h = c % nh, rc = c / nh;
+                    occ[c[r]] = (int32_t)id;        // memory_2.py:890
+                    const int32_t h = c[r] % nh, rc = c[r] / nh;
                     rgb_pos[3 * id + 0] = rc / gs;  // memory_2.py:893
                     rgb_pos[3 * id + 1] = rc % gs;
                     rgb_pos[3 * id + 2] = h;
@@ -181,7 +214,6 @@ __global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__rest
         pass_base += tp;
         first_base += tf;
         head_base += th;
-        __syncthreads();
     }
 }
 
