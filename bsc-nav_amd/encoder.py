@@ -10,6 +10,7 @@ trunc_normal(0.02) weights.  Its dense GEMMs run on MFMA through PyTorch-ROCm (h
 outputs are returned in fp32 for the voxel kernels.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -36,11 +37,21 @@ class _Block(nn.Module):
         self.fc1 = nn.Linear(width, mlp)
         self.fc2 = nn.Linear(mlp, width)
 
-    def attn(self, y):
-        B, T, C = y.shape
-        qkv = self.qkv(y).reshape(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+    def attn(self, y, fused=False):
+        B, T, Wd = y.shape
+        hd = Wd // self.heads
+        if fused and hd == 64 and T <= 288 and y.dtype == torch.bfloat16 and y.is_cuda:
+            # (B,T,3,heads,64) straight out of the qkv GEMM -> bsc_enc_attention (K, V of a head resident in LDS)
+            from . import _lib
+            qkv = self.qkv(y)
+            a = torch.empty((B, T, Wd), dtype=torch.bfloat16, device=y.device)
+            _lib.check(_lib.load().bsc_enc_attention(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
+                                                     C.c_void_p(a.data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return self.proj(a)
+        qkv = self.qkv(y).reshape(B, T, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-        return self.proj(a.transpose(1, 2).reshape(B, T, C))
+        return self.proj(a.transpose(1, 2).reshape(B, T, Wd))
 
     def mlp(self, y, fuse_gelu):
         if fuse_gelu:       # bias + GELU(tanh) in the GEMM epilogue (hipBLASLt)
@@ -54,6 +65,7 @@ class RandomViT(nn.Module):
     def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16, fused=True):
         super().__init__()
         self.fused = fused
+        self.fused_attention = fused and os.environ.get("BSC_ENC_ATTENTION", "1") == "1"   # 0: library SDPA
         s = VIT_SHAPES[arch]
         self.arch, self.image_size, self.patch = arch, image_size, s["patch"]
         self.grid = image_size // s["patch"]
@@ -110,7 +122,7 @@ class RandomViT(nn.Module):
         t = t.contiguous()
         t, y = self._add_ln(t, None, self.blocks[0].ln1, fuse)
         for i, blk in enumerate(self.blocks):
-            t, y = self._add_ln(t, blk.attn(y), blk.ln2, fuse)
+            t, y = self._add_ln(t, blk.attn(y, fuse and self.fused_attention), blk.ln2, fuse)
             nxt = self.blocks[i + 1].ln1 if i + 1 < len(self.blocks) else self.norm
             t, y = self._add_ln(t, blk.mlp(y, fuse), nxt, fuse)
         t = y[:, 1 + self.registers:]

@@ -182,6 +182,12 @@ bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id)
 bsc_status bsc_enc_add_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev, const void *beta_dev,
                                  void *xout_dev, void *y_dev, int64_t rows, int32_t width, float eps, void *hip_stream);
 
+/* Encoder helper: softmax(Q K^T / sqrt(d)) V for the short sequences of the ViT provider, one workgroup per (image, head)
+ * with K and V of the head resident in LDS.  qkv_dev (B,T,3,heads,head_dim) bf16 as the fused qkv GEMM writes it,
+ * out_dev (B,T,heads*head_dim) bf16.  head_dim == 64, T <= 288 (ViT-B/16: 197, ViT-L/14 + 4 registers: 261). */
+bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim, void *out_dev,
+                             void *hip_stream);
+
 /* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
  * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM
  * (memory_2.py:733-736 and transform_, :71-74, fused into one pass). */

@@ -8,6 +8,8 @@ _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.getpid()}_.csv")
 shutil.copy(_src, _dst[:-4] + "0.csv")
 os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=_dst, PYTORCH_TUNABLEOP_VERBOSE="0")
 import torch
+if os.environ.get("BSC_FA"):
+    print("fa library ->", os.environ["BSC_FA"], torch.backends.cuda.preferred_rocm_fa_library(os.environ["BSC_FA"]))
 from bsc_nav_amd import encoder
 arch = sys.argv[1] if len(sys.argv) > 1 else "vit_b16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128

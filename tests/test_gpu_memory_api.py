@@ -259,3 +259,23 @@ def test_frontier_helpers_match_reference(tmp_path, case):
     mem.update_frontier_map(frontiers, clusters, best, navigable_mask)
     assert mem.FrontierMap.shape == (gs, gs, 3) and (mem.FrontierMap[cv.sum(-1) == 0].sum() == 0 or best is not None)
     mem.engine.close()
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 197, 12), (2, 261, 16), (1, 16, 2), (2, 33, 3), (1, 224, 1)])
+def test_fused_attention_matches_fp32_softmax(B, T, H):
+    """bsc_enc_attention (K, V resident in LDS, MFMA bf16, f32 softmax) against softmax(QK^T/8)V evaluated in fp32 on the
+    same bf16 inputs: output error bounded by the bf16 rounding of P and of the result."""
+    import ctypes as C
+    import torch
+    from bsc_nav_amd import _lib
+    torch.manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B, T, 3, H, 64, device="cuda") * 1.5).bfloat16()
+    out = torch.empty(B, T, H * 64, dtype=torch.bfloat16, device="cuda")
+    _lib.check(_lib.load().bsc_enc_attention(C.c_void_p(qkv.data_ptr()), B, T, H, 64, C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    err = (out.float() - ref).abs()
+    assert torch.isfinite(out.float()).all()
+    assert err.max().item() < 0.03 and err.mean().item() < 0.003, (err.max().item(), err.mean().item())
