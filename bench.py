@@ -48,7 +48,8 @@ def pmc_traffic():
     coalesced reads at half (MI355X_MICROARCH.md, HBM).  None when the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_ingest_kernels.json")) as f:
-            k = json.load(f)["kernels"]["void k_dense_reduce<3, 1>"]
+            ks = json.load(f)["kernels"]
+        k = next(v for name, v in ks.items() if name.startswith("void k_dense_reduce<"))
         return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
     except Exception:
         return None
