@@ -58,6 +58,8 @@ SIGNATURES = {
     "bsc_dense_replace": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "bsc_kernel_stats": (_I32, [_VP, _I32, _I32, _VP]),
+    "bsc_enc_embed_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "bsc_enc_final_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_attention": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP]),
     "bsc_enc_preprocess_patches": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
     "bsc_enc_add_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, C.c_float, _VP]),

@@ -107,6 +107,173 @@ extern "C" bsc_status bsc_enc_add_layernorm(const void *x, const void *delta, co
     return BSC_OK;
 }
 
+// ---- the two ends of the transformer stack, fused the same way ---------------------------------------------------------
+// wave-level LayerNorm statistics of a row held as NG x 4 values per lane
+template <int NG>
+__device__ __forceinline__ void ln_stats(const float (&v)[NG][4], int width, float eps, float &mean, float &rstd)
+{
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) sum += (v[g][0] + v[g][1]) + (v[g][2] + v[g][3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    mean = sum / (float)width;
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = v[g][k] - mean;
+            var += d * d;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    rstd = rsqrtf(var / (float)width + eps);
+}
+
+// token assembly + first LayerNorm: row 0 = cls + pos[0]; rows 1..R = register tokens; the others = patch embedding +
+// pos (bf16 sums, as `cat([cls, x]) + pos` and the register insertion produce them); writes the residual stream and
+// LayerNorm(row)
+template <int NG>
+__global__ __launch_bounds__(TPB) void k_embed_layernorm(const ushort4 *__restrict__ patch, const ushort4 *__restrict__ cls,
+                                                         const ushort4 *__restrict__ reg, const ushort4 *__restrict__ pos,
+                                                         const ushort4 *__restrict__ gamma, const ushort4 *__restrict__ beta,
+                                                         ushort4 *__restrict__ xout, ushort4 *__restrict__ y, int64_t rows,
+                                                         int T, int R, int width, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const int w4 = width >> 2;
+    const int64_t b = row / T;
+    const int r = (int)(row - b * T);
+    const int np = T - 1 - R;                               // patch tokens per image
+    float v[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        ushort4 a;
+        if (r >= 1 && r <= R) {
+            a = reg[(int64_t)(r - 1) * w4 + c];
+        } else {
+            const ushort4 s0 = r == 0 ? cls[c] : patch[(b * np + (r - 1 - R)) * w4 + c];
+            const ushort4 pp = pos[(int64_t)(r == 0 ? 0 : r - R) * w4 + c];
+            a.x = f2bf(bf2f(s0.x) + bf2f(pp.x)); a.y = f2bf(bf2f(s0.y) + bf2f(pp.y));
+            a.z = f2bf(bf2f(s0.z) + bf2f(pp.z)); a.w = f2bf(bf2f(s0.w) + bf2f(pp.w));
+        }
+        xout[row * w4 + c] = a;
+        v[g][0] = bf2f(a.x); v[g][1] = bf2f(a.y); v[g][2] = bf2f(a.z); v[g][3] = bf2f(a.w);
+    }
+    float mean, rstd;
+    ln_stats<NG>(v, width, eps, mean, rstd);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        const ushort4 ga = gamma[c], be = beta[c];
+        ushort4 o;
+        o.x = f2bf((v[g][0] - mean) * rstd * bf2f(ga.x) + bf2f(be.x));
+        o.y = f2bf((v[g][1] - mean) * rstd * bf2f(ga.y) + bf2f(be.y));
+        o.z = f2bf((v[g][2] - mean) * rstd * bf2f(ga.z) + bf2f(be.z));
+        o.w = f2bf((v[g][3] - mean) * rstd * bf2f(ga.w) + bf2f(be.w));
+        y[row * w4 + c] = o;
+    }
+}
+
+// last residual add + final LayerNorm, patch rows only, straight into the (B, g*g, width) token tensor the memory ingests:
+// f32 (the bf16-rounded value widened, what `.float()` of the bf16 result gives) or bf16
+template <int NG, bool F32OUT>
+__global__ __launch_bounds__(TPB) void k_final_layernorm(const ushort4 *__restrict__ x, const ushort4 *__restrict__ delta,
+                                                         const ushort4 *__restrict__ gamma, const ushort4 *__restrict__ beta,
+                                                         void *__restrict__ out, int64_t rows_out, int T, int skip, int width,
+                                                         float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t orow = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (orow >= rows_out) return;
+    const int w4 = width >> 2;
+    const int np = T - skip;
+    const int64_t b = orow / np;
+    const int64_t row = b * T + skip + (orow - b * np);
+    float v[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        const ushort4 a = x[row * w4 + c], d = delta[row * w4 + c];
+        v[g][0] = bf2f(f2bf(bf2f(a.x) + bf2f(d.x))); v[g][1] = bf2f(f2bf(bf2f(a.y) + bf2f(d.y)));
+        v[g][2] = bf2f(f2bf(bf2f(a.z) + bf2f(d.z))); v[g][3] = bf2f(f2bf(bf2f(a.w) + bf2f(d.w)));
+    }
+    float mean, rstd;
+    ln_stats<NG>(v, width, eps, mean, rstd);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        const ushort4 ga = gamma[c], be = beta[c];
+        ushort4 o;
+        o.x = f2bf((v[g][0] - mean) * rstd * bf2f(ga.x) + bf2f(be.x));
+        o.y = f2bf((v[g][1] - mean) * rstd * bf2f(ga.y) + bf2f(be.y));
+        o.z = f2bf((v[g][2] - mean) * rstd * bf2f(ga.z) + bf2f(be.z));
+        o.w = f2bf((v[g][3] - mean) * rstd * bf2f(ga.w) + bf2f(be.w));
+        if (F32OUT) ((float4 *)out)[orow * w4 + c] = make_float4(bf2f(o.x), bf2f(o.y), bf2f(o.z), bf2f(o.w));
+        else ((ushort4 *)out)[orow * w4 + c] = o;
+    }
+}
+
+#define ENC_NG_SWITCH(ng, CALL)                                                                          \
+    switch (ng) {                                                                                        \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;  \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; default: CALL(8); break; \
+    }
+
+extern "C" bsc_status bsc_enc_embed_layernorm(const void *patch_dev, const void *cls_dev, const void *reg_dev,
+                                              const void *pos_dev, const void *gamma_dev, const void *beta_dev,
+                                              void *xout_dev, void *y_dev, int32_t B, int32_t T, int32_t registers,
+                                              int32_t width, float eps, void *hip_stream)
+{
+    if (!patch_dev || !cls_dev || !pos_dev || !gamma_dev || !beta_dev || !xout_dev || !y_dev || B < 1 || registers < 0 ||
+        T < 2 + registers || (registers > 0 && !reg_dev) || width % 256 != 0 || width < 256 || width > 2048) {
+        bsc_set_error("bsc_enc_embed_layernorm: invalid argument");
+        return BSC_E_INVALID;
+    }
+    const int64_t rows = (int64_t)B * T;
+    const dim3 grid((unsigned)((rows * 64 + TPB - 1) / TPB)), block(TPB);
+#define EL(NG) hipLaunchKernelGGL((k_embed_layernorm<NG>), grid, block, 0, (hipStream_t)hip_stream, (const ushort4 *)patch_dev, \
+                                  (const ushort4 *)cls_dev, (const ushort4 *)reg_dev, (const ushort4 *)pos_dev,              \
+                                  (const ushort4 *)gamma_dev, (const ushort4 *)beta_dev, (ushort4 *)xout_dev,                \
+                                  (ushort4 *)y_dev, rows, T, registers, width, eps)
+    ENC_NG_SWITCH(width / 256, EL)
+#undef EL
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev,
+                                              const void *beta_dev, void *out_dev, int32_t out_f32, int32_t B, int32_t T,
+                                              int32_t skip, int32_t width, float eps, void *hip_stream)
+{
+    if (!x_dev || !delta_dev || !gamma_dev || !beta_dev || !out_dev || B < 1 || skip < 0 || T <= skip || width % 256 != 0 ||
+        width < 256 || width > 2048) {
+        bsc_set_error("bsc_enc_final_layernorm: invalid argument");
+        return BSC_E_INVALID;
+    }
+    const int64_t rows = (int64_t)B * (T - skip);
+    const dim3 grid((unsigned)((rows * 64 + TPB - 1) / TPB)), block(TPB);
+#define FL(NG)                                                                                                                  \
+    do {                                                                                                                        \
+        if (out_f32)                                                                                                            \
+            hipLaunchKernelGGL((k_final_layernorm<NG, true>), grid, block, 0, (hipStream_t)hip_stream, (const ushort4 *)x_dev,  \
+                               (const ushort4 *)delta_dev, (const ushort4 *)gamma_dev, (const ushort4 *)beta_dev, out_dev, rows, \
+                               T, skip, width, eps);                                                                            \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_final_layernorm<NG, false>), grid, block, 0, (hipStream_t)hip_stream, (const ushort4 *)x_dev, \
+                               (const ushort4 *)delta_dev, (const ushort4 *)gamma_dev, (const ushort4 *)beta_dev, out_dev, rows, \
+                               T, skip, width, eps);                                                                            \
+    } while (0)
+    ENC_NG_SWITCH(width / 256, FL)
+#undef FL
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Frame pre-processing of the patch-feature provider (memory_2.py:733-736 + transform_ :71-74) in one pass:
 //   u8 (B,H,W,C) -> /255 -> antialiased bilinear resize to (S,S) -> ImageNet normalise -> bf16 patch matrix
@@ -150,15 +317,32 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__res
     aa_taps(x, (float)W / (float)S, W, xlo, xn, wx);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const uint8_t *img = rgb + (int64_t)b * H * W * C;
-    for (int i = 0; i < yn; ++i) {
-        const uint8_t *row = img + ((int64_t)(ylo + i) * W + xlo) * C;
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        for (int k = 0; k < xn; ++k) {
-            r0 += wx[k] * (float)row[k * C + 0];
-            r1 += wx[k] * (float)row[k * C + 1];
-            r2 += wx[k] * (float)row[k * C + 2];
+    if (C == 4) {           // RGBA frames: one 32-bit load per tap, all taps of a row in flight together
+        for (int i = 0; i < yn; ++i) {
+            const uint32_t *row = (const uint32_t *)(img + ((int64_t)(ylo + i) * W + xlo) * 4);
+            uint32_t pxl[PP_TAPS];
+#pragma unroll
+            for (int k = 0; k < PP_TAPS; ++k) pxl[k] = row[k < xn ? k : 0];
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PP_TAPS; ++k) {             // weights beyond xn are zero
+                r0 += wx[k] * (float)(pxl[k] & 0xffu);
+                r1 += wx[k] * (float)((pxl[k] >> 8) & 0xffu);
+                r2 += wx[k] * (float)((pxl[k] >> 16) & 0xffu);
+            }
+            a0 += wy[i] * r0; a1 += wy[i] * r1; a2 += wy[i] * r2;
         }
-        a0 += wy[i] * r0; a1 += wy[i] * r1; a2 += wy[i] * r2;
+    } else {
+        for (int i = 0; i < yn; ++i) {
+            const uint8_t *row = img + ((int64_t)(ylo + i) * W + xlo) * C;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            for (int k = 0; k < xn; ++k) {
+                r0 += wx[k] * (float)row[k * C + 0];
+                r1 += wx[k] * (float)row[k * C + 1];
+                r2 += wx[k] * (float)row[k * C + 2];
+            }
+            a0 += wy[i] * r0; a1 += wy[i] * r1; a2 += wy[i] * r2;
+        }
     }
     const int g = S / p, gy = y / p, gx = x / p, py = y - gy * p, px = x - gx * p;
     uint16_t *dst = out + ((int64_t)b * g * g + (int64_t)gy * g + gx) * (3 * p * p) + py * p + px;

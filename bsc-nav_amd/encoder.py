@@ -114,16 +114,45 @@ class RandomViT(nn.Module):
         """(B, g*g, 3*p*p) unfolded, normalised patches -> {'x_norm_patchtokens': (B, g*g, D)} (f32 unless keep_dtype)."""
         B = t.shape[0]
         t = self.patch_embed(t)
-        t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
-        if self.reg is not None:
-            t = torch.cat([t[:, :1], self.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
-        # pre-LN transformer with every residual add fused into the LayerNorm that follows it
         fuse = self.fused and t.is_cuda and t.dtype == torch.bfloat16 and self.width % 256 == 0
-        t = t.contiguous()
-        t, y = self._add_ln(t, None, self.blocks[0].ln1, fuse)
+        T = 1 + self.registers + self.grid * self.grid
+        if fuse:
+            # token assembly (cls, registers, + pos) and the first LayerNorm in one pass
+            from . import _lib
+            lib = _lib.load()
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            ln0 = self.blocks[0].ln1
+            x = torch.empty((B, T, self.width), dtype=torch.bfloat16, device=t.device)
+            y = torch.empty_like(x)
+            t = t.contiguous()
+            _lib.check(lib.bsc_enc_embed_layernorm(
+                C.c_void_p(t.data_ptr()), C.c_void_p(self.cls.data_ptr()),
+                None if self.reg is None else C.c_void_p(self.reg.data_ptr()), C.c_void_p(self.pos.data_ptr()),
+                C.c_void_p(ln0.weight.data_ptr()), C.c_void_p(ln0.bias.data_ptr()), C.c_void_p(x.data_ptr()),
+                C.c_void_p(y.data_ptr()), B, T, self.registers, self.width, float(ln0.eps), stream))
+            t = x
+        else:
+            t = torch.cat([self.cls.expand(B, -1, -1), t], dim=1) + self.pos
+            if self.reg is not None:
+                t = torch.cat([t[:, :1], self.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
+            t = t.contiguous()
+            t, y = self._add_ln(t, None, self.blocks[0].ln1, fuse)
+        # pre-LN transformer with every residual add fused into the LayerNorm that follows it
+        last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
             t, y = self._add_ln(t, blk.attn(y, fuse and self.fused_attention), blk.ln2, fuse)
-            nxt = self.blocks[i + 1].ln1 if i + 1 < len(self.blocks) else self.norm
+            if i == last and fuse and self.head is None:
+                # last residual add + final LayerNorm of the patch rows, written as the token tensor itself
+                delta = blk.mlp(y, fuse).contiguous()
+                skip = 1 + self.registers
+                out = torch.empty((B, T - skip, self.width), dtype=torch.bfloat16 if keep_dtype else torch.float32,
+                                  device=t.device)
+                _lib.check(lib.bsc_enc_final_layernorm(
+                    C.c_void_p(t.data_ptr()), C.c_void_p(delta.data_ptr()), C.c_void_p(self.norm.weight.data_ptr()),
+                    C.c_void_p(self.norm.bias.data_ptr()), C.c_void_p(out.data_ptr()), 0 if keep_dtype else 1, B, T, skip,
+                    self.width, float(self.norm.eps), stream))
+                return {"x_norm_patchtokens": out}
+            nxt = self.blocks[i + 1].ln1 if i < last else self.norm
             t, y = self._add_ln(t, blk.mlp(y, fuse), nxt, fuse)
         t = y[:, 1 + self.registers:]
         if self.head is not None:

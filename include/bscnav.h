@@ -182,6 +182,20 @@ bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id)
 bsc_status bsc_enc_add_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev, const void *beta_dev,
                                  void *xout_dev, void *y_dev, int64_t rows, int32_t width, float eps, void *hip_stream);
 
+/* Encoder helpers for the two ends of the transformer stack (bf16, width % 256 == 0, <= 2048):
+ *   bsc_enc_embed_layernorm  token assembly + first LayerNorm: row 0 = cls + pos[0], rows 1..registers = register tokens,
+ *                            the others = patch embedding (B, T-1-registers, width) + pos[1..] -> xout (B,T,width) and
+ *                            y = LayerNorm(xout)   (replaces cat / add / LayerNorm passes)
+ *   bsc_enc_final_layernorm  last residual add + final LayerNorm of the patch rows only (the first `skip` rows of every
+ *                            image are dropped), written as the (B, T-skip, width) token tensor bsc_ingest reads:
+ *                            f32 (out_f32 != 0: the bf16 result widened) or bf16 */
+bsc_status bsc_enc_embed_layernorm(const void *patch_dev, const void *cls_dev, const void *reg_dev, const void *pos_dev,
+                                   const void *gamma_dev, const void *beta_dev, void *xout_dev, void *y_dev, int32_t B,
+                                   int32_t T, int32_t registers, int32_t width, float eps, void *hip_stream);
+bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *delta_dev, const void *gamma_dev, const void *beta_dev,
+                                   void *out_dev, int32_t out_f32, int32_t B, int32_t T, int32_t skip, int32_t width,
+                                   float eps, void *hip_stream);
+
 /* Encoder helper: softmax(Q K^T / sqrt(d)) V for the short sequences of the ViT provider, one workgroup per (image, head)
  * with K and V of the head resident in LDS.  qkv_dev (B,T,3,heads,head_dim) bf16 as the fused qkv GEMM writes it,
  * out_dev (B,T,heads*head_dim) bf16.  head_dim == 64, T <= 288 (ViT-B/16: 197, ViT-L/14 + 4 registers: 261). */
