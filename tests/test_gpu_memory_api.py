@@ -279,3 +279,25 @@ def test_fused_attention_matches_fp32_softmax(B, T, H):
     err = (out.float() - ref).abs()
     assert torch.isfinite(out.float()).all()
     assert err.max().item() < 0.03 and err.mean().item() < 0.003, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("arch", ["vit_b16", "vit_l14"])
+def test_fused_encoder_ends_match_pytorch(arch):
+    """bsc_enc_embed_layernorm / bsc_enc_final_layernorm (registers, cls, pos, f32 and bf16 token outputs) against the
+    same ViT evaluated with plain PyTorch ops."""
+    import torch
+    from bsc_nav_amd import encoder
+    torch.manual_seed(1)
+    vit = encoder.RandomViT(arch, seed=5).cuda()
+    for prm in (vit.cls, vit.pos) + ((vit.reg,) if vit.reg is not None else ()):
+        prm.data = (0.5 * torch.randn_like(prm.float())).to(prm.dtype)
+    rgb = torch.randint(0, 255, (2, 60, 80, 4), dtype=torch.uint8, device="cuda")
+    vit.fused = True
+    a32 = vit.patch_tokens(rgb)
+    a16 = vit.patch_tokens(rgb, keep_dtype=True)
+    vit.fused = False
+    b = vit.patch_tokens(rgb)
+    g = vit.grid
+    assert a32.shape == (2, g, g, vit.width) and a32.dtype == torch.float32 and a16.dtype == torch.bfloat16
+    assert torch.equal(a16.float(), a32)                      # the f32 output is the bf16 result widened
+    assert (a32 - b).abs().max().item() < 0.2 and (a32 - b).abs().mean().item() < 0.012
