@@ -4,6 +4,7 @@
 //     s = x + delta (bf16) ; y = LayerNorm(s) * gamma + beta            one wavefront per token row
 // Stateless entry point, launched on the caller's stream (captured into the encoder's HIP graph).
 #include "bsc_internal.h"
+#include <stdlib.h>
 
 #define TPB 256
 
@@ -372,9 +373,9 @@ extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B,
 }
 
 // ---- self-attention of the ViT patch-feature provider: short sequences (T = 197 / 261), head dim 64 -------------------
-// One workgroup per (image, head).  K and V of the head live in LDS for the whole workgroup (K row-major, V transposed
+// One (image, head) item at a time per workgroup.  Q, K and V of the head live in LDS (Q, K row-major, V transposed
 // so that the P.V operand is a contiguous 8-byte read); every wavefront takes strips of 16 queries:
-//   S^T = K . Q^T     A = 16 keys x 32 features from LDS, B = 16 queries x 32 features straight from HBM
+//   S^T = K . Q^T     A = 16 keys x 32 features, B = 16 queries x 32 features, both from LDS
 //                     -> accumulator tile t holds S^T[key 16t + 4g + i][query lane & 15]  (g = lane >> 4)
 //   softmax           along the keys: a lane owns 4 keys of every tile for ONE query, the other keys of that query sit
 //                     in the lanes 16, 32, 48 apart (two xor-shuffles); exp2 with log2(e)/sqrt(d) folded in
@@ -394,9 +395,40 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)      // v_cvt_
     return *(const uint32_t *)&r;
 }
 
+// The staging registers of the next item are first-class vector values (not arrays: an array that is live across the
+// item loop is left in memory by the compiler, and the loads would be waited for on the spot).
+template <int N> struct u32vec { typedef uint32_t type __attribute__((ext_vector_type(N))); };
+
+// every global load of an (image, head) item is issued together (clamped addresses, no branches)
+template <int NLD, int NTHR>
+__device__ __forceinline__ void att_issue_loads(typename u32vec<4 * NLD>::type &k8, typename u32vec<4 * NLD>::type &v8,
+                                                typename u32vec<4 * NLD>::type &q8, const uint16_t *__restrict__ qkv,
+                                                int item, int T, int H, int tid)
+{
+    const int64_t tok_stride = (int64_t)3 * H * 64;
+    const int b = item / H, h = item % H;
+    const uint16_t *Qp = qkv + (int64_t)b * T * tok_stride + (int64_t)h * 64;
+    const uint16_t *Kp = Qp + (int64_t)H * 64, *Vp = Qp + (int64_t)2 * H * 64;
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int idx = tid + NTHR * r;
+        const int t = idx >> 3, ch = idx & 7;
+        const int tc = t < T ? t : T - 1;
+        const uint4 k = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + ch * 8);
+        const uint4 v = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + ch * 8);
+        const uint4 q = *(const uint4 *)(Qp + (int64_t)tc * tok_stride + ch * 8);
+        k8[4 * r] = k.x; k8[4 * r + 1] = k.y; k8[4 * r + 2] = k.z; k8[4 * r + 3] = k.w;
+        v8[4 * r] = v.x; v8[4 * r + 1] = v.y; v8[4 * r + 2] = v.z; v8[4 * r + 3] = v.w;
+        q8[4 * r] = q.x; q8[4 * r + 1] = q.y; q8[4 * r + 2] = q.z; q8[4 * r + 3] = q.w;
+    }
+}
+
 // NT key tiles of 16 (even): sequence length <= 16 * NT.  NW wavefronts, each takes the query strips w, w + NW, ...
+// Persistent workgroups: a workgroup walks the (image, head) items i, i + gridDim, ... and issues the global loads of
+// its NEXT item (K, V and its wavefronts' query strips, into registers) before it computes the current one out of LDS,
+// so the HBM-bound load phase and the issue-bound compute phase overlap instead of alternating chip-wide.
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restrict__ qkv, int T, int H,
+__global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restrict__ qkv, int T, int H, int items,
                                                        uint16_t *__restrict__ out)
 {
     constexpr int NTHR = 64 * NW;
@@ -406,137 +438,137 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
     constexpr int NLD = (TP * 8 + NTHR - 1) / NTHR;         // 16-byte pieces of K (and of V) per thread
     constexpr int NSTRIP = (NT + NW - 1) / NW;              // strips of 16 queries per wavefront
     __shared__ __attribute__((aligned(16))) uint16_t sK[TP * KP];
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[TP * KP];
     __shared__ __attribute__((aligned(16))) uint16_t sVt[64 * VP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int64_t tok_stride = (int64_t)3 * H * 64;                 // elements between consecutive tokens
-    const uint16_t *base = qkv + (int64_t)b * T * tok_stride + (int64_t)h * 64;
-    const uint16_t *Qp = base, *Kp = base + (int64_t)H * 64, *Vp = base + (int64_t)2 * H * 64;
-    // every global load of the workgroup is issued up front (clamped addresses, no branches): K, V and the wavefront's
-    // query strips are all in flight together
-    uint4 k8[NLD], v8[NLD];
-#pragma unroll
-    for (int r = 0; r < NLD; ++r) {
-        const int idx = tid + NTHR * r;
-        const int t = idx >> 3, ch = idx & 7;
-        const int tc = t < T ? t : T - 1;
-        k8[r] = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + ch * 8);
-        v8[r] = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + ch * 8);
-    }
-    uint4 q8[NSTRIP][2];
-#pragma unroll
-    for (int si = 0; si < NSTRIP; ++si) {
-        const int tq = (wave + NW * si) * 16 + n;
-        const int tc = tq < T ? tq : T - 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) q8[si][kk] = *(const uint4 *)(Qp + (int64_t)tc * tok_stride + kk * 32 + g * 8);
-    }
-#pragma unroll
-    for (int r = 0; r < NLD; ++r) {
-        const int idx = tid + NTHR * r;
-        const int t = idx >> 3, ch = idx & 7;
-        if (idx < TP * 8) {
-            const bool in = t < T;
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-            *(uint4 *)&sK[t * KP + ch * 8] = in ? k8[r] : z;
-            const uint4 v = in ? v8[r] : z;
-            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-            // V^T[d][t] lives at granule (t >> 2) ^ (d >> 3) of row d: the 8 rows a lane writes per element pair and
-            // the 8 lanes that share a token then fall into different banks
-            const int col = 4 * ((t >> 2) ^ ch) + (t & 3);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sVt[(ch * 8 + 2 * e) * VP + col] = (uint16_t)(vv[e] & 0xffffu);
-                sVt[(ch * 8 + 2 * e + 1) * VP + col] = (uint16_t)(vv[e] >> 16);
-            }
-        }
-    }
-    __syncthreads();
     const float c = 0.125f * 1.44269504088896340736f;               // 1/sqrt(64) * log2(e)
     const int nstrip = (T + 15) >> 4;
-    const int full_tiles = T >> 4;                                  // key tiles without padding
+    typename u32vec<4 * NLD>::type k8, v8, q8;
+
+    // software pipeline over the workgroup's items; the prefetch past the last item re-reads the last one (harmless)
+    int item = blockIdx.x;
+    att_issue_loads<NLD, NTHR>(k8, v8, q8, qkv, item < items ? item : items - 1, T, H, tid);
+    for (; item < items; item += gridDim.x) {
+        const int b = item / H, h = item % H;
+        __syncthreads();                                            // the previous item's strips are done with LDS
 #pragma unroll
-    for (int si = 0; si < NSTRIP; ++si) {
-        const int strip = wave + NW * si;
-        if (strip >= nstrip) break;
-        const int q0 = strip * 16;
-        bf16x8_t bq[2];
+        for (int r = 0; r < NLD; ++r) {
+            const int idx = tid + NTHR * r;
+            const int t = idx >> 3, ch = idx & 7;
+            if (idx < TP * 8) {
+                const bool in = t < T;
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 kr = make_uint4(k8[4 * r], k8[4 * r + 1], k8[4 * r + 2], k8[4 * r + 3]);
+                const uint4 vr = make_uint4(v8[4 * r], v8[4 * r + 1], v8[4 * r + 2], v8[4 * r + 3]);
+                *(uint4 *)&sK[t * KP + ch * 8] = in ? kr : z;
+                *(uint4 *)&sQ[t * KP + ch * 8] = make_uint4(q8[4 * r], q8[4 * r + 1], q8[4 * r + 2], q8[4 * r + 3]);
+                const uint4 v = in ? vr : z;
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                // V^T[d][t] lives at granule (t >> 2) ^ (d >> 3) of row d: the 8 rows a lane writes per element pair
+                // and the 8 lanes that share a token then fall into different banks
+                const int col = 4 * ((t >> 2) ^ ch) + (t & 3);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) bq[kk] = *(bf16x8_t *)&q8[si][kk];
-        f32x4_t acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8_t a = *(const bf16x8_t *)&sK[(t * 16 + n) * KP + kk * 32 + g * 8];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[kk], acc[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    sVt[(ch * 8 + 2 * e) * VP + col] = (uint16_t)(vv[e] & 0xffffu);
+                    sVt[(ch * 8 + 2 * e + 1) * VP + col] = (uint16_t)(vv[e] >> 16);
+                }
             }
         }
-        // padded keys (only the last one or two tiles have any) leave the softmax with -inf
+        __syncthreads();
+        {                                                           // in flight during the strips below
+            const int nxt = item + (int)gridDim.x;
+            att_issue_loads<NLD, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
+        }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t >= full_tiles) {
+        for (int si = 0; si < NSTRIP; ++si) {
+            const int strip = wave + NW * si;
+            if (strip >= nstrip) break;
+            const int q0 = strip * 16;
+            bf16x8_t bq[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (t * 16 + g * 4 + i >= T) acc[t][i] = -INFINITY;
+            for (int kk = 0; kk < 2; ++kk) bq[kk] = *(const bf16x8_t *)&sQ[(q0 + n) * KP + kk * 32 + g * 8];
+            f32x4_t acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8_t a = *(const bf16x8_t *)&sK[(t * 16 + n) * KP + kk * 32 + g * 8];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[kk], acc[t], 0, 0, 0);
+                }
             }
-        f32x4_t mv = acc[0];
+            // padded keys leave the softmax with -inf; for the usual lengths only the last two tiles have any
+            if (T > 16 * (NT - 2)) {
 #pragma unroll
-        for (int t = 1; t < NT; ++t) mv = __builtin_elementwise_max(mv, acc[t]);
-        float m = fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3]));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        const float mc = m * c;
-        f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+                for (int t = NT - 2; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4_t e = acc[t] * c - mc;                 // exp2((s - m) * c)
+                    for (int i = 0; i < 4; ++i)
+                        if (t * 16 + g * 4 + i >= T) acc[t][i] = -INFINITY;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
-            acc[t] = e;
-            sv += e;
-        }
-        float sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        f32x4_t o[4];
-        // (8 ks + g) ^ x == 8 ks + (g ^ x) for x < 8: the swizzle folds into two lane constants per d tile and the
-        // key step becomes an immediate offset
-        const uint16_t *v0p[4], *v1p[4];
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            const int d = dt * 16 + n;
-            v0p[dt] = &sVt[d * VP + 4 * (g ^ (d >> 3))];
-            v1p[dt] = &sVt[d * VP + 4 * ((4 + g) ^ (d >> 3))];
-        }
+                    for (int i = 0; i < 4; ++i)
+                        if (t * 16 + g * 4 + i >= T) acc[t][i] = -INFINITY;
+            }
+            f32x4_t mv = acc[0];
 #pragma unroll
-        for (int ks = 0; ks < NT / 2; ++ks) {
-            uint4 pa;
-            pa.x = pack_bf16(acc[2 * ks][0], acc[2 * ks][1]);
-            pa.y = pack_bf16(acc[2 * ks][2], acc[2 * ks][3]);
-            pa.z = pack_bf16(acc[2 * ks + 1][0], acc[2 * ks + 1][1]);
-            pa.w = pack_bf16(acc[2 * ks + 1][2], acc[2 * ks + 1][3]);
-            const bf16x8_t a = *(bf16x8_t *)&pa;
+            for (int t = 1; t < NT; ++t) mv = __builtin_elementwise_max(mv, acc[t]);
+            float m = fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3]));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const f32x4_t cv = {c, c, c, c}, nmc = {-m * c, -m * c, -m * c, -m * c};
+            f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4_t e = __builtin_elementwise_fma(acc[t], cv, nmc);     // exp2((s - m) * c), v_pk_fma_f32
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                acc[t] = e;
+                sv += e;
+            }
+            float sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            f32x4_t o[4];
+            // (8 ks + g) ^ x == 8 ks + (g ^ x) for x < 8: the swizzle folds into two lane constants per d tile and the
+            // key step becomes an immediate offset
+            const uint16_t *v0p[4], *v1p[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint2 v0 = *(const uint2 *)(v0p[dt] + 32 * ks), v1 = *(const uint2 *)(v1p[dt] + 32 * ks);
-                uint4 vb = make_uint4(v0.x, v0.y, v1.x, v1.y);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *(bf16x8_t *)&vb, o[dt], 0, 0, 0);
+                o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                const int d = dt * 16 + n;
+                v0p[dt] = &sVt[d * VP + 4 * (g ^ (d >> 3))];
+                v1p[dt] = &sVt[d * VP + 4 * ((4 + g) ^ (d >> 3))];
             }
-        }
-        // o[dt][i] = O[query q0 + 4g + i][d = 16 dt + n]; the row sums sit with the lanes whose n is that query
-        const float inv = 1.f / sum;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float r = __shfl(inv, g * 4 + i);
-            const int q = q0 + g * 4 + i;
-            if (q < T) {
-                uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + n;
+            for (int ks = 0; ks < NT / 2; ++ks) {
+                uint4 pa;
+                pa.x = pack_bf16(acc[2 * ks][0], acc[2 * ks][1]);
+                pa.y = pack_bf16(acc[2 * ks][2], acc[2 * ks][3]);
+                pa.z = pack_bf16(acc[2 * ks + 1][0], acc[2 * ks + 1][1]);
+                pa.w = pack_bf16(acc[2 * ks + 1][2], acc[2 * ks + 1][3]);
+                const bf16x8_t a = *(bf16x8_t *)&pa;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (uint16_t)(pack_bf16(o[dt][i] * r, 0.f) & 0xffffu);
+                for (int dt = 0; dt < 4; ++dt) {
+                    const uint2 v0 = *(const uint2 *)(v0p[dt] + 32 * ks), v1 = *(const uint2 *)(v1p[dt] + 32 * ks);
+                    uint4 vb = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *(bf16x8_t *)&vb, o[dt], 0, 0, 0);
+                }
+            }
+            // o[dt][i] = O[query q0 + 4g + i][d = 16 dt + n]; the row sums sit with the lanes whose n is that query
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = __shfl(inv, g * 4 + i);
+                const int q = q0 + g * 4 + i;
+                if (q < T) {
+                    uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + n;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (uint16_t)(pack_bf16(o[dt][i] * r, 0.f) & 0xffffu);
+                }
             }
         }
     }
@@ -551,11 +583,21 @@ extern "C" bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t 
         return BSC_E_INVALID;
     }
     hipStream_t s = (hipStream_t)hip_stream;
-    const dim3 grid((unsigned)((int64_t)B * heads));
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        BSC_HIP(hipGetDevice(&dev));
+        BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (getenv("BSC_ATT_WGS")) n_cu = atoi(getenv("BSC_ATT_WGS"));
+    }
+    const int64_t items = (int64_t)B * heads;
+    const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
     if (T <= 224)
-        hipLaunchKernelGGL((k_attention<14, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (uint16_t *)out_dev);
+        hipLaunchKernelGGL((k_attention<14, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
+                           (uint16_t *)out_dev);
     else
-        hipLaunchKernelGGL((k_attention<18, 9>), grid, dim3(64 * 9), 0, s, (const uint16_t *)qkv_dev, T, heads, (uint16_t *)out_dev);
+        hipLaunchKernelGGL((k_attention<18, 8>), grid, dim3(64 * 8), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
+                           (uint16_t *)out_dev);
     BSC_HIP(hipGetLastError());
     return BSC_OK;
 }
