@@ -4,7 +4,6 @@
 //     s = x + delta (bf16) ; y = LayerNorm(s) * gamma + beta            one wavefront per token row
 // Stateless entry point, launched on the caller's stream (captured into the encoder's HIP graph).
 #include "bsc_internal.h"
-#include <stdlib.h>
 
 #define TPB 256
 
@@ -352,6 +351,74 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__res
     dst[2 * p * p] = f2bf((a2 * (1.f / 255.f) - m2) / s2);
 }
 
+// RGBA frames, one workgroup per output patch.  The taps of every output row and column (first input index, count, 12
+// normalised weights) are tabulated once per call by k_pp_taps; the input window of the patch (p * scale + 2 * support
+// pixels each way) is staged in LDS with coalesced 32-bit loads, and every thread evaluates its output pixel from LDS:
+// eight input pixels fetched per output pixel instead of ~35 cached loads, no per-thread tap arithmetic, and the
+// patch's three channel planes leave as contiguous runs.  Same taps, weights and summation order as k_preprocess_patches.
+#define PPT_MAXW 64
+#define PPT_MAXH 48
+struct PpTap {
+    int lo, n;
+    float w[PP_TAPS];
+};
+
+__global__ void k_pp_taps(int S, int H, int W, PpTap *__restrict__ ty, PpTap *__restrict__ tx)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 2 * S) return;
+    const bool isx = o >= S;
+    const int i = isx ? o - S : o;
+    PpTap t;
+    aa_taps(i, isx ? (float)W / (float)S : (float)H / (float)S, isx ? W : H, t.lo, t.n, t.w);
+    (isx ? tx : ty)[i] = t;
+}
+
+template <int TXN>      // column taps evaluated per row (>= the largest tap count of any output column)
+__global__ __launch_bounds__(TPB) void k_preprocess_patches_tiled(const uint32_t *__restrict__ rgba, int B, int H, int W, int S,
+                                                                  int p, const PpTap *__restrict__ ty,
+                                                                  const PpTap *__restrict__ tx, uint16_t *__restrict__ out,
+                                                                  float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    __shared__ uint32_t tile[PPT_MAXH][PPT_MAXW + 1];
+    const int g = S / p;
+    const int patch = blockIdx.x % (g * g), b = blockIdx.x / (g * g);
+    const int gy = patch / g, gx = patch % g;
+    // window = union of the taps of the patch's first and last output row / column (taps are monotone in the output index)
+    const int y_lo = ty[gy * p].lo, x_lo = tx[gx * p].lo;
+    const int win_h = ty[gy * p + p - 1].lo + ty[gy * p + p - 1].n - y_lo;
+    const int win_w = tx[gx * p + p - 1].lo + tx[gx * p + p - 1].n - x_lo;
+    const uint32_t *img = rgba + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < win_h * win_w; i += TPB) {
+        const int r = i / win_w, c = i - r * win_w;
+        tile[r][c] = img[(int64_t)(y_lo + r) * W + x_lo + c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= p * p) return;
+    const int py = threadIdx.x / p, px = threadIdx.x - py * p;
+    const PpTap *wyp = &ty[gy * p + py];            // its weights are read in the row loop (dynamic index)
+    const PpTap wx = tx[gx * p + px];
+    const int yn = wyp->n, ylo = wyp->lo;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < yn; ++i) {
+        const uint32_t *row = &tile[ylo - y_lo + i][wx.lo - x_lo];
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < TXN; ++k) {                 // weights beyond n are zero
+            const uint32_t v = row[k < wx.n ? k : 0];
+            r0 += wx.w[k] * (float)(v & 0xffu);
+            r1 += wx.w[k] * (float)((v >> 8) & 0xffu);
+            r2 += wx.w[k] * (float)((v >> 16) & 0xffu);
+        }
+        const float wyi = wyp->w[i];
+        a0 += wyi * r0; a1 += wyi * r1; a2 += wyi * r2;
+    }
+    uint16_t *dst = out + ((int64_t)b * g * g + patch) * (3 * p * p) + py * p + px;
+    dst[0] = f2bf((a0 * (1.f / 255.f) - m0) / s0);
+    dst[p * p] = f2bf((a1 * (1.f / 255.f) - m1) / s1);
+    dst[2 * p * p] = f2bf((a2 * (1.f / 255.f) - m2) / s2);
+}
+
 extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C,
                                                  int32_t S, int32_t patch, void *out_dev, const float *mean3_host,
                                                  const float *std3_host, void *hip_stream)
@@ -363,6 +430,34 @@ extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B,
     if ((float)H / S > (PP_TAPS - 1) / 2.0f || (float)W / S > (PP_TAPS - 1) / 2.0f) {
         bsc_set_error("bsc_enc_preprocess_patches: down-scale factor above %g not supported", (PP_TAPS - 1) / 2.0);
         return BSC_E_INVALID;
+    }
+    const float fy = (float)H / S, fx = (float)W / S;
+    const float suph = fy >= 1.f ? fy : 1.f, supw = fx >= 1.f ? fx : 1.f;
+    if (C == 4 && patch * patch <= TPB && patch * fy + 2.f * suph + 3.f <= PPT_MAXH && patch * fx + 2.f * supw + 3.f <= PPT_MAXW) {
+        const int g = S / patch;
+        // per-device tap table (2 x S entries), rewritten by every call on the call's stream
+        static PpTap *tab[16] = {nullptr};
+        static int tab_S[16] = {0};
+        int dev = 0;
+        BSC_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16) return BSC_E_INVALID;
+        if (tab_S[dev] < S) {
+            if (tab[dev]) BSC_HIP(hipFree(tab[dev]));
+            BSC_HIP(hipMalloc((void **)&tab[dev], sizeof(PpTap) * 2 * S));
+            tab_S[dev] = S;
+        }
+        hipLaunchKernelGGL(k_pp_taps, dim3((unsigned)((2 * S + 127) / 128)), dim3(128), 0, (hipStream_t)hip_stream, S, H, W,
+                           tab[dev], tab[dev] + S);
+#define PPT_LAUNCH(TXN)                                                                                               \
+        hipLaunchKernelGGL((k_preprocess_patches_tiled<TXN>), dim3((unsigned)((int64_t)B * g * g)), dim3(TPB), 0,         \
+                           (hipStream_t)hip_stream, (const uint32_t *)rgb_dev, B, H, W, S, patch, tab[dev], tab[dev] + S, \
+                           (uint16_t *)out_dev, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],  \
+                           std3_host[2])
+        if (2.f * supw + 2.f <= 8.f) PPT_LAUNCH(8);     // a column has at most floor(2 * support) + 2 taps
+        else PPT_LAUNCH(PP_TAPS);
+#undef PPT_LAUNCH
+        BSC_HIP(hipGetLastError());
+        return BSC_OK;
     }
     const int64_t n = (int64_t)B * S * S;
     hipLaunchKernelGGL(k_preprocess_patches, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)hip_stream,
@@ -583,12 +678,11 @@ extern "C" bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t 
         return BSC_E_INVALID;
     }
     hipStream_t s = (hipStream_t)hip_stream;
-    static int n_cu = 0;
+    static int n_cu = 0;                // one workgroup per CU (its LDS footprint allows no second one)
     if (!n_cu) {
         int dev = 0;
         BSC_HIP(hipGetDevice(&dev));
         BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (getenv("BSC_ATT_WGS")) n_cu = atoi(getenv("BSC_ATT_WGS"));
     }
     const int64_t items = (int64_t)B * heads;
     const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
