@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
     ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
     ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurement")
+    ap.add_argument("--no-iid", action="store_true", help="skip the iid-depth (HBM-bound regime) measurement of k_dense_reduce")
     return ap.parse_args()
 
 
@@ -248,6 +249,37 @@ def main():
         out["stages"] = {"encoder_ms_per_step": enc_ms, "ingest_ms_per_step": ing_ms,
                          "encoder_tflops": vit.flops_per_frame() * a.batch / (enc_ms * 1e-3) / 1e12,
                          "voxels": c1["max_id"]}
+        if not a.no_iid:
+            # The same kernel in the regime the HBM roofline describes: "iid" depth (one voxel per point,
+            # U ~ P), where it is a pure accumulator read-modify-write stream instead of an L2-resident token re-read.
+            Fi, calls = 16, 4
+            engI = B.VoxelEngine(H, W, gs, cs, -half, half, g, D, mode=a.mode, voxel_capacity=min(gs ** 3, calls * Fi * N),
+                                 max_points=Fi * N, device=local_rank)
+            pi = synthetic.random_walk_poses(77, calls * Fi)
+            chain_i = B.PoseChain()
+            Ti = np.stack([chain_i.pc_transform(p) for p in pi])
+            toki = torch.randn((Fi, g, g, D), device="cuda")
+            fr = [synthetic.make_frames(900 + s, Fi, H, W, "iid", device="cuda", poses=pi[s * Fi:(s + 1) * Fi])
+                  for s in range(calls)]
+            engI.ingest(fr[0][1], fr[0][0], toki, Ti[:Fi])              # first call: every voxel is new (write-only rows)
+            torch.cuda.synchronize()
+            cj0 = engI.counters()
+            engI.kernel_stats(0, reset=True)
+            for s in range(1, calls):
+                engI.ingest(fr[s][1], fr[s][0], toki, Ti[s * Fi:(s + 1) * Fi])
+            torch.cuda.synchronize()
+            ksj, cj1 = engI.kernel_stats(0), engI.counters()
+            kk = calls - 1
+            Uj = (cj1["voxel_rmw"] - cj0["voxel_rmw"]) / kk
+            alg_j = (2 * Uj - (cj1["max_id"] - cj0["max_id"]) / kk) * D * 4 + 8 * Uj + Fi * g * g * D * 4 \
+                + 12 * (cj1["pairs"] - cj0["pairs"]) / kk
+            ms_j = ksj["ms"] / max(1, ksj["launches"])
+            out["roofline_iid"] = {"kernel": "k_dense_reduce", "note": f"iid depth, {Fi} frames per call, bsc_ingest alone",
+                                   "achieved": alg_j / (ms_j * 1e-3) / 1e9, "unit": "GB/s",
+                                   "frac": alg_j / (ms_j * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_j,
+                                   "bytes_per_launch": alg_j, "voxel_rows_per_launch": Uj}
+            engI.close()
+            del fr, toki
         if not a.no_localize:
             # second half of the metric: localize top-K latency over a 2^20-voxel x D map (BASELINE configs[3]/[4] size)
             V = 1 << 20

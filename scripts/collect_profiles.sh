@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- pytho
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc/$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc/$c -- python bench.py --no-cpu-baseline --no-localize > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc/$c -- python bench.py --no-cpu-baseline --no-localize --no-iid > /dev/null 2>&1
   f=$(find /tmp/pmc/$c -name "*counter_collection.csv" | head -1)
   mkdir -p /tmp/pmc_flat/$c && cp "$f" /tmp/pmc_flat/$c/pmc_counter_collection.csv
 done
