@@ -224,3 +224,58 @@ def test_bf16_tokens_equal_widened_f32_tokens(mode):
         eng.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def _dense_vs_oracle(H, W, g, D, gs, cs, lo, hi, F, per_call, seed, vcap, kind="room", depth_override=None):
+    """Dense mean mode, every pixel, host alpha: ids, positions, rgb bytes, weights, top-down map, counts bit-exact and
+    feature sums within 1e-3 against the sequential oracle."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    rgb, depth, poses = synth.make_frames(seed, F, H, W, kind)
+    if depth_override is not None:
+        depth = depth_override(depth)
+    tokens = synth.make_tokens(seed, F, g, D)
+    eng = B.VoxelEngine(H, W, gs, cs, lo, hi, g, D, mode="mean", voxel_capacity=vcap, max_points=per_call * H * W)
+    oc = orc.make_config(H, W, gs, cs, lo, hi, g, D, mode=1)
+    om = orc.OracleMemory(oc, voxel_capacity=vcap)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    alphas = []
+    for f in range(F):
+        gm = orc.geometry(oc, depth[f], None, Ts[f])
+        al = np.exp(-gm["r2"] / (2 * 0.6))
+        alphas.append(al)
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f], al)
+    d_depth, d_rgb, d_tok = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    for a in range(0, F, per_call):
+        eng.ingest(d_depth[a:a + per_call].contiguous(), d_rgb[a:a + per_call].contiguous(),
+                   d_tok[a:a + per_call].contiguous(), Ts[a:a + per_call], None, None,
+                   torch.from_numpy(np.concatenate(alphas[a:a + per_call])).cuda())
+    k, ok = eng.counters(), om.counters()
+    assert k["max_id"] == ok["max_id"]
+    for a, b in zip(eng.export_rgb(), om.export_rgb()):
+        assert np.array_equal(a, b)
+    for a, b in zip(eng.export_heightmap(), om.export_heightmap()):
+        assert np.array_equal(a, b)
+    (acc, cnt), (oacc, ocnt) = eng.export_dense(), om.export_dense()
+    assert np.array_equal(cnt, ocnt) and int(ocnt.astype(np.int64).sum()) == k["points_passed"]
+    # feature values = per-voxel means (the oracle adds the points one by one in f32, the device adds multiplicity x row)
+    c = np.maximum(cnt, 1)[:, None].astype(np.float64)
+    np.testing.assert_allclose(acc / c, oacc / c, rtol=1e-3, atol=1e-3)
+    eng.close()
+    return int(ocnt.max()), k["max_id"]
+
+
+def test_full_size_dense_against_oracle():
+    """BASELINE configs[1] frame and token size (640x480, 14x14x768, 256^3 grid), 6 frames in two calls, vs the oracle."""
+    longest, n_vox = _dense_vs_oracle(480, 640, 14, 768, 256, 0.1, -12.8, 12.8, F=6, per_call=3, seed=31, vcap=400_000)
+    assert n_vox > 5000
+
+
+def test_very_long_voxel_chains_against_oracle():
+    """1 m cells: single voxels collect > 10^5 points of a call, so the rgb chain walks thousands of 64-point chunks per
+    segment (prefetch pipeline, longest-first queue, segments far longer than the wavefront count) — bit-exact rgb."""
+    longest, n_vox = _dense_vs_oracle(480, 640, 14, 32, 32, 1.0, -16.0, 16.0, F=6, per_call=6, seed=9, vcap=40_000)
+    assert longest > 100_000 and n_vox < 2000
