@@ -312,16 +312,8 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
         if (s >= nseg) continue;
         const int64_t i0 = seg_start[s];
         const uint32_t vid = (uint32_t)(pkey[i0] >> cb);
-        // the accumulator row is fetched first so that its HBM latency hides behind the pair walk
         const bool is_new = (int64_t)vid >= max_id_prev;
         float4 *dst = (float4 *)(acc + (int64_t)vid * D);
-        float4 old[NV];
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            const int v = lane + 64 * t;
-            old[t] = (!is_new && v < D4) ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const int32_t old_cnt = (!is_new && lane == 0) ? acnt[vid] : 0;
         float4 a[NV];
 #pragma unroll
         for (int t = 0; t < NV; ++t)
@@ -398,6 +390,15 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
             const uint32_t rc[4] = {pend_cnt, 0u, 0u, 0u};
             apply_runs4<NV, MODE, TOK>(a, cc, rc, tokens, g2, D, D4, lane, pb);
         }
+        // one read-modify-write of the accumulator row (read here, not before the walk: 12 registers fewer per lane
+        // during the walk = one more resident wavefront per SIMD, and the other wavefronts cover this latency)
+        float4 old[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            old[t] = (!is_new && v < D4) ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int32_t old_cnt = (!is_new && lane == 0) ? acnt[vid] : 0;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int v = lane + 64 * t;
