@@ -5,9 +5,9 @@ through the shim package of that name at the repository root.
 """
 from . import _lib
 from .engine import VoxelEngine
-from .geometry import PoseChain, cam_mat_fov, cam_mat_patch, pose_vec2tf, sample_indices
+from .geometry import PoseChain, cam_mat_fov, cam_mat_patch, pose_vec2tf, sample_indices, sample_indices_fast
 from .config import MemoryArgs
 from .memory import Memory, VoxelTokenMemory
 from .dataset import create_memory_for_dataset
 
-__all__ = ["VoxelEngine", "VoxelTokenMemory", "Memory", "create_memory_for_dataset", "MemoryArgs", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "_lib"]
+__all__ = ["VoxelEngine", "VoxelTokenMemory", "Memory", "create_memory_for_dataset", "MemoryArgs", "PoseChain", "cam_mat_fov", "cam_mat_patch", "pose_vec2tf", "sample_indices", "sample_indices_fast", "_lib"]

@@ -66,7 +66,30 @@ class PoseChain:
 
 
 def sample_indices(n_pixels, rate):
-    """The reference's shuffled sub-sampling; consumes np.random's global stream identically."""
+    """The reference's shuffled sub-sampling (memory_2.py:747-749); consumes np.random's global stream identically."""
     idx = np.arange(n_pixels)
     np.random.shuffle(idx)
     return np.ascontiguousarray(idx[::rate].astype(np.int32))
+
+
+_scratch = {}
+
+
+def sample_indices_fast(n_pixels, rate):
+    """Same permutation, same final state of np.random's global MT19937 stream, from the library's own restatement of
+    NumPy's legacy shuffle (bsc_host_shuffled_sample: ~2.5x faster than np.random.shuffle at 640x480)."""
+    import ctypes as C
+    from . import _lib
+    st = np.random.get_state()
+    if st[0] != "MT19937":
+        return sample_indices(n_pixels, rate)
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    scratch = _scratch.get(n_pixels)
+    if scratch is None:
+        scratch = _scratch[n_pixels] = np.empty(n_pixels, np.int32)
+    out = np.empty((n_pixels + rate - 1) // rate, np.int32)
+    _lib.check(_lib.load().bsc_host_shuffled_sample(key.ctypes.data_as(C.c_void_p), C.byref(pos), n_pixels, int(rate),
+                                                    scratch.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    np.random.set_state((st[0], key, pos.value, st[3], st[4]))
+    return out

@@ -17,7 +17,7 @@ import torch
 from . import store
 from .config import from_namespace
 from .engine import VoxelEngine
-from .geometry import PoseChain, cam_mat_fov, sample_indices
+from .geometry import PoseChain, cam_mat_fov, sample_indices_fast as sample_indices
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)

@@ -176,6 +176,13 @@ bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, c
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
 bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
 
+/* Host helper (no device work): `idx = arange(n); np.random.shuffle(idx); idx[::rate]` of _backproject_depth
+ * (memory_2.py:747-749), bit for bit, on a copy of NumPy's global MT19937 state (np.random.get_state()[1:3] =
+ * key624 / pos, advanced in place so that np.random.set_state() leaves the stream where NumPy's own shuffle would).
+ * scratch_n: n int32 of workspace; out: ceil(n / rate) int32. */
+bsc_status bsc_host_shuffled_sample(uint32_t *key624, int32_t *pos, int64_t n, int32_t rate, int32_t *scratch_n,
+                                    int32_t *out);
+
 /* Encoder helper (stateless, bf16): s = x + delta ; y = LayerNorm(s)*gamma + beta, one pass over the (rows,width)
  * token matrix.  delta/xout may be NULL (plain LayerNorm).  Fuses the residual add and the LayerNorm that sit
  * between the library GEMMs of the ViT patch-feature provider (memory_2.py:738).  width % 256 == 0, <= 2048. */

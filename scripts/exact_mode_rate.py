@@ -12,7 +12,8 @@ F = 256
 poses = synthetic.random_walk_poses(3, F)
 rgb, depth, _ = synthetic.make_frames(3, F, H, W, "room", poses=poses)
 tokens = torch.randn(F, g, g, D, device="cuda")
-for s, batch in ((1000, 1), (1000, 32), (50, 32), (1, 8)):
+for sampler, s, batch in ((B.sample_indices, 1000, 32), (B.sample_indices_fast, 1000, 32), (B.sample_indices_fast, 1000, 1),
+                          (B.sample_indices_fast, 50, 32), (B.sample_indices_fast, 1, 8)):
     eng = B.VoxelEngine(H, W, gs, 0.1, -12.8, 12.8, g, D, mode="exact", voxel_capacity=2_000_000,
                         token_capacity=6_000_000, max_points=batch * H * W)
     chain = B.PoseChain()
@@ -23,7 +24,7 @@ for s, batch in ((1000, 1), (1000, 32), (50, 32), (1, 8)):
     t_host = 0.0
     for a in range(0, F, batch):
         th = time.perf_counter()
-        idxs = [B.sample_indices(H * W, s) for _ in range(batch)]
+        idxs = [sampler(H * W, s) for _ in range(batch)]
         off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
         idx = torch.from_numpy(np.concatenate(idxs)).cuda()
         t_host += time.perf_counter() - th
@@ -32,6 +33,6 @@ for s, batch in ((1000, 1), (1000, 32), (50, 32), (1, 8)):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     k = eng.counters()
-    print(f"s={s} batch={batch}: {F/dt:.1f} frames/s ({dt*1e3/F:.2f} ms/frame, host shuffle {t_host*1e3/F:.2f} ms/frame) "
+    print(f"{sampler.__name__} s={s} batch={batch}: {F/dt:.1f} frames/s ({dt*1e3/F:.2f} ms/frame, host shuffle {t_host*1e3/F:.2f} ms/frame) "
           f"voxels={k['max_id']} store_tokens={k['store_tokens']} flushes={k['flushes']}")
     eng.close()

@@ -57,3 +57,25 @@ def test_config_struct_layout_matches_header():
             m = re.search(r"([A-Za-z_][A-Za-z_0-9]*)\s*(\[\d+\])?\s*$", part.strip())
             names.append(m.group(1))
     assert names == [f[0] for f in bsc_nav_amd._lib.BscConfig._fields_]
+
+
+def test_host_shuffle_matches_numpy_bit_for_bit():
+    """bsc_host_shuffled_sample == `idx = arange(n); np.random.shuffle(idx); idx[::rate]` (memory_2.py:747-749): same
+    permutation and the same global MT19937 state afterwards (host code only, no GPU needed)."""
+    import numpy as np
+    from bsc_nav_amd import geometry as G
+    for seed in (0, 1, 20250928):
+        for n, rate in ((1, 1), (2, 1), (3, 2), (7, 3), (1000, 7), (76800, 1000), (307200, 1000), (65536, 1), (462400, 50)):
+            np.random.seed(seed)
+            a = G.sample_indices(n, rate)
+            sa = np.random.randint(0, 1 << 30, 4)
+            np.random.seed(seed)
+            b = G.sample_indices_fast(n, rate)
+            sb = np.random.randint(0, 1 << 30, 4)
+            assert np.array_equal(a, b) and b.dtype == np.int32, (seed, n, rate)
+            assert np.array_equal(sa, sb), "NumPy's stream must end where np.random.shuffle leaves it"
+    np.random.seed(3)                       # a running stream across frames, crossing many 624-word refills
+    a = [G.sample_indices(4801, 13) for _ in range(30)]
+    np.random.seed(3)
+    b = [G.sample_indices_fast(4801, 13) for _ in range(30)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
