@@ -11,9 +11,22 @@
 
 namespace {
 struct Mt {
-    uint32_t *key;      // 624 words, NumPy's layout
+    uint32_t *key;              // 624 words, NumPy's layout (untempered)
+    uint32_t out[624];          // the same block tempered, produced 624 at a time (the loop vectorises)
     int pos;
 };
+
+inline void mt_temper_block(Mt &m)
+{
+    for (int k = 0; k < 624; ++k) {
+        uint32_t y = m.key[k];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        m.out[k] = y;
+    }
+}
 
 inline void mt_refill(Mt &m)
 {
@@ -31,17 +44,13 @@ inline void mt_refill(Mt &m)
     const uint32_t y = (mt[623] & UPPER) | (mt[0] & LOWER);
     mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX : 0u);
     m.pos = 0;
+    mt_temper_block(m);
 }
 
 inline uint32_t mt_next(Mt &m)
 {
     if (m.pos == 624) mt_refill(m);
-    uint32_t y = m.key[m.pos++];
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    return m.out[m.pos++];
 }
 }  // namespace
 
@@ -51,12 +60,14 @@ extern "C" bsc_status bsc_host_shuffled_sample(uint32_t *key624, int32_t *pos, i
 {
     if (!key624 || !pos || !scratch_n || !out || n < 1 || n > 0x7fffffffll || rate < 1 || *pos < 0 || *pos > 624)
         return BSC_E_INVALID;
-    Mt m{key624, *pos};
+    Mt m;
+    m.key = key624;
+    m.pos = *pos;
+    mt_temper_block(m);
     int32_t *x = scratch_n;
     for (int64_t i = 0; i < n; ++i) x[i] = (int32_t)i;
     for (uint32_t i = (uint32_t)n - 1; i >= 1; --i) {
-        uint32_t mask = i;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t mask = 0xffffffffu >> __builtin_clz(i);      // smallest all-ones mask >= i
         uint32_t j;
         while ((j = (mt_next(m) & mask)) > i) {}
         const int32_t t = x[j];
