@@ -78,3 +78,23 @@ extern "C" bsc_status bsc_host_shuffled_sample(uint32_t *key624, int32_t *pos, i
     *pos = m.pos;
     return BSC_OK;
 }
+
+// n draws of Python's `random.choice(range(n_choices))` (memory_2.py:352) on a copy of the `random` module's MT19937
+// state (random.getstate()[1] = 624 key words + pos, advanced in place): CPython's _randbelow_with_getrandbits takes
+// k = n_choices.bit_length() bits per try as genrand_uint32() >> (32 - k) and rejects values >= n_choices.
+extern "C" bsc_status bsc_host_choice_draws(uint32_t *key624, int32_t *pos, uint32_t n_choices, uint32_t n, uint32_t *out)
+{
+    if (!key624 || !pos || (!out && n) || n_choices < 1 || *pos < 0 || *pos > 624) return BSC_E_INVALID;
+    Mt m;
+    m.key = key624;
+    m.pos = *pos;
+    mt_temper_block(m);
+    const int k = 32 - __builtin_clz(n_choices);            // bit_length
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t r;
+        while ((r = mt_next(m) >> (32 - k)) >= n_choices) {}
+        out[i] = r;
+    }
+    *pos = m.pos;
+    return BSC_OK;
+}

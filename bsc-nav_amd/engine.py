@@ -56,8 +56,17 @@ class VoxelEngine:
     # memory_2.py:352 — Python's global RNG, one draw per row that meets a full voxel
     def _draw_cb(self, user, n, out):
         k = self.cfg.cache_size
-        for i in range(n):
-            out[i] = random.choice(range(k))
+        if n < 64:
+            for i in range(n):
+                out[i] = random.choice(range(k))
+            return
+        # many draws (saturated voxels): the same stream, advanced by the library's restatement of random.choice
+        version, internal, gauss = random.getstate()
+        key = np.array(internal[:624], dtype=np.uint32)
+        pos = C.c_int32(internal[624])
+        _lib.check(self.lib.bsc_host_choice_draws(key.ctypes.data_as(C.c_void_p), C.byref(pos), k, n,
+                                                  C.cast(out, C.c_void_p)))
+        random.setstate((version, tuple(key.tolist()) + (pos.value,), gauss))
 
     def close(self):
         if getattr(self, "h", None):

@@ -183,6 +183,11 @@ bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id)
 bsc_status bsc_host_shuffled_sample(uint32_t *key624, int32_t *pos, int64_t n, int32_t rate, int32_t *scratch_n,
                                     int32_t *out);
 
+/* Host helper: n draws of Python's `random.choice(range(n_choices))` (the replacement index of a full voxel,
+ * memory_2.py:352) on a copy of the `random` module's MT19937 state (random.getstate()[1]: 624 key words, then pos),
+ * advanced in place — what a bsc_draw_fn that must stay on Python's stream can call instead of looping in Python. */
+bsc_status bsc_host_choice_draws(uint32_t *key624, int32_t *pos, uint32_t n_choices, uint32_t n, uint32_t *out);
+
 /* Encoder helper (stateless, bf16): s = x + delta ; y = LayerNorm(s)*gamma + beta, one pass over the (rows,width)
  * token matrix.  delta/xout may be NULL (plain LayerNorm).  Fuses the residual add and the LayerNorm that sit
  * between the library GEMMs of the ViT patch-feature provider (memory_2.py:738).  width % 256 == 0, <= 2048. */

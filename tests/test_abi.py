@@ -79,3 +79,25 @@ def test_host_shuffle_matches_numpy_bit_for_bit():
     np.random.seed(3)
     b = [G.sample_indices_fast(4801, 13) for _ in range(30)]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_host_choice_draws_match_python_random():
+    """bsc_host_choice_draws == [random.choice(range(k)) ...] (memory_2.py:352) incl. the state of Python's stream."""
+    import ctypes as C
+    import random
+    import numpy as np
+    from bsc_nav_amd import _lib
+    lib = _lib.load()
+    for seed, k, n in ((0, 10, 1), (1, 10, 5000), (2, 7, 777), (3, 16, 300), (4, 1, 50), (5, 33, 2000), (6, 10, 50000)):
+        random.seed(seed)
+        want = [random.choice(range(k)) for _ in range(n)]
+        tail = [random.random() for _ in range(3)]
+        random.seed(seed)
+        version, internal, gauss = random.getstate()
+        key = np.array(internal[:624], dtype=np.uint32)
+        pos = C.c_int32(internal[624])
+        out = np.zeros(n, np.uint32)
+        _lib.check(lib.bsc_host_choice_draws(key.ctypes.data_as(C.c_void_p), C.byref(pos), k, n, out.ctypes.data_as(C.c_void_p)))
+        random.setstate((version, tuple(key.tolist()) + (pos.value,), gauss))
+        assert out.tolist() == want, (seed, k, n)
+        assert [random.random() for _ in range(3)] == tail
