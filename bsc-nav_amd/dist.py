@@ -131,12 +131,30 @@ def merge_dense_maps(engine, group=None):
     return dict(n_union=n_union, per_rank=per, n_local=n_local)
 
 
+def name_keys_np(pos):
+    """Vectorised name_key_np: (n,3) positions -> three (n,) int64 sort keys (HDF5 link-name order of 'grid_r_c_h')."""
+    pos = np.asarray(pos, np.int64).reshape(-1, 3)
+    keys = []
+    for col, last in ((0, False), (1, False), (2, True)):
+        v = pos[:, col]
+        nd = 1 + sum((v >= 10 ** e).astype(np.int64) for e in range(1, 6))
+        k = np.zeros_like(v)
+        for p in range(6):                                  # symbols from the most significant digit
+            exp = np.maximum(nd - 1 - p, 0)
+            digit = (v // (10 ** exp)) % 10
+            sym = np.where(p < nd, digit + (1 if last else 0), 0 if last else 10)
+            k = k * 11 + sym
+        keys.append(k)
+    return keys
+
+
 def merge_topk(pos_list, sim_list, K):
     """K-way merge of per-rank winners with the reference's order: similarity descending, ties in
     HDF5 group-name order (memory_2.py:665 stable sort over name-sorted keys)."""
     pos = np.concatenate([np.asarray(p).reshape(-1, 3) for p in pos_list])
     sim = np.concatenate([np.asarray(s).reshape(-1) for s in sim_list])
-    order = sorted(range(len(sim)), key=lambda i: (-float(sim[i]),) + name_key_np(pos[i]))[:K]
+    k0, k1, k2 = name_keys_np(pos)
+    order = np.lexsort((k2, k1, k0, -sim.astype(np.float64)))[:K]
     return pos[order], sim[order]
 
 
@@ -152,16 +170,12 @@ def localize_sharded(engine, q, K=100, radius=None, curr=None, floor=None, group
     rec[..., :3] = torch.from_numpy(pos.astype(np.float64)).to(dev)
     rec[..., 3] = torch.from_numpy(sim.astype(np.float64)).to(dev)
     n = torch.from_numpy(cnt.astype(np.int64)).to(dev)
-    recs = _all_gather(rec, group)
-    ns = _all_gather(n, group)
+    recs = torch.stack(_all_gather(rec, group)).cpu().numpy()           # (world, Q, K, 4): one transfer
+    ns = torch.stack(_all_gather(n, group)).cpu().numpy()               # (world, Q)
     out_p, out_s = [], []
     for qi in range(Q):
-        pl, sl = [], []
-        for r in range(world):
-            m = int(ns[r][qi].item())
-            a = recs[r][qi, :m].cpu().numpy()
-            pl.append(a[:, :3].astype(np.int32))
-            sl.append(a[:, 3].astype(np.float32))
+        pl = [recs[r, qi, :ns[r, qi], :3].astype(np.int32) for r in range(world)]
+        sl = [recs[r, qi, :ns[r, qi], 3].astype(np.float32) for r in range(world)]
         p, s = merge_topk(pl, sl, K)
         out_p.append(p)
         out_s.append(s)
