@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import shutil, tempfile
 _src = os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
 _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.getpid()}_.csv")
-shutil.copy(_src, _dst[:-4] + "0.csv")
+if not os.environ.get("BSC_TUNE_FRESH"):
+    shutil.copy(_src, _dst[:-4] + "0.csv")
 os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=_dst, PYTORCH_TUNABLEOP_VERBOSE="0")
 import torch
 if os.environ.get("BSC_FA"):
@@ -24,4 +25,5 @@ for _ in range(n):
     vit.patch_tokens(rgb)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
+print("tunableop file:", _dst[:-4] + "0.csv")
 print(f"{arch} B={B}: {dt * 1e3:.2f} ms per forward, {vit.flops_per_frame() * B / dt / 1e12:.0f} TFLOP/s")
