@@ -56,6 +56,9 @@ SIGNATURES = {
     "bsc_import_cv_map": (_I32, [_VP, _VP]),
     "bsc_dense_gather": (_I32, [_VP, _I64, _VP, _VP, _VP]),
     "bsc_dense_replace": (_I32, [_VP, _I64, _VP, _VP, _VP]),
+    "bsc_dense_gather_rgb": (_I32, [_VP, _I64, _VP, _VP, _VP]),
+    "bsc_dense_replace_full": (_I32, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),
+    "bsc_import_heightmap": (_I32, [_VP, _VP, _VP]),
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "bsc_kernel_stats": (_I32, [_VP, _I32, _I32, _VP]),
     "bsc_enc_embed_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP]),

@@ -709,28 +709,98 @@ extern "C" bsc_status bsc_dense_gather(bsc_ctx *x, int64_t n, const int32_t *key
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_dense_replace(bsc_ctx *x, int64_t n, const int32_t *keys_dev, const float *acc_dev,
-                                        const int32_t *cnt_dev)
+// rgb / weight of the voxels `keys` (absent voxels: weight 0) — the rank-local colour state that travels with a merge
+__global__ __launch_bounds__(TPB) void k_rgb_gather(int64_t n, const int32_t *__restrict__ keys, int gs, int nh,
+                                                    const int32_t *__restrict__ occ, const uint8_t *__restrict__ rgb,
+                                                    const float *__restrict__ weight, uint8_t *__restrict__ out_rgb,
+                                                    float *__restrict__ out_w)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = keys[3 * i], c = keys[3 * i + 1], h = keys[3 * i + 2];
+    int32_t vid = -1;
+    if (r >= 0 && c >= 0 && h >= 0 && r < gs && c < gs && h < nh) vid = occ[((int64_t)r * gs + c) * nh + h];
+    out_w[i] = vid >= 0 ? weight[vid] : 0.f;
+    for (int k = 0; k < 3; ++k) out_rgb[3 * i + k] = vid >= 0 ? rgb[3 * (int64_t)vid + k] : (uint8_t)0;
+}
+
+extern "C" bsc_status bsc_dense_gather_rgb(bsc_ctx *x, int64_t n, const int32_t *keys_dev, uint8_t *rgb_dev, float *weight_dev)
+{
+    if (!x || !keys_dev || !rgb_dev || !weight_dev) { bsc_set_error("bsc_dense_gather_rgb: null argument"); return BSC_E_INVALID; }
+    if (n <= 0) return BSC_OK;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->side));            // the rgb chain of the last ingest writes rgb / weight on the side stream
+    hipLaunchKernelGGL(k_rgb_gather, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, n, keys_dev, x->c.grid_size,
+                       x->nh, x->occ, x->rgb, x->weight, rgb_dev, weight_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+// The map becomes exactly the n voxels handed in, ids 0..n-1 in the order given: keys, feature rows, counts AND the
+// colour state (rgb, weight) are replaced together, so every per-id array stays aligned (memory_2.py:888-899 state).
+// rgb_dev / weight_dev may be null: colours and weights are then zeroed (a map that was never given colours).
+extern "C" bsc_status bsc_dense_replace_full(bsc_ctx *x, int64_t n, const int32_t *keys_dev, const float *acc_dev,
+                                             const int32_t *cnt_dev, const uint8_t *rgb_dev, const float *weight_dev)
 {
     if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_dense_replace: dense modes only"); return BSC_E_STATE; }
+    if (n < 0 || (n > 0 && (!keys_dev || !acc_dev || !cnt_dev)) || ((rgb_dev == nullptr) != (weight_dev == nullptr))) {
+        bsc_set_error("bsc_dense_replace: invalid argument");
+        return BSC_E_INVALID;
+    }
     if (n > x->c.voxel_capacity) { bsc_set_error("bsc_dense_replace: %lld voxels > capacity", (long long)n); return BSC_E_CAPACITY; }
     BSC_HIP(hipSetDevice(x->device));
     hipStream_t s = x->stream;
-    // the feature map is replaced; rgb / weight / top-down map stay rank-local (multi-GPU)
     BSC_TRY(sync_all(x));
+    const int64_t vcap = x->c.voxel_capacity;
     fill<int32_t>(x, x->occ, x->ncell, -1);
-    BSC_HIP(hipMemsetAsync(x->acnt, 0, sizeof(int32_t) * (x->c.voxel_capacity + 1), s));
+    BSC_HIP(hipMemsetAsync(x->acnt, 0, sizeof(int32_t) * (vcap + 1), s));
+    BSC_HIP(hipMemsetAsync(x->rgb, 0, 3 * vcap, s));
+    BSC_HIP(hipMemsetAsync(x->weight, 0, sizeof(float) * vcap, s));
+    BSC_HIP(hipMemsetAsync(x->dscal + DS_ERROR, 0, sizeof(int64_t), s));
     if (n > 0) {
         BSC_HIP(hipMemcpyAsync(x->rgb_pos, keys_dev, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToDevice, s));
         BSC_HIP(hipMemcpyAsync(x->acc, acc_dev, sizeof(float) * n * x->c.token_dim, hipMemcpyDeviceToDevice, s));
         BSC_HIP(hipMemcpyAsync(x->acnt, cnt_dev, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, s));
+        if (rgb_dev) {
+            BSC_HIP(hipMemcpyAsync(x->rgb, rgb_dev, 3 * n, hipMemcpyDeviceToDevice, s));
+            BSC_HIP(hipMemcpyAsync(x->weight, weight_dev, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+        }
         hipLaunchKernelGGL(k_import_occ, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, n, x->rgb_pos, x->c.grid_size,
                            x->nh, x->occ, x->dscal);
     }
     int64_t m[2] = {n, n};
     BSC_HIP(hipMemcpyAsync(x->dscal + DS_MAX_ID, m, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
-    BSC_HIP(hipStreamSynchronize(s));
+    BSC_TRY(read_scalars(x));
     x->names_dirty = true;
+    if (x->hscal[DS_ERROR]) {
+        BSC_HIP(hipMemsetAsync(x->dscal + DS_ERROR, 0, sizeof(int64_t), s));
+        bsc_set_error("bsc_dense_replace: a key lies outside the grid");
+        return BSC_E_INVALID;
+    }
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_dense_replace(bsc_ctx *x, int64_t n, const int32_t *keys_dev, const float *acc_dev,
+                                        const int32_t *cnt_dev)
+{
+    return bsc_dense_replace_full(x, n, keys_dev, acc_dev, cnt_dev, nullptr, nullptr);
+}
+
+// top-down map from host arrays (merge of per-rank maps; memory_2.py:901-903 state): max_height (gs,gs) f64 with -inf
+// for empty cells, cv_map (gs,gs,3).  Imported cells carry tie order 0, so any later point at the same height wins
+// them, as `h >= max_height` does in the reference.
+extern "C" bsc_status bsc_import_heightmap(bsc_ctx *x, const double *max_height, const uint8_t *cv_map)
+{
+    if (!x || !max_height || !cv_map) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));
+    const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
+    u64 *h = (u64 *)malloc(sizeof(u64) * gs2);
+    for (int64_t i = 0; i < gs2; ++i) h[i] = isfinite(max_height[i]) ? ((u64)((int64_t)max_height[i] + 1) << 40) : 0ull;
+    hipError_t e = hipMemcpy(x->hmap, h, sizeof(u64) * gs2, hipMemcpyHostToDevice);
+    free(h);
+    BSC_HIP(e);
+    BSC_HIP(hipMemcpy(x->cv_map, cv_map, 3 * gs2, hipMemcpyHostToDevice));
     return BSC_OK;
 }
 

@@ -4,11 +4,15 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm
 single-process; this module is the new frame-sharded design of SURVEY.md §8e:
 
   merge_dense_maps   (dense mean / max modes)
-     1. all-gather of the per-rank voxel keys  -> identical sorted union on every rank
+     1. all-gather of the per-rank voxel keys (local id order) -> the union in GLOBAL first-touch order,
+        identical on every rank: ids equal the single-process numbering
      2. each rank lays its rows out in union order (bsc_dense_gather; untouched voxels are neutral)
      3. reduce-scatter of the (U,D) accumulators and (U,) counts: rank r ends up owning the r-th
         contiguous slice of the union.  xGMI is point-to-point, so reduce-scatter (all 7 links busy)
         is preferred over a ring all-reduce followed by a broadcast.
+     4. colour state (7 B / voxel / rank) and the top-down map (gs^2 cells) are all-gathered and merged
+        (merge_colour_states: documented rule; merge_heightmaps: exact)
+  gather_merged_to_root   slices -> one engine that holds the whole memory and can save a loadable directory
   localize_sharded   every rank scans its slice, all-gather of the (Q,K) local winners, K-way merge
                      with the reference's tie order (HDF5 group-name order).
 
@@ -79,16 +83,28 @@ def all_gather_ragged(t, group=None):
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
-def union_keys(local_codes, group=None):
-    """Sorted union of every rank's voxel codes, padded with sentinels to a multiple of the world size."""
+def global_id_order(local_codes, group=None):
+    """Voxel codes of every rank, each in its LOCAL id order -> the union in GLOBAL first-touch order, identical on
+    every rank, padded with sentinels to a multiple of the world size.  -> (codes, n_union, per_rank)
+
+    Frames are sharded in contiguous blocks (rank 0 holds the earliest frames), so the order in which a single process
+    would have met the voxels (memory_2.py:888-894, `max_id` numbering) is: rank 0's voxels in their local order, then
+    the voxels rank 1 saw that rank 0 did not, in rank 1's local order, and so on — the first occurrence of every code
+    in the rank-major concatenation of the local lists."""
     rank, world = _world(group)
     parts = all_gather_ragged(local_codes, group)
-    union = torch.unique(torch.cat(parts))          # sorted ascending
+    allc = torch.cat(parts)
+    if allc.numel():
+        uniq, inv = torch.unique(allc, return_inverse=True)
+        first = torch.full((uniq.numel(),), allc.numel(), dtype=torch.int64, device=allc.device)
+        first.scatter_reduce_(0, inv, torch.arange(allc.numel(), dtype=torch.int64, device=allc.device), reduce="amin")
+        union = uniq[torch.argsort(first)]
+    else:
+        union = allc
     n_union = union.numel()
     per = (n_union + world - 1) // world if n_union else 0
     if per * world > n_union:
-        union = torch.cat([union, torch.full((per * world - n_union,), _SENTINEL, dtype=torch.int64,
-                                             device=union.device)])
+        union = torch.cat([union, torch.full((per * world - n_union,), _SENTINEL, dtype=torch.int64, device=union.device)])
     return union, n_union, per
 
 
@@ -108,27 +124,134 @@ def reduce_scatter_rows(rows, op, per, group=None):
     return out
 
 
-def merge_dense_maps(engine, group=None):
-    """Merge per-rank dense maps; afterwards rank r holds slice r of the global voxel set.
+def merge_colour_states(rgbs, weights, present):
+    """Colour state of one voxel set held by several ranks -> one (rgb u8 (n,3), weight f32 (n,)).
 
-    `engine` needs: mode, keys_tensor(), dense_gather(keys), dense_replace(keys, acc, cnt).
-    Returns dict(n_union, per_rank, n_local)."""
+    The reference's running mean `c' = trunc((f32(c*w) + r*a) / (w + a)); w' = f32(w + a)` (memory_2.py:895-899) is
+    defined by the global point order and truncates at every step, so per-rank results cannot be combined into the
+    sequential answer.  The dense-mode rule: a rank's final state (c_r, w_r) enters the SAME update as one
+    observation of colour c_r and weight a = w_r, ranks in rank order (= frame order), the first rank that holds the
+    voxel initialises it.  Same arithmetic as the chain: the product c*w rounded in f32, the rest in f64, truncating
+    store.  rgbs (R,n,3) u8, weights (R,n) f32, present (R,n) bool."""
+    R, n = weights.shape
+    c = torch.zeros((n, 3), dtype=torch.float64, device=weights.device)
+    w = torch.zeros(n, dtype=torch.float32, device=weights.device)
+    have = torch.zeros(n, dtype=torch.bool, device=weights.device)
+    for r in range(R):
+        cr, wr, pr = rgbs[r].to(torch.float64), weights[r], present[r]
+        first, cont = pr & ~have, pr & have
+        den = w.to(torch.float64) + wr.to(torch.float64)
+        num = (c.to(torch.float32) * w[:, None]).to(torch.float64) + cr * wr.to(torch.float64)[:, None]
+        cn = torch.trunc(num / torch.where(den > 0, den, torch.ones_like(den))[:, None])
+        c = torch.where(first[:, None], cr, torch.where(cont[:, None], cn, c))
+        w = torch.where(first, wr, torch.where(cont, den.to(torch.float32), w))
+        have = have | pr
+    return c.to(torch.uint8), w
+
+
+def merge_heightmaps(heights, colours):
+    """Per-rank top-down maps -> the sequential result.  `h >= max_height` in point order (memory_2.py:901-903) keeps,
+    per cell, the LATEST point among those at the greatest height; points of a higher rank come later, so the winner
+    is the highest rank that reaches the cell's maximum.  heights (R,gs,gs) f64 (-inf empty), colours (R,gs,gs,3) u8."""
+    R = heights.shape[0]
+    top = heights.max(axis=0)
+    at_top = heights == top[None]                                       # -inf == -inf: empty everywhere -> rank R-1, colour 0
+    winner = (R - 1) - np.argmax(at_top[::-1], axis=0)
+    rr, cc = np.meshgrid(np.arange(top.shape[0]), np.arange(top.shape[1]), indexing="ij")
+    return top, colours[winner, rr, cc]
+
+
+def _all_gather_np(a, device, group=None):
+    """NumPy array (same shape on every rank) -> (world, ...) NumPy array."""
+    rank, world = _world(group)
+    if world == 1:
+        return a[None]
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    return torch.stack(_all_gather(t, group)).cpu().numpy()
+
+
+def merge_dense_maps(engine, group=None):
+    """Merge per-rank dense maps into ONE memory whose rows are distributed: afterwards rank r holds slice r of the
+    global voxel set, in global id order (ids of slice r start at r * per_rank).
+
+      ids / positions   global first-touch order (global_id_order) == the single-process numbering
+      features, counts  one reduce-scatter of the (U,D) sums (or maxima) and (U,) counts
+      rgb, weights      merge_colour_states (documented dense-mode rule)
+      top-down map      merge_heightmaps (exact), replicated on every rank
+
+    `engine` needs: mode, device, keys_tensor(), dense_gather(keys), dense_gather_rgb(keys), export_heightmap(),
+    import_heightmap(h, cv), dense_replace(keys, acc, cnt, rgb, weight).  Returns dict(n_union, per_rank, n_local)."""
     rank, world = _world(group)
     keys = engine.keys_tensor()
     codes = pack_keys(keys) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=keys.device)
-    union, n_union, per = union_keys(codes, group)
+    union, n_union, per = global_id_order(codes, group)
     if world == 1:
         return dict(n_union=n_union, per_rank=n_union, n_local=n_union)
     ukeys = unpack_keys(union)
     acc, cnt = engine.dense_gather(ukeys)
+    rgb, wgt = engine.dense_gather_rgb(ukeys)
     op = dist.ReduceOp.MAX if engine.mode == "max" else dist.ReduceOp.SUM
     my_acc = reduce_scatter_rows(acc, op, per, group)
     my_cnt = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, per, group)
-    mine = union[rank * per:(rank + 1) * per]
-    n_local = int((mine < _SENTINEL).sum().item())
-    engine.dense_replace(ukeys[rank * per:rank * per + n_local].contiguous(), my_acc[:n_local].contiguous(),
-                         my_cnt[:n_local].contiguous())
+    # colour state: 7 bytes per voxel and rank; every rank gathers the union and merges its own slice
+    lo, hi = rank * per, (rank + 1) * per
+    all_rgb = torch.stack(_all_gather(rgb, group))[:, lo:hi]
+    all_w = torch.stack(_all_gather(wgt, group))[:, lo:hi]
+    all_present = torch.stack(_all_gather(cnt, group))[:, lo:hi] > 0
+    my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
+    # top-down map: gs^2 cells, replicated
+    mh, cv = engine.export_heightmap()
+    top, colour = merge_heightmaps(_all_gather_np(mh, engine.device, group), _all_gather_np(cv, engine.device, group))
+    n_local = int((union[lo:hi] < _SENTINEL).sum().item())
+    engine.dense_replace(ukeys[lo:lo + n_local].contiguous(), my_acc[:n_local].contiguous(), my_cnt[:n_local].contiguous(),
+                         my_rgb[:n_local].contiguous(), my_w[:n_local].contiguous())
+    engine.import_heightmap(top, colour)
     return dict(n_union=n_union, per_rank=per, n_local=n_local)
+
+
+def _gather_to_root(t, root, group=None):
+    """Same-shape tensor from every rank -> list on `root` (None elsewhere)."""
+    rank, world = _world(group)
+    stage = dist.get_backend(group) == "gloo" and t.is_cuda
+    src = t.cpu() if stage else t
+    bufs = [torch.empty_like(src) for _ in range(world)] if rank == root else None
+    dist.gather(src, bufs, dst=root, group=group)
+    if rank != root:
+        return None
+    return [b.to(t.device) for b in bufs] if stage else bufs
+
+
+def gather_merged_to_root(engine, info, root=0, group=None):
+    """After merge_dense_maps: collect every rank's slice on `root`, whose engine then holds the WHOLE merged memory
+    (ids 0..n_union-1 in global order, features, counts, rgb, weights, top-down map) and can `save_memory` a directory
+    that `load_memory` accepts (memory_2.py:1136-1145 / :189-200).  Other ranks keep their slice.  -> True on root."""
+    rank, world = _world(group)
+    if world == 1:
+        return True
+    per, n_local, D = info["per_rank"], info["n_local"], engine.cfg.token_dim
+    dev = engine.device
+    keys = torch.full((per, 3), -1, dtype=torch.int32, device=dev)
+    acc = torch.zeros((per, D), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(per, dtype=torch.int32, device=dev)
+    rgb = torch.zeros((per, 3), dtype=torch.uint8, device=dev)
+    wgt = torch.zeros(per, dtype=torch.float32, device=dev)
+    if n_local:
+        k = engine.keys_tensor()
+        keys[:n_local] = k
+        a, c = engine.dense_gather(k)
+        r, w = engine.dense_gather_rgb(k)
+        acc[:n_local], cnt[:n_local], rgb[:n_local], wgt[:n_local] = a, c, r, w
+    parts = [_gather_to_root(t, root, group) for t in (keys, acc, cnt, rgb, wgt)]
+    if rank != root:
+        return False
+    n = info["n_union"]
+    full = [torch.cat(p)[:n].contiguous() for p in parts]        # slices are contiguous blocks of the global order
+    mh, cv = engine.export_heightmap()
+    engine.dense_replace(*full)
+    engine.import_heightmap(mh, cv)
+    return True
 
 
 def name_keys_np(pos):

@@ -47,9 +47,11 @@ class VoxelEngine:
         self.device = torch.device("cuda", device)
         self.nh = c.max_h - c.min_h
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # The library launches on the stream that is current NOW; calls made later under another torch stream are
+        # ordered against it in _enter() (see there).
+        self.stream = torch.cuda.current_stream(self.device)
         h = C.c_void_p()
-        _lib.check(self.lib.bsc_create(C.byref(c), device, C.c_void_p(stream), C.byref(h)))
+        _lib.check(self.lib.bsc_create(C.byref(c), device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.h = h
         self._draw = _lib.DRAW_FN(self._draw_cb)
 
@@ -67,6 +69,24 @@ class VoxelEngine:
         _lib.check(self.lib.bsc_host_choice_draws(key.ctypes.data_as(C.c_void_p), C.byref(pos), k, n,
                                                   C.cast(out, C.c_void_p)))
         random.setstate((version, tuple(key.tolist()) + (pos.value,), gauss))
+
+    def _enter(self, *tensors):
+        """Order the library stream after the caller's current stream and pin the inputs to it: when the caller works
+        under a different torch stream than the one the engine was created on, the kernels must not start before
+        the producers of `tensors` have finished, and the caching allocator must not hand their blocks out again
+        while the library is still reading them."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.stream)
+
+    def _leave(self):
+        """Results written by the library (device outputs) become visible to the caller's current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
 
     def close(self):
         if getattr(self, "h", None):
@@ -95,6 +115,7 @@ class VoxelEngine:
             assert sample_idx.is_cuda and sample_idx.dtype == torch.int32 and off is not None and len(off) == F + 1
         if alpha is not None:
             assert alpha.is_cuda and alpha.dtype == torch.float64
+        self._enter(depth, rgb, tokens, sample_idx, alpha)
         _lib.check(self.lib.bsc_ingest_typed(self.h, F, _dp(depth), _dp(rgb), rgb.shape[-1], _dp(tokens),
                                              1 if tokens.dtype == torch.bfloat16 else 0, _hp(T), _dp(sample_idx),
                                              _hp(off), _dp(alpha), self._draw, None))
@@ -181,7 +202,9 @@ class VoxelEngine:
         assert tokens.is_cuda and tokens.dtype == torch.float32 and tokens.is_contiguous()
         B, T, D = tokens.shape
         out = torch.empty(D, dtype=torch.float32, device=tokens.device)
+        self._enter(tokens, out)
         _lib.check(self.lib.bsc_pool_query(self.h, _dp(tokens), B, T, D, _dp(out)))
+        self._leave()
         return out
 
     def localize(self, q, K=100, radius=None, curr=None, floor=None):
@@ -192,6 +215,7 @@ class VoxelEngine:
         pos, sim, cnt = np.zeros((Q, K, 3), np.int32), np.zeros((Q, K), np.float32), np.zeros(Q, np.int32)
         curr_a = None if curr is None else np.ascontiguousarray(curr, np.int32)
         lo, hi = (0, -1) if floor is None else (int(floor[0]), int(floor[1]))
+        self._enter(q)
         _lib.check(self.lib.bsc_localize(self.h, _dp(q), Q, K, -1.0 if radius is None else float(radius), _hp(curr_a),
                                          lo, hi, _hp(pos), _hp(sim), _hp(cnt)))
         return pos, sim, cnt
@@ -256,14 +280,44 @@ class VoxelEngine:
             out.copy_(torch.from_numpy(pos))
         return out
 
+    def max_height_cv_map(self):
+        """(max_height (gs,gs) f64 with -inf for empty cells, cv_map (gs,gs,3) u8) — the top-down map state."""
+        return self.export_heightmap()
+
     def dense_gather(self, keys):
         keys = keys.contiguous()
         n = keys.shape[0]
         acc = torch.empty((n, self.cfg.token_dim), dtype=torch.float32, device=self.device)
         cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._enter(keys, acc, cnt)
         _lib.check(self.lib.bsc_dense_gather(self.h, n, _dp(keys), _dp(acc), _dp(cnt)))
+        self._leave()
         return acc, cnt
 
-    def dense_replace(self, keys, acc, cnt):
-        _lib.check(self.lib.bsc_dense_replace(self.h, keys.shape[0], _dp(keys.contiguous()), _dp(acc.contiguous()),
-                                              _dp(cnt.contiguous())))
+    def dense_gather_rgb(self, keys):
+        """rgb (n,3) u8 and weight (n,) f32 of the voxels `keys` (weight 0 where this map has no such voxel)."""
+        keys = keys.contiguous()
+        n = keys.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.uint8, device=self.device)
+        w = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._enter(keys, rgb, w)
+        _lib.check(self.lib.bsc_dense_gather_rgb(self.h, n, _dp(keys), _dp(rgb), _dp(w)))
+        self._leave()
+        return rgb, w
+
+    def dense_replace(self, keys, acc, cnt, rgb=None, weight=None):
+        """The map becomes exactly these voxels (ids in the given order); rgb / weight None -> zeroed colours."""
+        keys, acc, cnt = keys.contiguous(), acc.contiguous(), cnt.contiguous()
+        assert keys.dtype == torch.int32 and acc.dtype == torch.float32 and cnt.dtype == torch.int32
+        if rgb is not None:
+            rgb, weight = rgb.contiguous(), weight.contiguous()
+            assert rgb.dtype == torch.uint8 and weight.dtype == torch.float32 and rgb.shape[0] == keys.shape[0]
+        self._enter(keys, acc, cnt, rgb, weight)
+        _lib.check(self.lib.bsc_dense_replace_full(self.h, keys.shape[0], _dp(keys), _dp(acc), _dp(cnt), _dp(rgb), _dp(weight)))
+
+    def import_heightmap(self, max_height, cv_map):
+        gs = self.cfg.grid_size
+        mh = np.ascontiguousarray(max_height, np.float64)
+        cv = np.ascontiguousarray(cv_map, np.uint8)
+        assert mh.shape == (gs, gs) and cv.shape == (gs, gs, 3)
+        _lib.check(self.lib.bsc_import_heightmap(self.h, _hp(mh), _hp(cv)))

@@ -55,6 +55,13 @@ class PoseChain:
     def reset(self):
         self.inv_init_base_tf = None
 
+    def anchor(self, pose):
+        """Fix the map origin at `pose` instead of at the first ingested frame (memory_2.py:844-847).  A frame-sharded
+        build calls this on every rank with the scene's first pose, so that all ranks write into one map frame."""
+        B = self.base_transform
+        self.init_base_tf = B @ pose_vec2tf(np.asarray(pose, dtype=np.float64)) @ np.linalg.inv(B)
+        self.inv_init_base_tf = np.linalg.inv(self.init_base_tf)
+
     def pc_transform(self, pose):
         B = self.base_transform
         if self.inv_init_base_tf is None:

@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from . import store
+from . import floors, store
 from .config import from_namespace
 from .engine import VoxelEngine
 from .geometry import PoseChain, cam_mat_fov, sample_indices_fast as sample_indices
@@ -27,7 +27,7 @@ class VoxelTokenMemory:
     def __init__(self, args, memory_path=None, init_state=None, build_map=False, preload_dino=None,
                  preload_yolo=None, need_diffusion=True, *, feature_mode="exact", env=None, imaginer=None,
                  token_dim=None, patch_size=None, voxel_capacity=None, token_capacity=None, gpu=0,
-                 alpha_source="device", max_frames_per_call=1, quiet=True):
+                 alpha_source=None, max_frames_per_call=1, quiet=True):
         self.args = args
         self.cfg = from_namespace(args)
         self.device = "cuda"                                    # memory_2.py:41
@@ -40,7 +40,12 @@ class VoxelTokenMemory:
         self.Env = env                                           # NavEnv-like collaborator (env.py:49)
         self.quiet = quiet
         self.feature_mode = feature_mode
-        self.alpha_source = alpha_source
+        # exp(-r^2/1.2): "host" evaluates the reference's own NumPy expression (rgb bytes / weights bit-exact against the
+        # reference), "device" uses the GPU's exp (last-ulp differences flip < 0.1 % of the truncated rgb bytes by one).
+        # The reference-exact mode defaults to the exact setting; the dense north-star modes to the fast one.
+        self.alpha_source = alpha_source or ("host" if feature_mode == "exact" else "device")
+        self._gen = 0                                            # bumped by every call that changes the map
+        self._export_cache = {}
         if memory_path:                                          # memory_2.py:61-64
             self.memory_save_path = memory_path
         else:
@@ -86,43 +91,57 @@ class VoxelTokenMemory:
                                   device=self.gpu, min_depth=self.min_depth, max_depth=self.max_depth,
                                   min_h=self.minh, max_h=self.maxh)
         self.chain.reset()
+        self._touch()
 
     def _log(self, *a):
         if not self.quiet:
             print(*a)
 
-    # state the reference keeps as NumPy attributes, exported from HBM on access
+    # State the reference keeps as NumPy attributes (BSCAgent.py:179-218 reads them repeatedly).  Here it lives in HBM;
+    # an export is one D2H copy (occupied_ids: 800 MB at the reference defaults), so exports are cached until the next
+    # call that changes the map.
+    def _touch(self):
+        self._gen += 1
+        self._export_cache.clear()
+
+    def _cached(self, name, fn):
+        hit = self._export_cache.get(name)
+        if hit is None or hit[0] != self._gen:
+            hit = (self._gen, fn())
+            self._export_cache[name] = hit
+        return hit[1]
+
     @property
     def max_id(self):
-        return self.engine.counters()["max_id"]
+        return self._cached("counters", self.engine.counters)["max_id"]
 
     @property
     def iter_id(self):
-        return self.engine.counters()["iter_id"]
+        return self._cached("counters", self.engine.counters)["iter_id"]
 
     @property
     def grid_rgb_pos(self):
-        return self.engine.export_rgb()[0]
+        return self._cached("rgb", self.engine.export_rgb)[0]
 
     @property
     def grid_rgb(self):
-        return self.engine.export_rgb()[1]
+        return self._cached("rgb", self.engine.export_rgb)[1]
 
     @property
     def weight(self):
-        return self.engine.export_rgb()[2]
+        return self._cached("rgb", self.engine.export_rgb)[2]
 
     @property
     def occupied_ids(self):
-        return self.engine.export_occupied()
+        return self._cached("occ", self.engine.export_occupied)
 
     @property
     def cv_map(self):
-        return self.engine.export_heightmap()[1]
+        return self._cached("hmap", self.engine.export_heightmap)[1]
 
     @property
     def max_height(self):
-        return self.engine.export_heightmap()[0]
+        return self._cached("hmap", self.engine.export_heightmap)[0]
 
     @property
     def inv_init_base_tf(self):
@@ -150,6 +169,7 @@ class VoxelTokenMemory:
         """memory_2.py:326-358 — flush ALL iter_size cache rows into the per-voxel token store."""
         t1 = time.time()
         self.engine.flush()
+        self._touch()
         self._log(f"finish updating, time:{time.time() - t1}")
 
     # ------------------------------------------------------------------------------------------
@@ -162,6 +182,16 @@ class VoxelTokenMemory:
             tok = self.dinov2.forward_features(x)["x_norm_patchtokens"].squeeze(0)
             tok = tok.reshape(self.n_patch_w, self.n_patch_h, -1)
         return tok
+
+    def _batch_patch_tokens(self, rgb):
+        """(F,H,W,C) u8 device frames -> (F,g,g,D) tokens: the encoder's fused batch entry when it has one
+        (encoder.RandomViT.patch_tokens), otherwise the reference's forward_features contract (memory_2.py:732-742)."""
+        if hasattr(self.dinov2, "patch_tokens"):
+            return self.dinov2.patch_tokens(rgb)
+        x = self._transform_tensor(rgb[..., :3].permute(0, 3, 1, 2).float() / 255)
+        with torch.no_grad():
+            tok = self.dinov2.forward_features(x)["x_norm_patchtokens"]
+        return tok.reshape(rgb.shape[0], self.n_patch_w, self.n_patch_h, -1).float().contiguous()
 
     def _transform_tensor(self, x):
         """transform_ (memory_2.py:71-74): Resize((qh,qw)) on a float tensor (bilinear, antialias) + Normalize."""
@@ -207,6 +237,7 @@ class VoxelTokenMemory:
         self.engine.ingest(torch.from_numpy(depth).to(self.device).unsqueeze(0),
                            torch.from_numpy(rgb).to(self.device).unsqueeze(0), patch_tokens.unsqueeze(0), T[None],
                            torch.from_numpy(idx).to(self.device), np.array([0, len(idx)], np.int64), alpha)
+        self._touch()
 
     def ingest_frames(self, rgb, depth, poses, tokens=None):
         """Batched ingest (new): rgb (F,H,W,C) u8, depth (F,H,W) f32 device tensors, poses (F,7).
@@ -215,7 +246,8 @@ class VoxelTokenMemory:
         F = rgb.shape[0]
         Ts = np.stack([self.chain.pc_transform(p) for p in np.asarray(poses, dtype=np.float64)])
         if tokens is None:
-            tokens = self.dinov2.patch_tokens(rgb)
+            tokens = self._batch_patch_tokens(rgb)
+        self._touch()
         if self.depth_sample_rate == 1 and self.feature_mode != "exact":
             self.engine.ingest(depth, rgb, tokens, Ts)
             return
@@ -294,6 +326,34 @@ class VoxelTokenMemory:
         else:
             store.save_dense(path, *self.engine.export_dense())
 
+    # ---- frame-sharded builds (new: the reference is single-process) ---------------------------------
+    def set_map_origin(self, pose):
+        """Anchor the map frame at `pose` (the scene's first pose) on every rank of a frame-sharded build."""
+        self.chain.anchor(pose)
+
+    def merge_shards(self, group=None, root=0):
+        """Dense modes: merge the per-rank maps (one reduce-scatter over RCCL, dist.merge_dense_maps) and collect the
+        result on `root`, whose object then holds the whole memory — ids in the single-process first-touch order,
+        features / counts reduced, rgb / weights by the documented merge rule, top-down map exact — ready for
+        save_memory().  base_height and long_memory entries are concatenated in rank order.  -> True on root."""
+        import torch.distributed as tdist
+        from . import dist as bdist
+        if self.feature_mode == "exact":
+            raise RuntimeError("the exact (token-cache) mode is defined by the global point order: replicas only")
+        info = bdist.merge_dense_maps(self.engine, group)
+        self._touch()
+        if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size(group) == 1:
+            return True
+        is_root = bdist.gather_merged_to_root(self.engine, info, root, group)
+        lists = [None] * tdist.get_world_size(group)
+        tdist.all_gather_object(lists, (list(map(float, self.base_height)), self.long_memory_dict), group=group)
+        if is_root:
+            self.base_height = [h for bh, _ in lists for h in bh]
+            self.long_memory_dict = [o for _, lm in lists for o in lm]
+            self.long_memory_integration()
+        self._touch()
+        return is_root
+
     def load_memory(self, init_state=None, build_map=False):
         """memory_2.py:166-256."""
         if self.Env is not None and hasattr(self.Env, "reset"):
@@ -303,19 +363,33 @@ class VoxelTokenMemory:
         if build_map:
             self.engine.reset()
             self.chain.reset()
+            self._touch()
             return
         path = self.memory_save_path
         st = store.load_rgb_state(path)
+        tok = store.load_token_store(path) if self.feature_mode == "exact" else None
+        remake = False
         if (st["minh"], st["maxh"]) != (self.minh, self.maxh):        # memory_2.py:200
             self.minh, self.maxh = st["minh"], st["maxh"]
             self.floor_height, self.map_height = self.minh * self.cs, self.maxh * self.cs
+            remake = True
+        # capacities follow the loaded memory (the reference store is bounded only by cache_size tokens per voxel):
+        # room for the loaded voxels / tokens plus a few more cache flushes
+        if len(st["pos"]) > self.engine.cfg.voxel_capacity:
+            self._voxel_capacity = 2 * len(st["pos"])
+            remake = True
+        if tok is not None and len(tok[2]) + self.iter_size > self.engine.cfg.token_capacity:
+            self._token_capacity = len(tok[2]) + 4 * self.iter_size
+            remake = True
+        if remake:
             self._make_engine()
         self.feat_path = path + "/feat.h5df"
         self.engine.import_rgb(st["pos"], st["rgb"], st["weight"])
-        if self.feature_mode == "exact":
-            self.engine.import_store(*store.load_token_store(path))
+        if tok is not None:
+            self.engine.import_store(*tok)
         else:
             self.engine.import_dense(*store.load_dense(path))
+        self._touch()
         self.long_memory_dict = st["long_memory"]
         self.original_pos = st["original_pos"]
         if self.Env is not None and hasattr(self.Env, "original_state"):
@@ -329,38 +403,15 @@ class VoxelTokenMemory:
             self._select_floor(st["pos"], st["rgb"], current_height)
 
     def _select_floor(self, grid_rgb_pos, grid_rgb, current_height):
-        """memory_2.py:202-252: DBSCAN over recorded base heights -> z-range of the current floor."""
-        from sklearn.cluster import DBSCAN
-        base = np.array(self.base_height).reshape(-1, 1)
-        min_samples = len(self.base_height) // 5 if len(self.base_height) // 5 > 0 else 1
-        clustering = DBSCAN(eps=0.4, min_samples=min_samples).fit(base)
-        floor_heights = []
-        for label in set(clustering.labels_):
-            if label != -1:
-                floor_heights.append(np.mean(base[clustering.labels_ == label]))
-        self.floor_heights = sorted(floor_heights)
-        self.num_floors = len(self.floor_heights)
-        current_floor = int(np.argmin(np.abs(np.array(self.floor_heights) - current_height)))
-        pos_range = [grid_rgb_pos[:, 2].min(), grid_rgb_pos[:, 2].max()]
-        if self.num_floors == 1:
-            rng = pos_range
-        else:
-            ranges = []
-            fh = self.floor_heights
-            for i in range(self.num_floors):
-                if i == 0:
-                    lo, hi = pos_range[0], pos_range[0] + (fh[1] - fh[0]) / self.cs
-                elif i == self.num_floors - 1:
-                    lo, hi = pos_range[0] + (fh[i] - fh[0]) / self.cs, pos_range[1]
-                else:
-                    lo, hi = pos_range[0] + (fh[i] - fh[0]) / self.cs, pos_range[0] + (fh[i + 1] - fh[0]) / self.cs
-                ranges.append([int(lo) + 1, int(hi) - 1])
-            rng = ranges[current_floor]
-        self.floor_min_height, self.floor_max_height = int(rng[0]), int(rng[1])
-        mask = np.logical_and(grid_rgb_pos[:, 2] >= self.floor_min_height, grid_rgb_pos[:, 2] <= self.floor_max_height)
-        np.save(self.memory_save_path + f"/grid_rgb_pos_floor_{current_floor}.npy", grid_rgb_pos[mask])
-        np.save(self.memory_save_path + f"/grid_rgb_floor_{current_floor}.npy", grid_rgb[mask])
-        return current_floor
+        """memory_2.py:202-252: floors from the recorded base heights, z-range of the floor the agent stands on, and the
+        per-floor rgb voxel files the reference's viewers read (host logic in floors.py)."""
+        sel = floors.select_floor(self.base_height, grid_rgb_pos, self.cs, current_height)
+        self.floor_heights, self.num_floors = sel["levels"], sel["num_floors"]
+        self.floor_min_height, self.floor_max_height = sel["zrange"]
+        k = sel["current_floor"]
+        np.save(self.memory_save_path + f"/grid_rgb_pos_floor_{k}.npy", grid_rgb_pos[sel["mask"]])
+        np.save(self.memory_save_path + f"/grid_rgb_floor_{k}.npy", grid_rgb[sel["mask"]])
+        return k
 
     # ------------------------------------------------------------------------------------------
     # simulator-driven loops: thin restatements over an injected NavEnv-like `Env` (env.py:49-296)

@@ -16,11 +16,18 @@ import os
 
 import numpy as np
 
-try:                                    # optional adapter for reference-built memories
-    import h5py                          # noqa: F401
-    HAVE_H5PY = True
-except Exception:                        # pragma: no cover - image has no h5py
-    HAVE_H5PY = False
+def _h5py():
+    """The h5py module, or None.  Looked up at call time: the adapter is optional (this image ships without h5py;
+    the tests exercise it through an in-memory stand-in registered under the same name)."""
+    try:
+        import h5py
+        return h5py
+    except Exception:
+        return None
+
+
+def have_h5py():
+    return _h5py() is not None
 
 
 def save_rgb_state(path, pos, rgb, weight, occupied, max_id, original_pos, minh, maxh, base_height, long_memory):
@@ -60,13 +67,25 @@ def save_token_store(path, pos, cnt, feats, dists, write_h5=True):
     np.save(os.path.join(path, "feat_token_offsets.npy"), off)
     np.save(os.path.join(path, "feat_features.npy"), feats.astype(np.float32))
     np.save(os.path.join(path, "feat_distances.npy"), dists.astype(np.float32))
-    if write_h5 and HAVE_H5PY:          # same groups / datasets the reference creates
-        import h5py
-        with h5py.File(os.path.join(path, "feat.h5df"), "w") as h5f:
-            for i, p in enumerate(pos):
-                g = h5f.create_group(f"grid_{p[0]}_{p[1]}_{p[2]}")
-                g.create_dataset("features", data=feats[off[i]:off[i + 1]], maxshape=(None, feats.shape[1]), chunks=True)
-                g.create_dataset("distances", data=dists[off[i]:off[i + 1]], maxshape=(None,), chunks=True)
+    if write_h5 and have_h5py():
+        write_h5_store(os.path.join(path, "feat.h5df"), pos, cnt, feats, dists)
+
+
+def write_h5_store(h5_path, pos, cnt, feats, dists):
+    """feat.h5df exactly as update_memory_dist_base leaves it (memory_2.py:330-354): one group per voxel named
+    grid_{row}_{col}_{h}; `features` (M, D) f32 and `distances` (M,) f32, both resizable along axis 0."""
+    h5py = _h5py()
+    if h5py is None:
+        raise RuntimeError("writing feat.h5df needs h5py")
+    off = np.zeros(len(cnt) + 1, np.int64)
+    np.cumsum(cnt, out=off[1:])
+    feats = np.asarray(feats, np.float32)
+    dists = np.asarray(dists, np.float32)
+    with h5py.File(h5_path, "w") as h5f:
+        for i, p in enumerate(np.asarray(pos)):
+            g = h5f.create_group(f"grid_{int(p[0])}_{int(p[1])}_{int(p[2])}")
+            g.create_dataset("features", data=feats[off[i]:off[i + 1]], maxshape=(None, feats.shape[1]), chunks=True)
+            g.create_dataset("distances", data=dists[off[i]:off[i + 1]], maxshape=(None,), chunks=True)
 
 
 def load_token_store(path):
@@ -79,7 +98,7 @@ def load_token_store(path):
                 np.load(os.path.join(path, "feat_distances.npy")))
     h5 = os.path.join(path, "feat.h5df")
     if os.path.exists(h5):
-        if not HAVE_H5PY:
+        if not have_h5py():
             raise RuntimeError(f"{h5} is an HDF5 token store but h5py is not installed; convert it with "
                                "bsc_nav_amd.store.convert_h5_store on a machine that has h5py")
         return read_h5_store(h5)
@@ -87,16 +106,20 @@ def load_token_store(path):
 
 
 def read_h5_store(h5_path):
-    import h5py
+    """feat.h5df -> (pos (V,3) i32, cnt (V,) i32, feats (T,D) f32, dists (T,) f32) in h5py iteration order, which is
+    HDF5's native link order = bytewise name order (the tie order of voxel_localized, memory_2.py:623-665)."""
+    h5py = _h5py()
+    if h5py is None:
+        raise RuntimeError("reading feat.h5df needs h5py")
     pos, cnt, feats, dists = [], [], [], []
     with h5py.File(h5_path, "r") as h5f:
         for name in h5f.keys():          # h5py iterates links in name order
             g = h5f[name]
-            f = g["features"][:]
+            f = np.asarray(g["features"][:], np.float32)
             pos.append([int(x) for x in name.split("_")[1:4]])
             cnt.append(f.shape[0])
             feats.append(f)
-            dists.append(g["distances"][:])
+            dists.append(np.asarray(g["distances"][:], np.float32))
     D = feats[0].shape[1] if feats else 0
     return (np.array(pos, np.int32).reshape(-1, 3), np.array(cnt, np.int32),
             np.concatenate(feats) if feats else np.zeros((0, D), np.float32),

@@ -170,9 +170,21 @@ bsc_status bsc_import_cv_map(bsc_ctx *ctx, const uint8_t *cv_map_host);
  * moves the buffers with torch.distributed and hands them back.
  *   bsc_dense_gather : rows of the local map for the given voxel keys -> acc_dev (n,D), cnt_dev (n);
  *                      keys this rank never touched give zeros (mean) / -inf (max) and count 0
- *   bsc_dense_replace: replace the whole map by n merged voxels (keys, acc, cnt) in the given order */
+ *   bsc_dense_gather_rgb : colour state of the same keys -> rgb_dev (n,3) u8, weight_dev (n) f32 (memory_2.py:888-899
+ *                      grid_rgb / weight; weight 0 for keys this rank never touched)
+ *   bsc_dense_replace_full: the map becomes exactly the n voxels handed in, ids 0..n-1 in the given order — keys
+ *                      (grid_rgb_pos), feature rows, counts, rgb and weights together, occupied_ids rebuilt, so every
+ *                      per-id array of the memory directory (memory_2.py:1136-1145) stays aligned.  rgb_dev and
+ *                      weight_dev may both be NULL: colours and weights are zeroed.
+ *   bsc_dense_replace: bsc_dense_replace_full without colours
+ *   bsc_import_heightmap: top-down map state (memory_2.py:98-100,901-903) from host arrays: max_height (gs,gs) f64
+ *                      (-inf = empty) and cv_map (gs,gs,3) u8 — the merged map of several ranks */
 bsc_status bsc_dense_gather(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev /* (n,3) */, float *acc_dev, int32_t *cnt_dev);
+bsc_status bsc_dense_gather_rgb(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, uint8_t *rgb_dev, float *weight_dev);
 bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, const float *acc_dev, const int32_t *cnt_dev);
+bsc_status bsc_dense_replace_full(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, const float *acc_dev,
+                                  const int32_t *cnt_dev, const uint8_t *rgb_dev, const float *weight_dev);
+bsc_status bsc_import_heightmap(bsc_ctx *ctx, const double *max_height_host, const uint8_t *cv_map_host);
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
 bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
 

@@ -30,63 +30,9 @@ sys.path.insert(0, HERE)
 import synth  # noqa: E402
 
 
-# ----------------------------------------------------------------------------
-# in-memory h5py stand-in (only what memory_2.py touches)
-# ----------------------------------------------------------------------------
-class _DS:
-    def __init__(self, data):
-        self.a = np.array(data, copy=True)
+import fake_h5py  # noqa: E402  (in-memory h5py stand-in, name-ordered keys like HDF5)
 
-    @property
-    def shape(self):
-        return self.a.shape
-
-    def resize(self, shape):
-        new = np.zeros(shape, dtype=self.a.dtype)
-        n = min(shape[0], self.a.shape[0])
-        new[:n] = self.a[:n]
-        self.a = new
-
-    def __setitem__(self, k, v):
-        self.a[k] = v
-
-    def __getitem__(self, k):
-        return self.a[k]
-
-
-class _Group(dict):
-    def create_dataset(self, name, data=None, maxshape=None, chunks=None):
-        self[name] = _DS(data)
-        return self[name]
-
-
-class _File:
-    _stores = {}
-
-    def __init__(self, path, mode="r"):
-        self.g = _File._stores.setdefault(path, {})
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-    def __contains__(self, k):
-        return k in self.g
-
-    def __getitem__(self, k):
-        return self.g[k]
-
-    def create_group(self, k):
-        self.g[k] = _Group()
-        return self.g[k]
-
-    def keys(self):
-        return sorted(self.g.keys())  # HDF5 native link order == name order (bytewise)
-
-    def __iter__(self):
-        return iter(self.keys())
+_File = fake_h5py.File
 
 
 def import_reference(ref):
@@ -100,9 +46,7 @@ def import_reference(ref):
                  "diffusers", "ultralytics", "torchvision", "torchvision.transforms", "env", "magnum",
                  "habitat", "transformers", "matplotlib", "matplotlib.pyplot", "matplotlib.colors"]:
         sys.modules[name] = stub(name)
-    h5 = types.ModuleType("h5py")
-    h5.File = _File
-    sys.modules["h5py"] = h5
+    fake_h5py.install()
     sys.path.insert(0, ref)
     import utils as ref_utils  # noqa
     import memory_2 as ref_mem  # noqa

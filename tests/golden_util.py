@@ -91,3 +91,21 @@ def assert_topk_matches(pos, sim, ref_pos, ref_sim, tol=2e-6):
             b = sorted(map(tuple, ref_pos[i:j].tolist()))
             assert a == b, f"top-K near-tie group [{i},{j}) differs"
         i = j
+
+
+def assert_topk_near(pos, sim, ref_pos, ref_sim, tol):
+    """Top-K against an independently computed ranking: scores within `tol`; members of every group of reference
+    scores closer than `tol` to each other (summation-order noise can reorder them) must agree as a set, unless the
+    group touches the K boundary."""
+    pos, ref_pos = np.asarray(pos).reshape(-1, 3), np.asarray(ref_pos).reshape(-1, 3)
+    sim, ref_sim = np.asarray(sim, np.float64).reshape(-1), np.asarray(ref_sim, np.float64).reshape(-1)
+    assert len(pos) == len(ref_pos), (len(pos), len(ref_pos))
+    np.testing.assert_allclose(sim, ref_sim, rtol=0, atol=tol)
+    i, n = 0, len(ref_pos)
+    while i < n:
+        j = i + 1
+        while j < n and abs(ref_sim[j] - ref_sim[j - 1]) <= tol:
+            j += 1
+        if j < n or j - i == 1:
+            assert sorted(map(tuple, pos[i:j].tolist())) == sorted(map(tuple, ref_pos[i:j].tolist())), f"top-K rows [{i},{j}) differ"
+        i = j

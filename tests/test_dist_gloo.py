@@ -13,9 +13,35 @@ import torch.multiprocessing as mp
 
 
 class DictEngine:
-    def __init__(self, mode, D, keys, acc, cnt):
+    """keys (n,3) in local id order, feature rows, counts, colour state and a top-down map, all on the CPU."""
+
+    def __init__(self, mode, D, keys, acc, cnt, rgb=None, w=None, gs=12, seed=0):
+        import types
         self.mode, self.D = mode, D
         self.keys, self.acc, self.cnt = keys, acc, cnt
+        self.device = torch.device("cpu")
+        self.cfg = types.SimpleNamespace(token_dim=D)
+        rs = np.random.RandomState(77 + seed)
+        self.rgb = torch.from_numpy(rs.randint(0, 255, size=(len(keys), 3)).astype(np.uint8)) if rgb is None else rgb
+        self.w = torch.from_numpy(rs.uniform(0.1, 4, size=len(keys)).astype(np.float32)) if w is None else w
+        self.mh = np.where(rs.uniform(size=(gs, gs)) < 0.5, rs.randint(0, 4, size=(gs, gs)).astype(np.float64), -np.inf)
+        self.cv = (rs.randint(1, 255, size=(gs, gs, 3)) * np.isfinite(self.mh)[..., None]).astype(np.uint8)
+
+    def dense_gather_rgb(self, ukeys):
+        lut = {tuple(k.tolist()): i for i, k in enumerate(self.keys)}
+        rgb = torch.zeros((len(ukeys), 3), dtype=torch.uint8)
+        w = torch.zeros(len(ukeys))
+        for i, k in enumerate(ukeys.tolist()):
+            j = lut.get(tuple(k))
+            if j is not None:
+                rgb[i], w[i] = self.rgb[j], self.w[j]
+        return rgb, w
+
+    def export_heightmap(self):
+        return self.mh.copy(), self.cv.copy()
+
+    def import_heightmap(self, mh, cv):
+        self.mh, self.cv = mh.copy(), cv.copy()
 
     def keys_tensor(self):
         return self.keys.clone()
@@ -31,8 +57,10 @@ class DictEngine:
                 acc[i], cnt[i] = self.acc[j], self.cnt[j]
         return acc, cnt
 
-    def dense_replace(self, keys, acc, cnt):
+    def dense_replace(self, keys, acc, cnt, rgb=None, weight=None):
         self.keys, self.acc, self.cnt = keys.clone(), acc.clone(), cnt.clone()
+        self.rgb = torch.zeros((len(keys), 3), dtype=torch.uint8) if rgb is None else rgb.clone()
+        self.w = torch.zeros(len(keys)) if weight is None else weight.clone()
 
     def localize(self, q, K=100, radius=None, curr=None, floor=None):
         rows = self.acc / self.acc.norm(dim=1, keepdim=True).clamp_min(1e-8)
@@ -53,6 +81,7 @@ class DictEngine:
 def _make_rank_map(rank, D, mode):
     rs = np.random.RandomState(10 + rank)
     keys = np.unique(rs.randint(0, 12, size=(150, 3)), axis=0).astype(np.int32)     # heavy overlap between ranks
+    keys = keys[rs.permutation(len(keys))]                                           # local id order is not sorted
     acc = rs.standard_normal((len(keys), D)).astype(np.float32)
     cnt = rs.randint(1, 9, size=len(keys)).astype(np.int32)
     return torch.from_numpy(keys), torch.from_numpy(acc), torch.from_numpy(cnt)
@@ -66,11 +95,15 @@ def _worker(rank, world, port, mode, out_dir):
     D = 8
     bd.warmup_collectives(torch.device("cpu"))      # the collectives bench.py warms up before its clock starts
     keys, acc, cnt = _make_rank_map(rank, D, mode)
-    eng = DictEngine(mode, D, keys, acc, cnt)
+    eng = DictEngine(mode, D, keys, acc, cnt, seed=rank)
+    before = dict(rgb=eng.rgb.clone(), w=eng.w.clone(), mh=eng.mh.copy(), cv=eng.cv.copy())
     info = bd.merge_dense_maps(eng)
     q = torch.from_numpy(np.random.RandomState(99).standard_normal((3, D)).astype(np.float32))
     pos, sim = bd.localize_sharded(eng, q, K=20)
-    torch.save(dict(info=info, keys=eng.keys, acc=eng.acc, cnt=eng.cnt, pos=pos, sim=sim), f"{out_dir}/r{rank}.pt")
+    sl = dict(keys=eng.keys.clone(), acc=eng.acc.clone(), cnt=eng.cnt.clone(), rgb=eng.rgb.clone(), w=eng.w.clone())
+    is_root = bd.gather_merged_to_root(eng, info, root=0)
+    torch.save(dict(info=info, pos=pos, sim=sim, before=before, mh=eng.mh, cv=eng.cv, is_root=is_root,
+                    full=dict(keys=eng.keys, acc=eng.acc, cnt=eng.cnt, rgb=eng.rgb, w=eng.w), **sl), f"{out_dir}/r{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -108,6 +141,35 @@ def test_two_rank_merge_equals_single_process_reduce(tmp_path, mode):
     for k in ref:
         assert got[k][1] == ref[k][1]                                  # counts exact
         assert torch.allclose(got[k][0], ref[k][0], atol=1e-6)        # sums within fp32 order, max exact
+    # ids: global first-touch order = rank 0's voxels in its local order, then rank 1's new voxels in its local order
+    k0 = [tuple(k) for k in _make_rank_map(0, D, mode)[0].tolist()]
+    k1 = [tuple(k) for k in _make_rank_map(1, D, mode)[0].tolist()]
+    seen = set(k0)
+    expect_order = k0 + [k for k in k1 if k not in seen]
+    got_order = [tuple(k) for r in range(world) for k in res[r]["keys"].tolist()]
+    assert got_order == expect_order
+    # the root holds the whole memory after the gather, in that order, rows aligned with the slices
+    assert res[0]["is_root"] and not res[1]["is_root"]
+    full = res[0]["full"]
+    assert [tuple(k) for k in full["keys"].tolist()] == expect_order
+    for name in ("acc", "cnt", "rgb", "w"):
+        assert torch.equal(full[name], torch.cat([res[r][name] for r in range(world)]))
+    # colour state: documented rule (merge_colour_states) — rank 0's state, then rank 1's as one observation
+    lut = [{k: i for i, k in enumerate(kk)} for kk in (k0, k1)]
+    for i, k in enumerate(expect_order):
+        st = [(res[r]["before"]["rgb"][lut[r][k]].double(), float(res[r]["before"]["w"][lut[r][k]])) for r in range(world) if k in lut[r]]
+        c, w = st[0]
+        for c2, w2 in st[1:]:
+            num = (c.float() * np.float32(w)).double() + c2 * w2
+            c = torch.trunc(num / (w + w2))
+            w = float(np.float32(w + w2))
+        assert torch.equal(full["rgb"][i].double(), c) and float(full["w"][i]) == np.float32(w)
+    # top-down map: highest cell wins, ties go to the later rank; identical on both ranks
+    h0, h1 = res[0]["before"]["mh"], res[1]["before"]["mh"]
+    exp_h = np.maximum(h0, h1)
+    exp_c = np.where((h1 >= h0)[..., None], res[1]["before"]["cv"], res[0]["before"]["cv"])
+    for r in range(world):
+        assert np.array_equal(res[r]["mh"], exp_h) and np.array_equal(res[r]["cv"], exp_c)
     # sharded localize == localize over the merged single map, identical on both ranks
     keys = torch.tensor(sorted(ref), dtype=torch.int32)
     acc = torch.stack([ref[tuple(k)][0] for k in keys.tolist()])

@@ -1,0 +1,157 @@
+"""BASELINE.json configs[2..4] at their real sizes on the HIP path (C3: ViT-L/14 tokens 16x16x1024 into a 512^3 grid;
+C4: localize top-K over a 512^3 x 1024-D map; C5: 2^20 voxels x 1024-D, 256 batched queries, voxel-sharded).
+
+The sequential oracle is affordable for a few full-size frames; the 2^20 x 1024 scans are checked against an
+independent fp64 scan (torch matmul in float64 on the same device — not the library), through the sample-threshold
+filter path the library takes for large maps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_dense_ingest_vit_l14_tokens_grid512_against_oracle():
+    """640x480 frames, 16x16x1024 tokens (ViT-L/14 @224, memory_2.py:107 token_dim 1024), 512^3 grid of 0.1 m cells,
+    every pixel, 4 frames in two calls: ids / rgb / weights / top-down map / counts bit-exact, means within 1e-3."""
+    from test_gpu_edges import _dense_vs_oracle
+    longest, n_vox = _dense_vs_oracle(480, 640, 16, 1024, 512, 0.1, -25.6, 25.6, F=4, per_call=2, seed=33, vcap=400_000)
+    assert n_vox > 5000
+
+
+def test_c3_dense_max_mode_1024d_against_oracle():
+    """Same sizes, element-wise max reduce (the scatter-max of the north star): rows bit-exact."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    H, W, g, D, gs, F = 480, 640, 16, 1024, 512, 2
+    rgb, depth, poses = synth.make_frames(34, F, H, W, "room")
+    tokens = synth.make_tokens(34, F, g, D)
+    eng = B.VoxelEngine(H, W, gs, 0.1, -25.6, 25.6, g, D, mode="max", voxel_capacity=300_000, max_points=F * H * W)
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -25.6, 25.6, g, D, mode=2), voxel_capacity=300_000)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    eng.ingest(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(tokens).cuda(), Ts)
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f])
+    (acc, cnt), (oacc, ocnt) = eng.export_dense(), om.export_dense()
+    assert np.array_equal(eng.export_rgb()[0], om.export_rgb()[0]) and np.array_equal(cnt, ocnt)
+    assert np.array_equal(acc, oacc)
+    eng.close()
+
+
+def test_c3_exact_mode_1024d_tokens_against_oracle():
+    """Reference-exact token cache at D=1024, g=16 (the reference's own encoder shape): cache rows, flush with
+    replacement draws, store — bit-exact against the oracle over several in-loop flushes."""
+    import random
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    H, W, g, D, gs, F, s = 240, 320, 16, 1024, 256, 6, 5
+    rgb, depth, poses = synth.make_frames(35, F, H, W, "room")
+    tokens = synth.make_tokens(35, F, g, D)
+    kw = dict(iter_size=6000)
+    eng = B.VoxelEngine(H, W, gs, 0.1, -12.8, 12.8, g, D, mode="exact", voxel_capacity=100_000, token_capacity=400_000,
+                        max_points=H * W, **kw)
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -12.8, 12.8, g, D, mode=0, **kw), voxel_capacity=100_000)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    rs = np.random.RandomState(1)
+    idxs = [np.ascontiguousarray(rs.permutation(H * W)[::s].astype(np.int32)) for _ in range(F)]
+    random.seed(123)
+    for f in range(F):
+        eng.ingest(torch.from_numpy(depth[f:f + 1]).cuda(), torch.from_numpy(rgb[f:f + 1]).cuda(),
+                   torch.from_numpy(tokens[f:f + 1]).cuda(), Ts[f:f + 1], torch.from_numpy(idxs[f]).cuda(),
+                   np.array([0, len(idxs[f])], np.int64))
+    eng.flush()
+    st_dev = eng.export_store()
+    k = eng.counters()
+    random.seed(123)
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], idxs[f], Ts[f], tokens[f])
+    om.flush()
+    ok = om.counters()
+    assert k["flushes"] == ok["flushes"] and k["flushes"] >= 10 and k["max_id"] == ok["max_id"]
+    for a, b in zip(st_dev, om.export_store()):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
+def _big_map(torch, V, D, gs, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    codes = torch.randperm(gs ** 3, device="cuda", generator=gen)[:V]
+    keys = torch.stack([codes // (gs * gs), (codes // gs) % gs, codes % gs], dim=1).to(torch.int32).contiguous()
+    rows = torch.randn((V, D), device="cuda", generator=gen)
+    return keys, rows, gen
+
+
+def _fp64_topk(torch, rows, q, K, mask=None, chunk=1 << 17):
+    """Independent scan: cosine in float64, chunked; -> (idx (Q,K), sim (Q,K)) by descending similarity."""
+    qn = (q.double() / q.double().norm(dim=1, keepdim=True).clamp_min(1e-8))
+    sims = torch.empty((q.shape[0], rows.shape[0]), dtype=torch.float64, device=rows.device)
+    for a in range(0, rows.shape[0], chunk):
+        r = rows[a:a + chunk].double()
+        sims[:, a:a + chunk] = qn @ (r / r.norm(dim=1, keepdim=True).clamp_min(1e-8)).T
+    if mask is not None:
+        sims[:, ~mask] = -2.0
+    top = torch.topk(sims, K, dim=1)
+    return top.indices, top.values
+
+
+@pytest.mark.parametrize("Q", [1, 8, 256])
+def test_c4_c5_localize_2pow20_x_1024_matches_fp64_scan(Q):
+    """C4 / C5 size: 2^20 voxels x 1024-D inside a 512^3 grid, K=100, Q = 1 (text/patch query), 8, 256 (image-goal
+    batch): the library's scan + sample-threshold filter + top-K against the fp64 scan; scores within 2e-6 (north star: 1e-3), same voxels in the same order up to fp32 near-ties."""
+    import torch
+    import bsc_nav_amd as B
+    V, D, gs, K = 1 << 20, 1024, 512, 100
+    keys, rows, gen = _big_map(torch, V, D, gs, 7)
+    eng = B.VoxelEngine(48, 64, gs, 0.1, -25.6, 25.6, 16, D, mode="mean", voxel_capacity=V + 8, max_points=4096)
+    eng.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    pos, sim, n = eng.localize(q, K=K)
+    idx, ref = _fp64_topk(torch, rows, q, K)
+    kk = keys.cpu().numpy()
+    import golden_util as gu
+    for i in range(Q):
+        assert n[i] == K
+        gu.assert_topk_near(pos[i], sim[i], kk[idx[i].cpu().numpy()], ref[i].cpu().numpy(), tol=2e-6)
+    # region + floor filters at this size (memory_2.py:624-640): candidates within a radius of curr and a z-range
+    curr, radius, floor = [256, 256, 256], 120.0, (100, 400)
+    pos, sim, n = eng.localize(q[:min(Q, 8)], K=K, radius=radius, curr=curr, floor=floor)
+    k64 = keys.to(torch.int64)
+    mask = (((k64 - torch.tensor(curr, device="cuda")) ** 2).sum(1) <= radius * radius) & (k64[:, 2] >= floor[0]) & (k64[:, 2] <= floor[1])
+    idx, ref = _fp64_topk(torch, rows, q[:min(Q, 8)], K, mask)
+    for i in range(min(Q, 8)):
+        assert n[i] == K
+        gu.assert_topk_near(pos[i], sim[i], kk[idx[i].cpu().numpy()], ref[i].cpu().numpy(), tol=2e-6)
+    eng.close()
+
+
+def test_c5_voxel_sharded_localize_equals_single_map():
+    """C5's partitioning on one GPU: the 2^20 x 1024 map split into 8 voxel shards (one engine each, as 8 ranks would
+    hold them), 256 queries scanned per shard, K-way merge in the reference's tie order (dist.merge_topk) == the scan of
+    the whole map."""
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dist as bd
+    V, D, gs, K, Q, R = 1 << 20, 1024, 512, 100, 256, 8
+    keys, rows, gen = _big_map(torch, V, D, gs, 8)
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    ones = torch.ones(V, dtype=torch.int32, device="cuda")
+    full = B.VoxelEngine(48, 64, gs, 0.1, -25.6, 25.6, 16, D, mode="mean", voxel_capacity=V + 8, max_points=4096)
+    full.dense_replace(keys, rows, ones)
+    p0, s0, n0 = full.localize(q, K=K)
+    full.close()
+    per = V // R
+    shard = B.VoxelEngine(48, 64, gs, 0.1, -25.6, 25.6, 16, D, mode="mean", voxel_capacity=per + 8, max_points=4096)
+    parts = []
+    for r in range(R):
+        sl = slice(r * per, (r + 1) * per)
+        shard.dense_replace(keys[sl].contiguous(), rows[sl].contiguous(), ones[sl].contiguous())
+        parts.append(shard.localize(q, K=K))
+    shard.close()
+    for i in range(Q):
+        p, s = bd.merge_topk([pp[0][i, :pp[2][i]] for pp in parts], [pp[1][i, :pp[2][i]] for pp in parts], K)
+        assert np.array_equal(p, p0[i]) and np.array_equal(s, s0[i])

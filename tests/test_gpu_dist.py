@@ -1,0 +1,125 @@
+"""Frame-sharded build with REAL engines: two processes (gloo, 127.0.0.1) share the one GPU of the test box, each ingests
+its contiguous frame block through libbscnav, the maps are merged (dist.merge_dense_maps), collected on rank 0
+(dist.gather_merged_to_root), saved as a memory directory — and that directory, loaded into a fresh single-process
+object, equals the memory one process builds from all frames: ids / positions / occupied_ids / counts / top-down map
+bit-exact, features within 1e-3, weights within f32 rounding, rgb by the documented merge rule, identical top-K
+(the reference itself is single-process, memory_2.py:888-903 / :1136-1145 define the state)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+H, W, G, D, GS, F = 96, 128, 8, 32, 128, 8
+
+
+def _args(tmp, name):
+    import bsc_nav_amd as B
+    return B.MemoryArgs(width=W, height=H, grid_size=GS, cell_size=0.1, floor_height=-6.4, map_height=6.4,
+                        depth_sample_rate=1, query_width=G * 14, query_height=G * 14, token_dim=D, memory_path=str(tmp),
+                        scene_name=name)
+
+
+def _inputs():
+    import synth
+    rgb, depth, poses = synth.make_frames(41, F, H, W, "room")
+    tokens = synth.make_tokens(41, F, G, D)
+    return rgb, depth, poses, tokens
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dist as bd
+    rgb, depth, poses, tokens = _inputs()
+    mem = B.VoxelTokenMemory(_args(out_dir, "merged"), need_diffusion=False, feature_mode=mode, max_frames_per_call=F,
+                             voxel_capacity=100_000)
+    mem.set_map_origin(poses[0])                                   # every rank writes into the scene's map frame
+    a, b = bd.shard_frames(F)
+    dev = lambda x: torch.from_numpy(x[a:b]).cuda().contiguous()   # noqa: E731
+    mem.ingest_frames(dev(rgb), dev(depth), poses[a:b], tokens=dev(tokens))
+    mem.base_height.append(float(rank))
+    mem.long_memory_dict.append({"label": "chair", "loc": [10 * rank, 5, 5], "confidence": 0.5 + 0.1 * rank})
+    local_voxels = mem.max_id
+    info = bd.merge_dense_maps(mem.engine)                         # rows now distributed: slice `rank` of the global order
+    q = torch.from_numpy(np.random.RandomState(5).standard_normal((2, D)).astype(np.float32)).cuda()
+    sp, ss = bd.localize_sharded(mem.engine, q, K=50)              # every rank scans its slice, K-way merge
+    # the public entry: merge (again: merging an already merged map must change nothing) + collect on rank 0
+    is_root = mem.merge_shards(root=0)
+    if is_root:
+        mem.initial_memory()
+        mem.save_memory(original_pos=np.asarray(poses[0][:3], np.float32))
+        mh, cv = mem.engine.export_heightmap()
+        np.savez(f"{out_dir}/root.npz", path=np.array(mem.memory_save_path), mh=mh, cv=cv, n_union=info["n_union"])
+    np.savez(f"{out_dir}/r{rank}.npz", local_voxels=local_voxels, n_local=info["n_local"], per=info["per_rank"],
+             sp0=sp[0], ss0=ss[0], sp1=sp[1], ss1=ss[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["mean", "max"])
+def test_two_process_sharded_build_equals_single_process(tmp_path, mode):
+    import torch
+    import torch.multiprocessing as mp
+    import bsc_nav_amd as B
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    root = np.load(f"{tmp_path}/root.npz")
+    ranks = [np.load(f"{tmp_path}/r{r}.npz") for r in range(world)]
+    # ---- the same frames through ONE process ----
+    rgb, depth, poses, tokens = _inputs()
+    one = B.VoxelTokenMemory(_args(tmp_path, "single"), need_diffusion=False, feature_mode=mode, max_frames_per_call=F,
+                             voxel_capacity=100_000)
+    one.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+    n = one.max_id
+    assert int(root["n_union"]) == n and sum(int(r["n_local"]) for r in ranks) == n
+    assert all(int(r["local_voxels"]) < n for r in ranks)          # the shards really saw different voxel sets
+    # ---- the saved merged directory, loaded like any memory ----
+    args = _args(tmp_path, "loaded")
+    args.load_memory_path = str(root["path"])
+    got = B.VoxelTokenMemory(args, need_diffusion=False, feature_mode=mode, voxel_capacity=100_000)
+    got.load_memory()
+    assert got.max_id == n
+    assert np.array_equal(got.grid_rgb_pos, one.grid_rgb_pos)       # ids in the single-process first-touch order
+    assert np.array_equal(got.occupied_ids, one.occupied_ids)
+    (gacc, gcnt), (oacc, ocnt) = got.engine.export_dense(), one.engine.export_dense()
+    assert np.array_equal(gcnt, ocnt)                               # counts exact
+    if mode == "max":
+        assert np.array_equal(gacc, oacc)
+    else:
+        c = np.maximum(ocnt, 1)[:, None].astype(np.float64)
+        np.testing.assert_allclose(gacc / c, oacc / c, rtol=1e-3, atol=1e-3)
+    omh, ocv = one.engine.export_heightmap()
+    assert np.array_equal(root["mh"], omh) and np.array_equal(root["cv"], ocv)      # top-down map exact
+    np.testing.assert_allclose(got.weight, one.weight, rtol=2e-6)                  # f32 sums in a different order
+    # rgb: documented dense-mode rule (a rank's state enters the running mean as one observation), not the sequential
+    # truncating chain; voxels seen by one rank only are bit-exact, the others stay close
+    drgb = np.abs(got.grid_rgb.astype(np.int32) - one.grid_rgb.astype(np.int32))
+    assert (drgb == 0).mean() > 0.5 and drgb.mean() < 2.0 and np.percentile(drgb, 99) <= 16
+    assert np.load(str(root["path"]) + "/base_height.npy").tolist() == [0.0, 1.0]       # rank order
+    assert sorted(o["loc"][0] for o in got.long_memory_dict) == [0, 10]
+    # ---- identical top-K: sharded scan (before the gather), the loaded merged memory, the single-process memory ----
+    q = torch.from_numpy(np.random.RandomState(5).standard_normal((2, D)).astype(np.float32)).cuda()
+    p1, s1, n1 = one.engine.localize(q, K=50)
+    p2, s2, n2 = got.engine.localize(q, K=50)
+    for qi in range(2):
+        assert n1[qi] == n2[qi] == 50
+        gu.assert_topk_near(p2[qi], s2[qi], p1[qi], s1[qi], tol=5e-6)
+        for r in ranks:                                             # both ranks hold the same merged answer
+            gu.assert_topk_near(r[f"sp{qi}"], r[f"ss{qi}"], p1[qi], s1[qi], tol=5e-6)

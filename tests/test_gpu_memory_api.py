@@ -301,3 +301,132 @@ def test_fused_encoder_ends_match_pytorch(arch):
     assert a32.shape == (2, g, g, vit.width) and a32.dtype == torch.float32 and a16.dtype == torch.bfloat16
     assert torch.equal(a16.float(), a32)                      # the f32 output is the bf16 result widened
     assert (a32 - b).abs().max().item() < 0.2 and (a32 - b).abs().mean().item() < 0.012
+
+
+def _write_reference_dir(path, z, name, store_arrays=None):
+    """A memory directory as the reference leaves it (memory_2.py:1136-1145): npy set + long_memory.json; the token store
+    only as feat.h5df (through the stand-in) when `store_arrays` is given."""
+    import json
+    gs, cs, fh, mh = int(z["grid"][0]), float(z["grid"][1]), float(z["grid"][2]), float(z["grid"][3])
+    minh, maxh = int(fh / cs), int(mh / cs)
+    pos, rgb, w = z[f"{name}_pos"], z[f"{name}_rgb"], z[f"{name}_weight"]
+    occ = np.full((gs, gs, maxh - minh), -1, np.int32)
+    occ[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(len(pos))
+    os.makedirs(path, exist_ok=True)
+    np.save(path + "/grid_rgb_pos.npy", pos); np.save(path + "/grid_rgb.npy", rgb); np.save(path + "/weight.npy", w)
+    np.save(path + "/occupied_ids.npy", occ); np.save(path + "/max_id.npy", np.array(len(pos)))
+    np.save(path + "/original_pos.npy", np.array([1.0, float(z[f"{name}_current_height"]), -2.0], np.float32))
+    np.save(path + "/map_height.npy", np.array([minh, maxh])); np.save(path + "/base_height.npy", z[f"{name}_base_height"])
+    zlo, zhi = int(pos[:, 2].min()), int(pos[:, 2].max())
+    with open(path + "/long_memory.json", "w") as f:
+        json.dump([{"label": "chair", "loc": [3, 4, zlo + 1], "confidence": 0.9},
+                   {"label": "sofa", "loc": [7, 8, zhi - 1], "confidence": 0.8}], f)
+    if store_arrays is not None:
+        from bsc_nav_amd import store
+        store.write_h5_store(path + "/feat.h5df", *store_arrays)
+        open(path + "/feat.h5df", "w").close()
+    return gs, cs, fh, mh
+
+
+@pytest.mark.parametrize("name", ["one_floor", "two_floors_high", "three_floors_mid_with_noise", "few_samples"])
+def test_load_memory_single_floor_matches_reference(tmp_path, name):
+    """--load_single_floor (the flag of every README benchmark command): a reference-layout directory whose token store
+    exists only as feat.h5df is loaded; floor heights / z-range / per-floor files / long-memory filter equal the
+    reference's own load_memory outputs (g8_floor_split.npz) and voxel_localized only returns voxels of that floor."""
+    import sys
+    import torch
+    import bsc_nav_amd as B
+    import fake_h5py
+    z = gu.load("g8_floor_split")
+    saved = sys.modules.get("h5py")
+    fake_h5py.install()
+    try:
+        pos = z[f"{name}_pos"]
+        rs = np.random.RandomState(5)
+        D = 16
+        # exact-mode token store: 1..3 tokens per voxel, in HDF5 name order
+        from bsc_nav_amd import dist as bd
+        k0, k1, k2 = bd.name_keys_np(pos)
+        order = np.lexsort((k2, k1, k0))
+        spos = pos[order]
+        cnt = rs.randint(1, 4, size=len(spos)).astype(np.int32)
+        feats = rs.standard_normal((int(cnt.sum()), D)).astype(np.float32)
+        dists = rs.uniform(0.1, 9, size=int(cnt.sum())).astype(np.float32)
+        d = str(tmp_path / "scene")
+        gs, cs, fh, mh = _write_reference_dir(d, z, name, (spos, cnt, feats, dists))
+        args = B.MemoryArgs(width=64, height=48, grid_size=gs, cell_size=cs, floor_height=fh, map_height=mh,
+                            query_width=56, query_height=56, token_dim=D, memory_path=str(tmp_path), scene_name="other",
+                            load_memory_path=d, load_single_floor=True)
+        mem = B.VoxelTokenMemory(args, need_diffusion=False, voxel_capacity=100, token_capacity=64)   # too small on purpose
+        mem.load_memory()
+        assert mem.engine.cfg.voxel_capacity >= len(pos) and mem.engine.cfg.token_capacity >= len(feats)
+        np.testing.assert_array_equal(np.array(mem.floor_heights), z[f"{name}_floor_heights"])
+        assert mem.num_floors == int(z[f"{name}_num_floors"])
+        assert [mem.floor_min_height, mem.floor_max_height] == z[f"{name}_range"].tolist()
+        k = int(z[f"{name}_current_floor"])
+        assert np.array_equal(np.load(d + f"/grid_rgb_pos_floor_{k}.npy"), z[f"{name}_floor_pos"])
+        assert np.array_equal(np.load(d + f"/grid_rgb_floor_{k}.npy"), z[f"{name}_floor_rgb"])
+        assert [o["label"] for o in mem.long_memory_filter()] == [str(s) for s in z[f"{name}_long_memory_filtered"]]
+        assert np.array_equal(mem.grid_rgb_pos, pos) and np.array_equal(mem.weight, z[f"{name}_weight"])
+        # the scan honours the floor z-range (memory_2.py:633-640): same answer as an explicit NumPy scan of the floor
+        q = rs.standard_normal(D).astype(np.float32)
+        top1, tpos, tsim = mem.voxel_localized(torch.from_numpy(q), K=30)
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        fn = feats / np.maximum(np.linalg.norm(feats, axis=1, keepdims=True), 1e-8)
+        sims = fn @ (q / np.linalg.norm(q))
+        best = np.array([sims[off[i]:off[i + 1]].max() for i in range(len(spos))])
+        on_floor = (spos[:, 2] >= mem.floor_min_height) & (spos[:, 2] <= mem.floor_max_height)
+        cand = np.flatnonzero(on_floor)
+        top = cand[np.argsort(-best[cand], kind="stable")[:30]]
+        assert len(tpos) == min(30, len(cand)) and np.all((tpos[:, 2] >= mem.floor_min_height) & (tpos[:, 2] <= mem.floor_max_height))
+        assert np.array_equal(tpos, spos[top].astype(np.int64))
+        np.testing.assert_allclose(tsim, best[top], atol=3e-6, rtol=0)
+        # exported arrays are cached between map changes (BSCAgent.py:179-218 reads them repeatedly)
+        assert mem.occupied_ids is mem.occupied_ids and mem.grid_rgb is mem.grid_rgb
+    finally:
+        if saved is None:
+            sys.modules.pop("h5py", None)
+        else:
+            sys.modules["h5py"] = saved
+
+
+def test_exact_mode_defaults_to_reference_exact_alpha(tmp_path):
+    """feature_mode='exact' without an explicit alpha_source reproduces the reference's rgb bytes bit for bit."""
+    z = gu.load("g2_mini_s7_yaw")
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    import bsc_nav_amd as B
+    args = B.MemoryArgs(width=cfg["W"], height=cfg["H"], grid_size=cfg["gs"], cell_size=cfg["cs"],
+                        floor_height=cfg["floor_height"], map_height=cfg["map_height"], depth_sample_rate=cfg["s"],
+                        query_width=cfg["g"] * 14, query_height=cfg["g"] * 14, memory_path=str(tmp_path), token_dim=cfg["D"])
+    dino = FakeDino(tokens)
+    mem = B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False)
+    assert mem.alpha_source == "host" and B.VoxelTokenMemory(args, need_diffusion=False, feature_mode="mean").alpha_source == "device"
+    np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    for f in range(cfg["F"]):
+        dino.frame = f
+        mem.obs2voxeltoken({"rgb": rgb[f], "depth": depth[f]}, poses[f])
+    assert np.array_equal(mem.grid_rgb, z["grid_rgb"]) and np.array_equal(mem.weight, z["weight"])
+
+
+def test_ingest_frames_with_a_forward_features_only_encoder(tmp_path):
+    """An encoder that only has the reference's forward_features contract (a real DINOv2) works in the batched entry."""
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import synthetic
+    H, W, g, D, F = 48, 64, 4, 16, 3
+
+    class Dino:
+        def forward_features(self, x):
+            assert x.shape[1:] == (3, 56, 56) and x.dtype == torch.float32
+            t = x.reshape(x.shape[0], 3, g, 14, g, 14).mean(dim=(3, 5)).permute(0, 2, 3, 1).reshape(x.shape[0], g * g, 3)
+            return {"x_norm_patchtokens": torch.cat([t, torch.ones(x.shape[0], g * g, D - 3, device=x.device)], -1)}
+
+    args = B.MemoryArgs(width=W, height=H, grid_size=128, floor_height=-6.4, map_height=6.4, depth_sample_rate=1,
+                        query_width=56, query_height=56, token_dim=D, memory_path=str(tmp_path))
+    mem = B.VoxelTokenMemory(args, preload_dino=Dino(), need_diffusion=False, feature_mode="mean", max_frames_per_call=F)
+    poses = synthetic.random_walk_poses(3, F)
+    rgb, depth, _ = synthetic.make_frames(3, F, H, W, "room", poses=poses)
+    mem.ingest_frames(rgb, depth, poses)
+    acc, cnt = mem.engine.export_dense()
+    assert mem.max_id > 100 and np.isfinite(acc).all() and int(cnt.sum()) == mem.engine.counters()["points_passed"]
+    np.testing.assert_allclose(acc[:, 3:] / cnt[:, None], 1.0, rtol=1e-5)
