@@ -7,11 +7,10 @@
 #include "../../include/bscnav.h"
 
 typedef unsigned long long u64;
-// per-point payload of the rgb chain: one 16-byte gather per point instead of an 8-byte and a 4-byte one
-struct alignas(16) PointRec {
-    double alpha;      // exp(-r^2 / 1.2)   (memory_2.py:875)
+// per-point payload of the rgb chain: one 12-byte gather per point
+struct PointRec {
+    uint32_t alo, ahi; // exp(-r^2 / 1.2) as a double, low / high word   (memory_2.py:875)
     uint32_t rgbv;     // rgb[py, px] packed r | g << 8 | b << 16   (memory_2.py:870)
-    uint32_t pad;
 };
 #define BSC_EV_RING 512
 
@@ -34,7 +33,8 @@ enum {
     DS_B_NPSEG = 14,    // batch: voxel segments of the sorted pair list
     DS_PAIR_TOTAL = 15, // dense: pairs reduced since creation
     DS_B_NRUN = 16,     // batch: runs of consecutive points that fall into the same cell
-    DS_COUNT = 17
+    DS_B_NNEW = 17,     // batch: cells listed as new by their first claimer (== new voxels; before the capacity clip)
+    DS_COUNT = 18
 };
 
 struct bsc_ctx {
@@ -51,6 +51,9 @@ struct bsc_ctx {
     float *weight;     // (vcap)
     u64 *hmap;         // (gs,gs) packed (h+1)<<40 | order  (max_height + tie order)
     uint8_t *cv_map;   // (gs,gs,3)
+    // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
+    bool geom_fast;
+    uint8_t *pat_x, *pat_y;   // (W), (H): patch column / row of a pixel column / row, 255 = outside the patch grid
     int64_t *dscal;    // DS_COUNT device scalars
     int64_t *hscal;    // pinned host mirror for readbacks
     // exact mode
@@ -71,20 +74,20 @@ struct bsc_ctx {
     uint32_t *p_patf;
     PointRec *p_rec_s[2];    // double-buffered: read by the rgb chain on the side stream
     float *p_r2f;
-    int64_t *p_scan_in, *p_scan_out;
     // Points are ordered per voxel through their RUNS (maximal stretches of consecutive points in one cell; a 10 cm
     // voxel a few metres away covers ~16 pixels of an image row): the runs are sorted by voxel id (stable radix sort
     // keeps the order j inside a voxel) and expanded back into the per-voxel point order the rgb chain walks.
-    int32_t *run_j0;                    // first point of run r (runs in order j)
-    uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id, value = r (also scratch of the Morton sort)
-    uint32_t *skey_b_s[2];              // sorted run keys
-    uint32_t *run_val_b;                // sorted run indices
-    int32_t *run_len, *run_off;         // sorted runs: length, exclusive prefix = position in the per-voxel point order
-    int32_t *run_heads;                 // sorted-run index of every voxel's first run (ascending)
-    uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel (read by the rgb chain)
-    int4 *seg_info_s[2];                // per voxel segment: {first k, end k, voxel id, -}
-    int32_t *blk_cnt, *blk_off;         // per-block head counts / offsets (deterministic compaction)
+    int32_t *new_cells;                 // cells claimed for the first time in this batch (one entry per new voxel)
+    int32_t *blk_cnt, *blk_off;         // per 1024-point block: runs (count / exclusive prefix); also head compaction
+    int32_t *blk_pass, *blk_pass_off;   // per block: passing points
     int64_t nblk_cap;
+    uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id | (length - 1) << id bits, value = first point
+    uint32_t *skey_b_s[2];              // sorted run keys
+    uint32_t *run_val_b;                // sorted run values
+    int64_t *run_scan;                  // exclusive scan of (length | segment head << 32) over the sorted runs
+    int32_t *seg_k0, *seg_vid;          // voxel segments of the point order: first position, voxel id
+    uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel (read by the rgb chain)
+    int4 *seg_info_s[2];                // per voxel segment: {first k, end k, voxel id, rank in the length-class order}
     u64 *f_keys_a, *f_keys_b;  // flush-private sort buffers (iter_size)
     int32_t *pass_list;
     int32_t *seg_last_s[2];
@@ -169,6 +172,9 @@ bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, 
 bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
 bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
 bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
+// exclusive scan over sorted run keys (voxel id | (length - 1) << vb; id field all ones = no voxel) of
+// length | (first run of its voxel) << 32
+bsc_status prim_scan_runs(bsc_ctx *x, const uint32_t *keys_sorted, int vb, int64_t *out, size_t n);
 
 // ---- kernels launchers ----
 bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *idx, int64_t P, uint8_t *flags,
@@ -188,7 +194,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                         const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
                         const double *alpha, bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
-bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels);
+bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels, const uint32_t *p_patf);
 bsc_status frontier_mask_impl(bsc_ctx *x, const uint8_t *navigable_host, uint8_t *mask_host);
 bsc_status frontier_clusters_impl(bsc_ctx *x, const uint8_t *frontier_host, int32_t min_cluster_size, int32_t ig_radius,
                                   int32_t max_clusters, int32_t *n_clusters_host, int32_t *labels_host,
@@ -197,7 +203,6 @@ bsc_status frontier_clusters_impl(bsc_ctx *x, const uint8_t *frontier_host, int3
 bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, int n_frames);
 // list of segment starts of a sorted key array (segments = runs of equal key >> shift; keys == invalid are skipped);
 // the number of segments is written to *count_dev.  Deterministic: per-block counts + exclusive scan.
-bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev);
 bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev);
 bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, double radius, const int32_t *curr,
                          int32_t floor_lo, int32_t floor_hi, int32_t *out_pos, float *out_sim, int32_t *out_count);

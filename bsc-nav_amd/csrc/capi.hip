@@ -92,6 +92,28 @@ static bsc_status reset_state(bsc_ctx *x)
     return BSC_OK;
 }
 
+// Fast-geometry preconditions (geometry_dev.h): pinhole structure of K, Kinv, Kpatch, and per-pixel patch tables.
+// The patch index int(u - 0.5), u = (Kp (Kinv p2d z))[0] / z (utils.py:208-214 with get_sim_cam_mat, memory_2.py:871),
+// is evaluated per pixel column / row in extended precision; the fp64 chain of the reference differs from it by a few
+// ulps (< 1e-13), so the table is exact when no value lies within 1e-9 of an integer — otherwise (a pixel centre on a
+// patch boundary) the generic per-point chain stays in charge.
+static bool pinhole(const double *m)
+{
+    return m[1] == 0.0 && m[3] == 0.0 && m[6] == 0.0 && m[7] == 0.0 && m[8] == 1.0 && m[0] != 0.0 && m[4] != 0.0;
+}
+
+static bool patch_table(int n, double kinv_a, double kinv_b, double kp_a, double kp_b, int g, uint8_t *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const long double a = (long double)kinv_a * ((long double)i + 0.5L) + (long double)kinv_b;
+        const long double u = (long double)kp_a * a + (long double)kp_b - 0.5L;
+        if (fabsl(u - rintl(u)) < 1e-9L) return false;
+        const long t = (long)truncl(u);                    // int() truncates toward zero (utils.py:212-213)
+        out[i] = (t >= 0 && t < g) ? (uint8_t)t : (uint8_t)255;
+    }
+    return true;
+}
+
 extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hip_stream, bsc_ctx **out)
 {
     if (!cfg || !out) { bsc_set_error("bsc_create: null argument"); return BSC_E_INVALID; }
@@ -133,6 +155,22 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->cv_map, 3 * gs2);
     ALLOC(x->dscal, DS_COUNT);
     BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * DS_COUNT));
+    ALLOC(x->pat_x, c.width);
+    ALLOC(x->pat_y, c.height);
+    {
+        uint8_t *tx = (uint8_t *)malloc(c.width), *ty = (uint8_t *)malloc(c.height);
+        x->geom_fast = getenv("BSC_GENERIC_GEOMETRY") == nullptr && c.patch_grid < 255 && pinhole(c.K) && pinhole(c.Kinv) &&
+                       pinhole(c.Kpatch) && c.width < (1 << 24) / c.height &&
+                       patch_table(c.width, c.Kinv[0], c.Kinv[2], c.Kpatch[0], c.Kpatch[2], c.patch_grid, tx) &&
+                       patch_table(c.height, c.Kinv[4], c.Kinv[5], c.Kpatch[4], c.Kpatch[5], c.patch_grid, ty);
+        hipError_t e = hipSuccess;
+        if (x->geom_fast) {
+            e = hipMemcpy(x->pat_x, tx, c.width, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(x->pat_y, ty, c.height, hipMemcpyHostToDevice);
+        }
+        free(tx); free(ty);
+        if (e != hipSuccess) { bsc_set_error("bsc_create: patch tables: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
+    }
     if (c.mode == BSC_MODE_EXACT) {
         if (c.token_capacity <= 0) { bsc_set_error("bsc_create: token_capacity"); bsc_destroy(x); return BSC_E_INVALID; }
         ALLOC(x->cache_f, (int64_t)c.iter_size * D);
@@ -152,11 +190,11 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         ALLOC(x->acnt, vcap + 1);
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
-    ALLOC(x->p_scan_in, np / 1024 + 16); ALLOC(x->p_scan_out, np / 1024 + 16);   // per-block (first << 32 | pass) totals
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
-    ALLOC(x->run_j0, np + 1); ALLOC(x->run_val_b, np); ALLOC(x->run_len, np); ALLOC(x->run_off, np); ALLOC(x->run_heads, np);
+    ALLOC(x->new_cells, np); ALLOC(x->run_val_b, np); ALLOC(x->run_scan, np); ALLOC(x->seg_k0, np); ALLOC(x->seg_vid, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
+    ALLOC(x->blk_pass, x->nblk_cap); ALLOC(x->blk_pass_off, x->nblk_cap);
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
         ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
@@ -207,11 +245,11 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     hipSetDevice(x->device);
     if (x->side) hipStreamSynchronize(x->side);
     hipStreamSynchronize(x->stream);
-    void *ptrs[] = {x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
+    void *ptrs[] = {x->pat_x, x->pat_y, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
-                    x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->p_scan_in, x->p_scan_out,
+                    x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->new_cells, x->run_scan, x->seg_k0, x->seg_vid, x->blk_pass, x->blk_pass_off,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
-                    x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_info_s[0], x->seg_info_s[1], x->run_j0, x->run_val_b, x->run_len, x->run_off, x->run_heads,
+                    x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_info_s[0], x->seg_info_s[1], x->run_val_b,
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,

@@ -4,13 +4,14 @@
 // unique (voxel, frame, patch) PAIR with its multiplicity:
 //
 //   k_keys_pairs   one workgroup per tile of 1024 points (32x32 pixel tiles when every pixel is ingested,
-//                  1024 consecutive points otherwise).  Aggregates the tile's (voxel, frame, patch) codes in an LDS hash table
-//                  (ds_cmpst_b64 insert + ds_add count); the distinct pairs are appended to a global list.
+//                  1024 consecutive points otherwise).  Aggregates the tile's (cell, frame, patch) codes in an LDS hash
+//                  table (ds_cmpst_b64 insert + ds_add count); the distinct pairs are appended to a global list.
 //                  A 10 cm voxel 2 m away covers ~16x16 pixels, so a tile collapses 1024 points to a
-//                  handful of pairs.
-//   radix sort     of the pair list by (voxel, frame, patch) -> each voxel's pairs are contiguous and equal
+//                  handful of pairs.  The voxel is named by the MORTON code of its cell (row, col, h), not by its id:
+//                  the pairs do not wait for the ids, and the sorted list walks the voxels in a spatially coherent order.
+//   radix sort     of the pair list by (cell code, frame, patch) -> each voxel's pairs are contiguous and equal
 //                  codes coming from neighbouring tiles are adjacent.
-//   k_pair_heads   voxel segments of the sorted pair list.
+//   compact_heads  voxel segments of the sorted pair list.
 //   k_dense_reduce one wavefront per voxel: merges equal codes (integer multiplicities, so the result does
 //                  not depend on the order tiles were appended in), accumulates multiplicity x token row with
 //                  16-byte loads (lanes stride D, 1 KiB per wave-instruction, token tile L2 / MALL resident)
@@ -31,25 +32,66 @@ __device__ __forceinline__ u64 mix64(u64 x)
     return x;
 }
 
-template <bool PAIRS>
-__global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int H, int W, int tx_n, int ty_n,
-                                                    const int32_t *__restrict__ p_cell, const int32_t *__restrict__ occ,
-                                                    const uint32_t *__restrict__ p_patf, u64 *__restrict__ pstage_key,
-                                                    uint32_t *__restrict__ pstage_cnt, int32_t *__restrict__ tile_cnt,
-                                                    int pb, int cb)
+// ---- cell <-> sort code -------------------------------------------------------------------------------------------
+// Morton interleave of (row, col, h), `ab` bits per axis (ab = 0: the linear cell index itself, for grids whose Morton
+// code would not fit beside the frame / patch bits).  Spatially adjacent voxels see the same patches in every frame, so
+// walking the voxel segments in this order keeps the working set of token rows of concurrently running wavefronts small.
+struct CellCode {
+    int ab;        // bits per axis (0 = linear)
+    int gs, nh;
+};
+__device__ __forceinline__ u64 spread3(u64 v)       // 21 bits -> every third bit
 {
-    __shared__ u64 hkey[PAIRS ? PT_HS : 1];
-    __shared__ uint32_t hcnt[PAIRS ? PT_HS : 1];
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__device__ __forceinline__ u64 compact3(u64 v)
+{
+    v &= 0x1249249249249249ull;
+    v = (v ^ (v >> 2)) & 0x10c30c30c30c30c3ull;
+    v = (v ^ (v >> 4)) & 0x100f00f00f00f00full;
+    v = (v ^ (v >> 8)) & 0x1f0000ff0000ffull;
+    v = (v ^ (v >> 16)) & 0x1f00000000ffffull;
+    v = (v ^ (v >> 32)) & 0x1fffffull;
+    return v;
+}
+__device__ __forceinline__ u64 cell_to_code(const CellCode &cc, int32_t cell)
+{
+    if (cc.ab == 0) return (u64)(uint32_t)cell;
+    const int32_t h = cell % cc.nh, rc = cell / cc.nh;
+    return (spread3((u64)(rc / cc.gs)) << 2) | (spread3((u64)(rc % cc.gs)) << 1) | spread3((u64)h);
+}
+__device__ __forceinline__ int32_t code_to_cell(const CellCode &cc, u64 code)
+{
+    if (cc.ab == 0) return (int32_t)code;
+    const int32_t row = (int32_t)compact3(code >> 2), col = (int32_t)compact3(code >> 1), h = (int32_t)compact3(code);
+    return (row * cc.gs + col) * cc.nh + h;
+}
+
+// p_patf == nullptr: every pixel is a point (tiled2d) and the patch is a function of the pixel (pat_x / pat_y tables of
+// the fast geometry); otherwise frame << 16 | patch per point.
+__global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int H, int W, int tx_n, int ty_n, CellCode cc,
+                                                    const int32_t *__restrict__ p_cell, const uint32_t *__restrict__ p_patf,
+                                                    const uint8_t *__restrict__ pat_x, const uint8_t *__restrict__ pat_y, int g,
+                                                    u64 *__restrict__ pstage_key, uint32_t *__restrict__ pstage_cnt,
+                                                    int32_t *__restrict__ tile_cnt, int pb, int cb)
+{
+    __shared__ u64 hkey[PT_HS];
+    __shared__ uint32_t hcnt[PT_HS];
     __shared__ int nloc;
     const int tid = threadIdx.x;
-    if (PAIRS) {
-        for (int s = tid; s < PT_HS; s += TPB) { hkey[s] = ~0ull; hcnt[s] = 0u; }
-        if (tid == 0) nloc = 0;
-        __syncthreads();
-    }
+    for (int s = tid; s < PT_HS; s += TPB) { hkey[s] = ~0ull; hcnt[s] = 0u; }
+    if (tid == 0) nloc = 0;
+    __syncthreads();
     const int64_t tile = blockIdx.x;
     int64_t jbase = tile * PT_TILE;
     int x0 = 0, y0 = 0;
+    uint32_t frame = 0;
     if (tiled2d) {
         const int per_frame = tx_n * ty_n;
         const int64_t f = tile / per_frame;
@@ -57,69 +99,65 @@ __global__ __launch_bounds__(TPB) void k_keys_pairs(int64_t P, int tiled2d, int 
         y0 = (r / tx_n) * 32;
         x0 = (r % tx_n) * 32;
         jbase = f * (int64_t)H * W;
+        frame = (uint32_t)f;
     }
     // all loads of the thread's four points are issued before the first dependent use (clamped addresses, no branches)
     int32_t cell[PT_TILE / TPB];
     uint32_t patf[PT_TILE / TPB];
-    bool in[PT_TILE / TPB];
 #pragma unroll
     for (int r = 0; r < PT_TILE / TPB; ++r) {
         const int l = tid + r * TPB;
         int64_t j;
+        bool in;
+        int x = 0, y = 0;
         if (tiled2d) {
-            const int y = y0 + (l >> 5), x = x0 + (l & 31);
-            in[r] = x < W && y < H;
+            y = y0 + (l >> 5); x = x0 + (l & 31);
+            in = x < W && y < H;
             j = jbase + (int64_t)y * W + x;
         } else {
             j = jbase + l;
-            in[r] = j < P;
+            in = j < P;
         }
-        if (!in[r]) j = jbase;
-        cell[r] = p_cell[j];
-        patf[r] = p_patf[j];
+        if (!in) j = jbase;
+        const int32_t c = p_cell[j];
+        cell[r] = in ? c : -1;
+        if (p_patf) patf[r] = p_patf[j];
+        else patf[r] = (frame << 16) | ((uint32_t)pat_y[in ? y : 0] * (uint32_t)g + (uint32_t)pat_x[in ? x : 0]);
     }
-    int32_t vid[PT_TILE / TPB];
-#pragma unroll
-    for (int r = 0; r < PT_TILE / TPB; ++r) vid[r] = occ[cell[r] > 0 ? cell[r] : 0];
     const int lane = tid & 63;
 #pragma unroll
     for (int r = 0; r < PT_TILE / TPB; ++r) {
-        u64 code = ~0ull;
-        if (in[r] && cell[r] >= 0 && vid[r] >= 0)         // frame << 16 | patch  ->  voxel << cb | frame << pb | patch
-            code = ((u64)(uint32_t)vid[r] << cb) | ((u64)(patf[r] >> 16) << pb) | (u64)(patf[r] & 0xffffu);
-        if (PAIRS) {
-            // neighbouring pixels share (voxel, frame, patch): only the first lane of every stretch of equal codes
-            // inserts, with the stretch's length, instead of 64 conflicting LDS atomics
-            const u64 prev = __shfl_up(code, 1);
-            const bool edge = lane == 0 || code != prev;
-            const u64 em = __ballot(edge);
-            const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
-            const int end = above ? (__ffsll((long long)above) - 1) : 64;
-            if (edge && code != ~0ull) {
-                uint32_t h = (uint32_t)mix64(code) & (PT_HS - 1);
-                for (;;) {
-                    const u64 old = atomicCAS(&hkey[h], ~0ull, code);
-                    if (old == ~0ull || old == code) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
-                    h = (h + 1) & (PT_HS - 1);
-                }
+        // neighbouring pixels share (cell, frame, patch): only the first lane of every stretch of equal pairs
+        // inserts, with the stretch's length, instead of 64 conflicting LDS atomics
+        const int32_t pc = __shfl_up(cell[r], 1);
+        const uint32_t pp = __shfl_up(patf[r], 1);
+        const bool edge = lane == 0 || cell[r] != pc || patf[r] != pp;
+        const u64 em = __ballot(edge);
+        const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
+        const int end = above ? (__ffsll((long long)above) - 1) : 64;
+        if (edge && cell[r] >= 0) {        // frame << 16 | patch  ->  cell code << cb | frame << pb | patch
+            const u64 code = (cell_to_code(cc, cell[r]) << cb) | ((u64)(patf[r] >> 16) << pb) | (u64)(patf[r] & 0xffffu);
+            uint32_t h = (uint32_t)mix64(code) & (PT_HS - 1);
+            for (;;) {
+                const u64 old = atomicCAS(&hkey[h], ~0ull, code);
+                if (old == ~0ull || old == code) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
+                h = (h + 1) & (PT_HS - 1);
             }
         }
     }
-    if (PAIRS) {
-        // the tile's distinct pairs go to its private staging slice (no global same-address atomics);
-        // k_pair_compact packs the slices after an exclusive scan of the per-tile counts
-        __syncthreads();
-        for (int s = tid; s < PT_HS; s += TPB) {
-            const u64 code = hkey[s];
-            if (code != ~0ull) {
-                const int li = atomicAdd(&nloc, 1);
-                pstage_key[tile * PT_TILE + li] = code;
-                pstage_cnt[tile * PT_TILE + li] = hcnt[s];
-            }
+    // the tile's distinct pairs go to its private staging slice (no global same-address atomics);
+    // k_pair_compact packs the slices after an exclusive scan of the per-tile counts
+    __syncthreads();
+    for (int s = tid; s < PT_HS; s += TPB) {
+        const u64 code = hkey[s];
+        if (code != ~0ull) {
+            const int li = atomicAdd(&nloc, 1);
+            pstage_key[tile * PT_TILE + li] = code;
+            pstage_cnt[tile * PT_TILE + li] = hcnt[s];
         }
-        __syncthreads();
-        if (tid == 0) tile_cnt[tile] = nloc;
     }
+    __syncthreads();
+    if (tid == 0) tile_cnt[tile] = nloc;
 }
 
 __global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int32_t *__restrict__ tile_cnt,
@@ -211,50 +249,9 @@ static bsc_status compact_heads(bsc_ctx *x, const K *keys, int64_t n, int shift,
     return BSC_OK;
 }
 
-bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev)
-{
-    return compact_heads<uint32_t>(x, keys, n, 0, 0xffffffffu, out, count_dev);
-}
-
 bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev)
 {
     return compact_heads<u64>(x, keys, n, shift, ~0ull, out, count_dev);
-}
-
-// ---- locality-aware order of the voxel segments ---------------------------------------------------------------------
-// Token rows are re-read once per (voxel, frame, patch) pair; with 128 frames per call the token tile (77 MB) is far
-// larger than an XCD's 4 MB L2, and in voxel-id order the concurrently running wavefronts touch all of it (PMC: 4.5x the
-// algorithmic bytes fetched).  Spatially adjacent voxels see the same patches in every frame, so the segments are
-// walked in Morton order of their voxel coordinates, one contiguous eighth of that order per XCD (workgroup b runs on
-// XCD b % 8 — a placement used for speed only): each XCD's working set of token rows then fits its L2.
-__device__ __forceinline__ uint32_t spread3(uint32_t v)      // 10 bits -> every third bit
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-__global__ __launch_bounds__(TPB) void k_seg_morton(int64_t n_bound, const int64_t *dscal, const int32_t *__restrict__ seg_start,
-                                                    const u64 *__restrict__ pkey, int cb, const int32_t *__restrict__ rgb_pos,
-                                                    uint32_t *__restrict__ okey, uint32_t *__restrict__ oval)
-{
-    const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (s >= n_bound) return;
-    uint32_t key = 0xffffffffu, val = 0;
-    if (s < dscal[DS_B_NPSEG]) {
-        val = (uint32_t)seg_start[s];
-        const uint32_t vid = (uint32_t)(pkey[val] >> cb);
-        const uint32_t r = (uint32_t)rgb_pos[3 * (int64_t)vid], c = (uint32_t)rgb_pos[3 * (int64_t)vid + 1],
-                       h = (uint32_t)rgb_pos[3 * (int64_t)vid + 2];
-        // coarse cells of 4 voxels keep 10 bits per axis up to a 4096-cell grid; ties inside a cell are harmless
-        key = (spread3(r >> 2) << 2) | (spread3(c >> 2) << 1) | spread3(h >> 2);
-        key &= 0x3fffffffu;
-    }
-    okey[s] = key;
-    oval[s] = val;
 }
 
 // four runs at a time: all token-row loads (4 x NV x 16 B per lane) are in flight before the first FMA, so a voxel
@@ -294,15 +291,16 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
                                                       int64_t n_pairs, const uint32_t *__restrict__ seg_start,
                                                       const int64_t *dscal, const TOK *__restrict__ tokens, int g2,
                                                       int D, float *__restrict__ acc, int32_t *__restrict__ acnt, int pb,
-                                                      int cb)
+                                                      int cb, CellCode cc, const int32_t *__restrict__ occ)
 {
     const u64 cmask = (1ull << cb) - 1ull;
     const int lane = threadIdx.x & 63;
     const int64_t nseg = dscal[DS_B_NPSEG];
     const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
     const int D4 = D >> 2;
-    // XCD x (workgroups b with b % 8 == x) walks the super-chunks x, x+8, x+16, ... of the Morton-ordered segment
-    // list (64 super-chunks: spatial locality inside each, heavy regions spread over all XCDs)
+    // The segment list is in Morton order of the voxel cells.  XCD x (workgroups b with b % 8 == x) walks the
+    // super-chunks x, x+8, x+16, ... of it (64 super-chunks: spatial locality inside each, so an XCD's working set of
+    // token rows fits its L2; heavy regions spread over all XCDs)
     const int xcd = blockIdx.x & 7;
     const int64_t w_local = (int64_t)(blockIdx.x >> 3) * (TPB / 64) + (threadIdx.x >> 6);
     const int64_t w_per_xcd = (int64_t)(gridDim.x >> 3) * (TPB / 64);
@@ -311,7 +309,8 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
         const int64_t s = (xcd + 8 * (i / chunk)) * chunk + (i % chunk);
         if (s >= nseg) continue;
         const int64_t i0 = seg_start[s];
-        const uint32_t vid = (uint32_t)(pkey[i0] >> cb);
+        const u64 ccode = pkey[i0] >> cb;                    // cell code of the segment
+        const uint32_t vid = (uint32_t)occ[code_to_cell(cc, ccode)];
         const bool is_new = (int64_t)vid >= max_id_prev;
         float4 *dst = (float4 *)(acc + (int64_t)vid * D);
         float4 a[NV];
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
         for (int64_t base = i0;; base += 64) {
             const int64_t k = base + lane;
             const u64 key = (k < n_pairs) ? pkey[k] : ~0ull;
-            const bool inseg = (k < n_pairs) && ((uint32_t)(key >> cb) == vid);
+            const bool inseg = (k < n_pairs) && ((key >> cb) == ccode);
             const uint32_t code = inseg ? (uint32_t)(key & cmask) : 0xffffffffu;
             const uint32_t cnt = inseg ? pcnt[k] : 0u;
             const int n = __popcll(__ballot(inseg));
@@ -429,15 +428,28 @@ __global__ void k_dense_counters(int64_t *dscal)
 static inline int code_patch_bits(const bsc_ctx *x) { return ceil_log2_u64((uint64_t)x->g2); }
 static inline int code_bits(const bsc_ctx *x, int n_frames) { return code_patch_bits(x) + ceil_log2_u64((uint64_t)n_frames); }
 
+static CellCode make_cell_code(const bsc_ctx *x, int cb)
+{
+    CellCode cc;
+    cc.gs = x->c.grid_size; cc.nh = x->nh;
+    const int a = ceil_log2_u64((uint64_t)x->c.grid_size), b = ceil_log2_u64((uint64_t)x->nh);
+    cc.ab = a > b ? a : b;
+    if (cc.ab < 1) cc.ab = 1;
+    if (cc.ab > 21 || 3 * cc.ab + cb > 62) cc.ab = 0;          // linear cell index (< 2^31) instead
+    return cc;
+}
+static inline int cell_code_bits(const CellCode &cc) { return cc.ab ? 3 * cc.ab : 31; }
+
 template <int MODE, typename TOK>
 static void launch_dense(bsc_ctx *x, int64_t n_pairs, const TOK *tokens, int pb, int cb)
 {
+    const CellCode cc = make_cell_code(x, cb);
     const int D = x->c.token_dim;
     const int nv = (D / 4 + 63) / 64;
     const dim3 grid(256 * 8), block(TPB);
 #define LD(NV)                                                                                                          \
     hipLaunchKernelGGL((k_dense_reduce<NV, MODE, TOK>), grid, block, 0, x->stream, x->pair_key_b, x->pair_cnt_b, n_pairs,    \
-                       (const uint32_t *)x->pseg_start, x->dscal, tokens, x->g2, D, x->acc, x->acnt, pb, cb)
+                       (const uint32_t *)x->pseg_start, x->dscal, tokens, x->g2, D, x->acc, x->acnt, pb, cb, cc, x->occ)
     if (nv <= 1) LD(1);
     else if (nv == 2) LD(2);
     else if (nv == 3) LD(3);
@@ -446,25 +458,21 @@ static void launch_dense(bsc_ctx *x, int64_t n_pairs, const TOK *tokens, int pb,
 #undef LD
 }
 
-// dense modes: the per-tile (voxel, frame, patch) pairs of the batch
-bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels)
+// dense modes: the per-tile (cell, frame, patch) pairs of the batch
+bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels, const uint32_t *p_patf)
 {
-    const bool pairs = x->c.mode != BSC_MODE_EXACT;
-    if (!pairs) return BSC_OK;
+    if (x->c.mode == BSC_MODE_EXACT) return BSC_OK;
     const int H = x->c.height, W = x->c.width;
     const int tx_n = (W + 31) / 32, ty_n = (H + 31) / 32;
     const int64_t tiles = all_pixels ? (int64_t)n_frames * tx_n * ty_n : (P + PT_TILE - 1) / PT_TILE;
-    if (pairs && tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
+    if (tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
     const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
     const dim3 grid((unsigned)tiles), block(TPB);
-    if (pairs) {
-        hipLaunchKernelGGL((k_keys_pairs<true>), grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n,
-                           x->p_cell, x->occ, x->p_patf, x->pstage_key, x->pstage_cnt, x->tile_cnt,
-                           pb, cb);
-        BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
-        hipLaunchKernelGGL(k_pair_compact, grid, block, 0, x->stream, tiles, x->tile_cnt, x->tile_off, x->pstage_key,
-                           x->pstage_cnt, x->pair_key_a, x->pair_cnt_a, x->pair_cap, x->dscal);
-    }
+    hipLaunchKernelGGL(k_keys_pairs, grid, block, 0, x->stream, P, all_pixels ? 1 : 0, H, W, tx_n, ty_n, make_cell_code(x, cb),
+                       x->p_cell, p_patf, x->pat_x, x->pat_y, x->c.patch_grid, x->pstage_key, x->pstage_cnt, x->tile_cnt, pb, cb);
+    BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
+    hipLaunchKernelGGL(k_pair_compact, grid, block, 0, x->stream, tiles, x->tile_cnt, x->tile_off, x->pstage_key,
+                       x->pstage_cnt, x->pair_key_a, x->pair_cnt_a, x->pair_cap, x->dscal);
     BSC_HIP(hipGetLastError());
     return BSC_OK;
 }
@@ -479,16 +487,10 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
     }
     if (n_pairs == 0) return BSC_OK;
     const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
-    const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 1);
     BSC_TRY(prim_sort_pairs_onesweep(x, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, (size_t)n_pairs, 0,
-                                     cb + vid_bits));
+                                     cb + cell_code_bits(make_cell_code(x, cb))));
+    // voxel segments of the sorted list, already in Morton order of the cells
     BSC_TRY(compact_heads_u64(x, x->pair_key_b, n_pairs, cb, x->pseg_start, x->dscal + DS_B_NPSEG));
-    // segments in Morton order of their voxels (the number of segments is only known on the device; it is bounded by
-    // the voxel count read back earlier, slots beyond it carry 0xffffffff keys and sort last)
-    const int64_t n_bound = n_pairs < x->hscal[DS_MAX_ID] ? n_pairs : x->hscal[DS_MAX_ID];
-    hipLaunchKernelGGL(k_seg_morton, dim3((unsigned)((n_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, n_bound, x->dscal, x->pseg_start,
-                       x->pair_key_b, cb, x->rgb_pos, x->skey_a, x->sval_a);
-    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, x->pair_cnt_a, x->sval_a, (uint32_t *)x->pseg_start, (size_t)n_bound, 0, 30));
     stat_begin(x, 0);
     if (token_dtype == BSC_TOK_BF16) {
         if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, (const bf16_t *)tokens, pb, cb);

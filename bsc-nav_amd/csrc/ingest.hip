@@ -4,18 +4,20 @@
 // top-down map and the token cache are all defined by that order.  Here every point j of a batch
 // (frames in call order, points in the reference's shuffled order) carries its order implicitly:
 //
-//   k_points    geometry (fp64, bit-exact) -> cell / patch / rgb / r2 / alpha; atomicMin claims the
-//               first toucher of every still-empty cell                         (1 thread / point)
-//   k_flags + scan of block totals + k_assign  first-touch points get ids max_id + rank in order; the same pass
-//               lists the RUNS of the batch (maximal stretches of consecutive points in one cell)
-//   k_keys_pairs (dense.hip) LDS aggregation of (voxel, frame, patch) pairs
-//   radix sort  of the runs (stable, on the voxel id bits only) + k_expand: every voxel's points in order j,
-//               at a fraction of the traffic of sorting the points themselves (a voxel covers ~16 pixels of a row)
+//   k_points    1024 consecutive points per workgroup: geometry (fp64, bit-exact) -> cell / rgb / alpha; atomicMin
+//               claims the first toucher of every still-empty cell, the first claimer (in time) lists the cell as new;
+//               per-block counts of passing points and of RUNS (stretches of consecutive points in one cell)
+//   k_keys_pairs (dense.hip) LDS aggregation of (cell, frame, patch) pairs — independent of the ids
+//   k_new_keys + sort + k_new_assign   the new cells ranked by their winning point: id = max_id + rank, as the
+//               sequential max_id++ hands them out (a few thousand cells, not a pass over the points)
+//   k_runs      one pass over the cells: every run as key = voxel id | (length - 1) << id bits, value = first point
+//   radix sort  of the runs (stable, on the id bits only), one scan of (length, segment head) pairs, k_expand: every
+//               voxel's points in order j, at a fraction of the traffic of sorting the points themselves
 //   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
 //               (h, order of the voxel's latest point)                        (1 quad of lanes / voxel)
 //   k_hwin      the winning voxel of each map cell writes its colour
 //   dense.hip   pair sort + k_dense_reduce: multiplicity x token rows -> one RMW of the D-float
-//               accumulator row per voxel                                     (1 wavefront / voxel)
+//               accumulator row per voxel
 //   k_append    exact mode: token rows into the cache in order                (1 wavefront / row)
 #include "bsc_internal.h"
 #include "geometry_dev.h"
@@ -37,6 +39,9 @@ static GeomConst make_geom_const(const bsc_ctx *x)
     g.max_depth = x->c.max_depth;
     g.H = x->c.height; g.W = x->c.width; g.gs = x->c.grid_size;
     g.min_h = x->c.min_h; g.max_h = x->c.max_h; g.nh = x->nh; g.g = x->c.patch_grid;
+    g.fast = x->geom_fast ? 1 : 0;
+    g.rcs = 1.0 / x->c.cell_size;
+    g.pat_x = x->pat_x; g.pat_y = x->pat_y;
     return g;
 }
 
@@ -51,193 +56,273 @@ __device__ __forceinline__ int frame_of(const int64_t *offsets, int n_frames, in
 }
 
 // ------------------------------------------------------------------------------------------------
+#define FB 1024                 // consecutive points per workgroup
+#define PPT (FB / TPB)          // points per thread, strided by TPB (coalesced rounds)
+
+// Head flags of a block's points: point p (0 <= p < FB, order round-major: p = r * TPB + tid) starts a run when its
+// cell differs from the cell of point p - 1, at the block's first point, and at every multiple of `cap` (a run's
+// length has to fit the bits left beside the voxel id in the sort key).  cells[r] = cell of point r * TPB + tid
+// (-1: no voxel; points beyond P carry -2 so that the last real run ends at P).
+__device__ __forceinline__ void block_heads(const int32_t (&cell)[PPT], int cap_mask, int32_t (*s_edge)[TPB / 64], bool (&head)[PPT])
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+        if (lane == 63) s_edge[r][wid] = cell[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        int32_t prev = __shfl_up(cell[r], 1);
+        if (lane == 0) {
+            if (wid > 0) prev = s_edge[r][wid - 1];
+            else prev = r > 0 ? s_edge[r - 1][TPB / 64 - 1] : cell[r] - 1;      // block start: forced head
+        }
+        const int p = r * TPB + (int)threadIdx.x;
+        head[r] = prev != cell[r] || (p & cap_mask) == 0;
+    }
+}
+
+// FAST: geom_point_fast (pinhole intrinsics, patch tables; GeomConst.fast) — otherwise the generic fma chains.
+template <bool FAST>
 __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__restrict__ depth,
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
                                                 const int32_t *__restrict__ idx, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
-                                                const double *__restrict__ alpha_in, int64_t P, int32_t *occ,
-                                                int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
-                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f)
+                                                const double *__restrict__ alpha_in, int64_t P, float inv_w, int cap_mask,
+                                                int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
+                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f,
+                                                int32_t *__restrict__ new_cells, int64_t *dscal,
+                                                int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass)
 {
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= P) return;
-    const int64_t N = (int64_t)gc.H * gc.W;
-    int f;
-    int32_t i;
-    if (idx) {
-        f = frame_of(offsets, n_frames, j);
-        i = idx[j];
-    } else {
-        f = (int)(j / N);
-        i = (int32_t)(j - (int64_t)f * N);
-    }
-    const float z = depth[(int64_t)f * N + i];
-    GeomOut o;
-    geom_point(gc, i, z, transforms + 16 * f, o, alpha_in == nullptr);
-    if (o.flags != 7u) {
-        p_cell[j] = -1;
-        return;
-    }
-    const int32_t row = o.vox[0], col = o.vox[1], h = o.vox[2] - gc.min_h;   // memory_2.py:867
-    const int32_t cell = (row * gc.gs + col) * gc.nh + h;
-    int sx = o.pix[0], sy = o.pix[1];            // memory_2.py:870 rgb[py, px]: negative indices wrap
-    if (sx < 0) sx += gc.W;
-    if (sy < 0) sy += gc.H;
-    sx = min(max(sx, 0), gc.W - 1);
-    sy = min(max(sy, 0), gc.H - 1);
-    const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
-    p_cell[j] = cell;
-    p_patf[j] = ((uint32_t)f << 16) | (uint32_t)(o.pat[1] * gc.g + o.pat[0]);   // tokens[py, px]
-    if (p_r2f) p_r2f[j] = (float)o.r2;            // memory_2.py:885 grid_feat_dis is float32 (token cache only)
-    PointRec rec;
-    rec.alpha = alpha_in ? alpha_in[j] : o.alpha;
-    rec.rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
-    rec.pad = 0;
-    p_rec[j] = rec;
-    // first-touch claim: the smallest j wins an empty cell (ids are handed out in k_assign)
-    if (occ[cell] < 0) atomicMin(&occ[cell], INT_MIN + (int32_t)j);
-}
-
-// ---- first-touch ranks without a per-point scan -----------------------------------------------------------------
-// Blocks of FB consecutive points count their passing / first-touch points (k_flags); an exclusive scan over the
-// ~P/1024 block totals gives every block its base; k_assign recomputes the flags and ranks its points inside the
-// block in order j with wave ballots.  Same ranks as a scan over all P points, at a third of the traffic.
-#define FB 1024
-// flags of the block's FB points, FB / TPB per thread; every load is issued before its first dependent use
-// (clamped addresses instead of branches): bit0 passes, bit1 first toucher of its voxel, bit2 first point of a run
-// (any cell, -1 included)
-__device__ __forceinline__ void block_flags(int64_t blk, int64_t P, const int32_t *__restrict__ p_cell,
-                                            const int32_t *__restrict__ occ, int (&f)[FB / TPB], int32_t (&cell)[FB / TPB])
-{
-    int32_t prev[FB / TPB];
-    bool in[FB / TPB];
+    __shared__ int32_t s_edge[PPT][TPB / 64];
+    __shared__ int s_heads, s_pass;
+    if (threadIdx.x == 0) { s_heads = 0; s_pass = 0; }
+    const int lane = threadIdx.x & 63;
+    const int32_t N = gc.H * gc.W;
+    int32_t cells[PPT];
 #pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) {
-        const int64_t j = blk * FB + r * TPB + threadIdx.x;
-        in[r] = j < P;
-        const int64_t jc = in[r] ? j : P - 1;
-        cell[r] = p_cell[jc];
-        prev[r] = p_cell[jc > 0 ? jc - 1 : 0];
-    }
-    int32_t o[FB / TPB];
-#pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) o[r] = occ[cell[r] > 0 ? cell[r] : 0];
-#pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) {
-        const int64_t j = blk * FB + r * TPB + threadIdx.x;
-        int v = 0;
-        if (in[r]) {
-            if (j == 0 || prev[r] != cell[r]) v = 4;
-            if (cell[r] >= 0) v |= (o[r] == INT_MIN + (int32_t)j) ? 3 : 1;
-        } else {
-            cell[r] = -1;
-        }
-        f[r] = v;
-    }
-}
-
-__global__ __launch_bounds__(TPB) void k_flags(int64_t P, const int32_t *__restrict__ p_cell,
-                                               const int32_t *__restrict__ occ, int64_t *__restrict__ blk_tot,
-                                               int32_t *__restrict__ blk_runs)
-{
-    __shared__ int s_pass, s_first, s_head;
-    if (threadIdx.x == 0) { s_pass = 0; s_first = 0; s_head = 0; }
-    __syncthreads();
-    int f[FB / TPB];
-    int32_t c[FB / TPB];
-    block_flags(blockIdx.x, P, p_cell, occ, f, c);
-    int np = 0, nf = 0, nh = 0;
-#pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) {
-        np += f[r] & 1;
-        nf += (f[r] >> 1) & 1;
-        nh += f[r] >> 2;
-    }
-    for (int o = 32; o > 0; o >>= 1) { np += __shfl_xor(np, o); nf += __shfl_xor(nf, o); nh += __shfl_xor(nh, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_pass, np); atomicAdd(&s_first, nf); atomicAdd(&s_head, nh); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        blk_tot[blockIdx.x] = ((int64_t)s_first << 32) | (int64_t)s_pass;
-        blk_runs[blockIdx.x] = s_head;
-    }
-}
-
-__global__ __launch_bounds__(TPB) void k_assign(int64_t P, const int32_t *__restrict__ p_cell, int32_t *occ,
-                                                const int64_t *__restrict__ blk_off, int64_t *dscal, int vcap, int gs,
-                                                int nh, int32_t *__restrict__ rgb_pos, int32_t *__restrict__ pass_list,
-                                                const int32_t *__restrict__ blk_run_off, int32_t *__restrict__ run_j0)
-{
-    // ranks follow the order j: round, then wave, then lane
-    __shared__ int w_pass[FB / TPB][TPB / 64], w_first[FB / TPB][TPB / 64], w_head[FB / TPB][TPB / 64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t base = blk_off[blockIdx.x];
-    int64_t pass_base = base & 0xffffffffll, first_base = base >> 32;
-    int32_t head_base = blk_run_off[blockIdx.x];
-    const int64_t max_id = dscal[DS_MAX_ID];
-    int f[FB / TPB];
-    int32_t c[FB / TPB];
-    // occ is read here while other blocks overwrite claimed cells with ids: a claim INT_MIN + j can only be replaced by
-    // the id of that same point j, so the flags of every other point are unaffected
-    block_flags(blockIdx.x, P, p_cell, occ, f, c);
-    u64 mp[FB / TPB], mf[FB / TPB], mh[FB / TPB];
-#pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) {
-        mp[r] = __ballot(f[r] & 1); mf[r] = __ballot(f[r] & 2); mh[r] = __ballot(f[r] & 4);
-        if (lane == 0) { w_pass[r][wid] = __popcll(mp[r]); w_first[r][wid] = __popcll(mf[r]); w_head[r][wid] = __popcll(mh[r]); }
-    }
-    __syncthreads();
-    const u64 lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < FB / TPB; ++r) {
+    for (int r = 0; r < PPT; ++r) {
         const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        int bp = 0, bf = 0, bh = 0, tp = 0, tf = 0, th = 0;
-        for (int w = 0; w < TPB / 64; ++w) {
-            if (w < wid) { bp += w_pass[r][w]; bf += w_first[r][w]; bh += w_head[r][w]; }
-            tp += w_pass[r][w]; tf += w_first[r][w]; th += w_head[r][w];
-        }
-        if (f[r] & 4) run_j0[head_base + bh + __popcll(mh[r] & lt)] = (int32_t)j;     // runs in order j
-        if (f[r] & 1) {
-            if (pass_list) pass_list[pass_base + bp + __popcll(mp[r] & lt)] = (int32_t)j;
-            if (f[r] & 2) {
-                const int64_t id = max_id + first_base + bf + __popcll(mf[r] & lt);
-                if (id >= vcap) {
-                    dscal[DS_ERROR] = 1;        // capacity: the cell keeps its provisional (negative) value
+        int32_t cell = -2;
+        if (j < P) {
+            int f;
+            int32_t i;
+            if (idx) {
+                f = frame_of(offsets, n_frames, j);
+                i = idx[j];
+            } else {
+                // frame of the round's first point on the scalar unit; a round straddles at most one frame boundary
+                // when N >= TPB (smaller frames take the per-thread division)
+                const uint32_t j0 = blockIdx.x * (uint32_t)FB + (uint32_t)(r * TPB);      // P <= max_points < 2^31
+                int fb = (int)(j0 / (uint32_t)N);
+                int32_t ib = (int32_t)(j0 - (uint32_t)fb * (uint32_t)N) + (int32_t)threadIdx.x;
+                if (N >= TPB) {
+                    if (ib >= N) { ib -= N; ++fb; }
                 } else {
-                    occ[c[r]] = (int32_t)id;        // memory_2.py:890
-                    const int32_t h = c[r] % nh, rc = c[r] / nh;
-                    rgb_pos[3 * id + 0] = rc / gs;  // memory_2.py:893
-                    rgb_pos[3 * id + 1] = rc % gs;
-                    rgb_pos[3 * id + 2] = h;
+                    fb += ib / N;
+                    ib = ib % N;
+                }
+                f = fb;
+                i = ib;
+            }
+            const float z = depth[(int64_t)f * N + i];
+            // the frame's pc_transform: through the scalar cache when the wavefront lies inside one frame
+            double T[12];
+            const int f0 = __builtin_amdgcn_readfirstlane(f);
+            if (__all(f == f0)) {
+                const double *Ts = transforms + 16 * (int64_t)f0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) T[k] = Ts[k];
+            } else {
+                const double *Tv = transforms + 16 * (int64_t)f;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) T[k] = Tv[k];
+            }
+            int32_t sx = 0, sy = 0;
+            uint32_t patch = 0;
+            double r2 = 0.0, alpha = 0.0;
+            cell = -1;
+            if (FAST) {
+                // y = i / W without an integer division: float estimate (exact operands below 2^24), corrected by one
+                int32_t y = (int32_t)((float)i * inv_w);
+                int32_t x = i - y * gc.W;
+                if (x < 0) { --y; x += gc.W; } else if (x >= gc.W) { ++y; x -= gc.W; }
+                GeomFastOut o;
+                geom_point_fast(gc, x, y, z, T, o, alpha_in == nullptr);
+                cell = o.cell;
+                sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
+            } else {
+                GeomOut o;
+                geom_point(gc, i, z, T, o, alpha_in == nullptr);
+                if (o.flags == 7u) {
+                    const int32_t row = o.vox[0], col = o.vox[1], h = o.vox[2] - gc.min_h;   // memory_2.py:867
+                    cell = (row * gc.gs + col) * gc.nh + h;
+                    sx = o.pix[0]; sy = o.pix[1];            // memory_2.py:870 rgb[py, px]: negative indices wrap
+                    if (sx < 0) sx += gc.W;
+                    if (sy < 0) sy += gc.H;
+                    sx = min(max(sx, 0), gc.W - 1);
+                    sy = min(max(sy, 0), gc.H - 1);
+                    patch = (uint32_t)(o.pat[1] * gc.g + o.pat[0]);                          // tokens[py, px]
+                    r2 = o.r2; alpha = o.alpha;
                 }
             }
+            p_cell[j] = cell;
+            if (cell >= 0) {
+                const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
+                if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
+                if (p_r2f) p_r2f[j] = (float)r2;      // memory_2.py:885 grid_feat_dis is float32 (token cache only)
+                if (alpha_in) alpha = alpha_in[j];
+                PointRec rec;
+                rec.alo = (uint32_t)__double2loint(alpha);
+                rec.ahi = (uint32_t)__double2hiint(alpha);
+                rec.rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
+                p_rec[j] = rec;
+            }
+            // first-touch claim: the smallest j wins an empty cell.  Of a stretch of lanes in one cell only the first
+            // (smallest j) competes, and only while the cell is empty or claimed by a later point — so a batch in which
+            // every voxel is new costs about one atomic per cell and wavefront instead of one per point.
+            const int32_t prev_cell = __shfl_up(cell, 1);
+            bool first = false;
+            if (cell >= 0 && (lane == 0 || prev_cell != cell)) {
+                const int32_t mine = INT_MIN + (int32_t)j, cur = occ[cell];
+                if (cur < 0 && cur > mine) first = atomicMin(&occ[cell], mine) == -1;
+            }
+            // the claimer that found the cell empty lists it: exactly one entry per new voxel
+            const u64 fm = __ballot(first);
+            if (fm) {
+                unsigned long long base = 0;
+                if (lane == (int)(__ffsll((long long)fm) - 1)) base = atomicAdd((unsigned long long *)&dscal[DS_B_NNEW], (unsigned long long)__popcll(fm));
+                base = __shfl(base, __ffsll((long long)fm) - 1);
+                if (first) new_cells[base + __popcll(fm & ((1ull << lane) - 1ull))] = cell;
+            }
         }
-        pass_base += tp;
-        first_base += tf;
-        head_base += th;
+        cells[r] = cell;
     }
+    // runs and passing points of the block
+    bool head[PPT];
+    block_heads(cells, cap_mask, s_edge, head);
+    int nh = 0, np = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        nh += (head[r] && cells[r] != -2) ? 1 : 0;
+        np += cells[r] >= 0 ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { nh += __shfl_xor(nh, o); np += __shfl_xor(np, o); }
+    if (lane == 0) { atomicAdd(&s_heads, nh); atomicAdd(&s_pass, np); }
+    __syncthreads();
+    if (threadIdx.x == 0) { blk_runs[blockIdx.x] = s_heads; blk_pass[blockIdx.x] = s_pass; }
 }
 
-__global__ void k_totals(int64_t P, int64_t nblk, const int64_t *blk_tot, const int64_t *blk_off, int64_t *dscal, int vcap,
-                         int64_t *bscal, const int32_t *blk_runs, const int32_t *blk_run_off)
+// scalars of the batch, on the device: run / passing-point totals from the block scans, the new voxels' id range
+__global__ void k_totals(int64_t P, int64_t nblk, const int32_t *blk_runs, const int32_t *blk_run_off, const int32_t *blk_pass,
+                         const int32_t *blk_pass_off, int64_t *dscal, int vcap, int64_t *bscal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int64_t tot = blk_off[nblk - 1] + blk_tot[nblk - 1];
-    const int64_t npass = tot & 0xffffffffll, nfirst = tot >> 32;
+    const int64_t npass = (int64_t)blk_pass_off[nblk - 1] + blk_pass[nblk - 1];
+    int64_t nnew = dscal[DS_B_NNEW];
     dscal[DS_B_NPASS] = npass;
-    dscal[DS_B_NFIRST] = nfirst;
     dscal[DS_MAX_ID_PREV] = dscal[DS_MAX_ID];
-    int64_t m = dscal[DS_MAX_ID] + nfirst;
-    if (m > vcap) { m = vcap; dscal[DS_ERROR] = 1; }
-    dscal[DS_MAX_ID] = m;
+    if (dscal[DS_MAX_ID] + nnew > vcap) { nnew = vcap - dscal[DS_MAX_ID]; dscal[DS_ERROR] = 1; }
+    dscal[DS_B_NFIRST] = nnew;
+    dscal[DS_MAX_ID] += nnew;
     dscal[DS_NPASS_TOTAL] += npass;
     dscal[DS_NSEEN_TOTAL] += P;
-    dscal[DS_B_NSEG] = 0;
-    bscal[0] = 0;
-    bscal[1] = dscal[DS_MAX_ID_PREV];
-    bscal[3] = 0;                       // segment queue of the rgb chain
-    dscal[DS_B_NPAIR] = 0;
-    dscal[DS_B_NPSEG] = 0;
     dscal[DS_B_NRUN] = (int64_t)blk_run_off[nblk - 1] + blk_runs[nblk - 1];
+    dscal[DS_B_NPSEG] = 0;
+    bscal[0] = 0;                       // voxel segments of the point order (k_expand)
+    bscal[1] = dscal[DS_MAX_ID_PREV];
+    bscal[2] = 0;                       // points in the per-voxel order
+    bscal[3] = 0;                       // segment queue of the rgb chain
+}
+
+// ---- ids of the new voxels ---------------------------------------------------------------------------------------
+// new cell -> (winning point j, cell); sorted by j the list is in first-touch order
+__global__ __launch_bounds__(TPB) void k_new_keys(int64_t n, const int32_t *__restrict__ new_cells, const int32_t *__restrict__ occ,
+                                                  uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = new_cells[i];
+    key[i] = (uint32_t)(occ[c] - INT_MIN);
+    val[i] = (uint32_t)c;
+}
+
+// memory_2.py:888-894: id = max_id++ in first-touch order; grid_rgb_pos[id] = [row, col, h]
+__global__ __launch_bounds__(TPB) void k_new_assign(int64_t n, int64_t n_ok, const uint32_t *__restrict__ cells_sorted, int32_t *occ,
+                                                    const int64_t *dscal, int gs, int nh, int32_t *__restrict__ rgb_pos)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = (int32_t)cells_sorted[i];
+    if (i >= n_ok) return;              // capacity: the cell keeps its provisional (negative) value
+    const int64_t id = dscal[DS_MAX_ID_PREV] + i;
+    occ[c] = (int32_t)id;
+    const int32_t h = c % nh, rc = c / nh;
+    rgb_pos[3 * id + 0] = rc / gs;
+    rgb_pos[3 * id + 1] = rc % gs;
+    rgb_pos[3 * id + 2] = h;
+}
+
+// ---- runs -----------------------------------------------------------------------------------------------------------
+// One pass over the cells of a block: every run r (in order j) -> sort key = voxel id | (length - 1) << vb (id field all
+// ones: no voxel — invalid depth / outside the grid / over capacity), value = first point.  Runs end inside their block
+// (forced head at every block start), so the length comes from the block's own head bits.  Exact mode: the passing
+// points are listed in order as well.
+__global__ __launch_bounds__(TPB) void k_runs(int64_t P, int vb, int cap_mask, const int32_t *__restrict__ p_cell,
+                                              const int32_t *__restrict__ occ, const int32_t *__restrict__ blk_run_off,
+                                              const int32_t *__restrict__ blk_pass_off, uint32_t *__restrict__ rkey,
+                                              uint32_t *__restrict__ rval, int32_t *__restrict__ pass_list)
+{
+    __shared__ int32_t s_edge[PPT][TPB / 64];
+    __shared__ u64 s_hbits[FB / 64], s_pbits[FB / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t cells[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+        cells[r] = j < P ? p_cell[j] : -2;
+    }
+    int32_t vid[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) vid[r] = occ[cells[r] > 0 ? cells[r] : 0];       // all loads in flight before use
+    bool head[PPT];
+    block_heads(cells, cap_mask, s_edge, head);
+    // word w = r * 4 + wave covers the points [64 w, 64 w + 64) of the block; points beyond P count as heads (run ends)
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const u64 hb = __ballot(head[r]), pb = __ballot(cells[r] >= 0);
+        if (lane == 0) { s_hbits[r * (TPB / 64) + wid] = hb; s_pbits[r * (TPB / 64) + wid] = pb; }
+    }
+    __syncthreads();
+    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+    const int32_t run_base = blk_run_off[blockIdx.x];
+    const int32_t pass_base = pass_list ? blk_pass_off[blockIdx.x] : 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int w = r * (TPB / 64) + wid;
+        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+        if (cells[r] == -2) continue;
+        const u64 below = (1ull << lane) - 1ull;
+        if (pass_list && cells[r] >= 0) {
+            int rank = __popcll(s_pbits[w] & below);
+            for (int k = 0; k < w; ++k) rank += __popcll(s_pbits[k]);
+            pass_list[pass_base + rank] = (int32_t)j;
+        }
+        if (!head[r]) continue;
+        int rank = __popcll(s_hbits[w] & below);
+        for (int k = 0; k < w; ++k) rank += __popcll(s_hbits[k]);
+        // next head after this point (the block's end otherwise)
+        int nxt = FB;
+        const u64 above = lane == 63 ? 0ull : (s_hbits[w] & (~0ull << (lane + 1)));
+        if (above) nxt = w * 64 + __ffsll((long long)above) - 1;
+        else
+            for (int k = w + 1; k < FB / 64; ++k)
+                if (s_hbits[k]) { nxt = k * 64 + __ffsll((long long)s_hbits[k]) - 1; break; }
+        const int len = nxt - (w * 64 + lane);
+        const int32_t v = cells[r] >= 0 ? vid[r] : -1;
+        rkey[run_base + rank] = v >= 0 ? ((uint32_t)v | ((uint32_t)(len - 1) << vb)) : vmask;
+        rval[run_base + rank] = (uint32_t)j;
+    }
 }
 
 // memory_2.py:888-903 — the rgb chain c' = trunc((f32(c*w) + r*a) / (w + a)), w' = f32(w + a) is sequential by
@@ -289,9 +374,9 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
 #pragma unroll
     for (int i = 0; i < CQ; ++i) {
         const bool valid = J[i] != 0xffffffffu;
-        const uint4 raw = *(const uint4 *)(p_rec + (valid ? J[i] : 0u));       // { alpha lo, alpha hi, rgbv, pad }
-        R.alo[i] = raw.x; R.ahi[i] = raw.y;
-        R.rv[i] = valid ? (raw.z | 0xc0000000u) : 0u;
+        const PointRec raw = p_rec[valid ? J[i] : 0u];                         // { alpha lo, alpha hi, rgbv }: 12 bytes
+        R.alo[i] = raw.alo; R.ahi[i] = raw.ahi;
+        R.rv[i] = valid ? (raw.rgbv | 0xc0000000u) : 0u;
         last_j = valid ? J[i] : last_j;                                        // order indices grow along a segment
     }
 }
@@ -434,53 +519,42 @@ __global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ sj, i
 }
 
 // ---- runs -> per-voxel point order ---------------------------------------------------------------------------------
-// run r (in order j) -> sort key = voxel id of its cell (0xffffffff: invalid depth / outside the grid / capacity)
-__global__ __launch_bounds__(TPB) void k_run_keys(const int64_t *dscal, const int32_t *__restrict__ run_j0,
-                                                  const int32_t *__restrict__ p_cell, const int32_t *__restrict__ occ,
-                                                  uint32_t *__restrict__ rkey, uint32_t *__restrict__ rval)
-{
-    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (r >= dscal[DS_B_NRUN]) return;
-    const int32_t c = p_cell[run_j0[r]];
-    int32_t vid = -1;
-    if (c >= 0) vid = occ[c];
-    rkey[r] = vid >= 0 ? (uint32_t)vid : 0xffffffffu;
-    rval[r] = (uint32_t)r;
-}
-
-// sorted run -> its length (0 for the invalid runs, which sort last and take no room in the point order)
-__global__ __launch_bounds__(TPB) void k_run_len(const int64_t *dscal, int64_t P, const uint32_t *__restrict__ rkey_sorted,
-                                                 const uint32_t *__restrict__ rval_sorted,
-                                                 const int32_t *__restrict__ run_j0, int32_t *__restrict__ run_len)
-{
-    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    const int64_t R = dscal[DS_B_NRUN];
-    if (i >= R) return;
-    const int64_t r = rval_sorted[i];
-    const int64_t j1 = r + 1 < R ? run_j0[r + 1] : P;
-    run_len[i] = rkey_sorted[i] == 0xffffffffu ? 0 : (int32_t)(j1 - run_j0[r]);
-}
-
-// point order: sj[run_off[i] + t] = j0(i) + t.  One wavefront per 64 sorted runs; the outputs of the 64 runs are
-// contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.
-__global__ __launch_bounds__(TPB) void k_expand(const int64_t *dscal, const uint32_t *__restrict__ rval_sorted,
-                                                const int32_t *__restrict__ run_j0, const int32_t *__restrict__ run_len,
-                                                const int32_t *__restrict__ run_off, uint32_t *__restrict__ sj)
+// After the stable sort every voxel's runs are contiguous and in order j.  ONE exclusive scan over the sorted runs of the
+// pair (length, first run of its voxel) — packed as length | head << 32 — yields both the position of every run in the
+// per-voxel point order and the ordinal of every voxel segment (prims.hip: prim_scan_runs).
+//
+// point order: sj[off(i) + t] = j0(i) + t.  One wavefront per 64 sorted runs; the outputs of the 64 runs are
+// contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.  The first run of a
+// voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
+__global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_t *__restrict__ rkey_sorted,
+                                                const uint32_t *__restrict__ rval_sorted, const int64_t *__restrict__ scan,
+                                                uint32_t *__restrict__ sj, int32_t *__restrict__ seg_k0,
+                                                int32_t *__restrict__ seg_vid, int64_t *bscal)
 {
     __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t R = dscal[DS_B_NRUN];
+    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
     const int64_t i = ((int64_t)blockIdx.x * (TPB / 64) + wid) * 64 + lane;
     int32_t off = INT_MAX, len = 0, j0 = 0;
     if (i < R) {
-        off = run_off[i]; len = run_len[i];
-        j0 = run_j0[rval_sorted[i]];
+        const uint32_t key = rkey_sorted[i];
+        const int64_t sc = scan[i];
+        const uint32_t v = key & vmask;
+        j0 = (int32_t)rval_sorted[i];
+        off = (int32_t)(sc & 0xffffffffll);
+        if (v != vmask) {
+            len = (int32_t)(key >> vb) + 1;
+            const bool head = i == 0 || (rkey_sorted[i - 1] & vmask) != v;
+            if (head) { seg_k0[sc >> 32] = off; seg_vid[sc >> 32] = (int32_t)v; }
+            if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = (int64_t)off + len; }
+        } else if (i == R - 1) {
+            bscal[0] = sc >> 32; bscal[2] = off;            // invalid runs sort last and take no room
+        }
     }
-    s_off[wid][lane] = off;
+    s_off[wid][lane] = len > 0 ? off : INT_MAX;
     s_j0[wid][lane] = j0;
-    const int32_t begin = __shfl(off, 0);
-    int32_t end = off == INT_MAX ? 0 : off + len;
-    for (int o = 32; o > 0; o >>= 1) end = max(end, __shfl_xor(end, o));
+    int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0;
+    for (int o = 32; o > 0; o >>= 1) { begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); }
     __builtin_amdgcn_wave_barrier();
     if (begin == INT_MAX) return;
     for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
@@ -495,21 +569,17 @@ __global__ __launch_bounds__(TPB) void k_expand(const int64_t *dscal, const uint
 // voxel segments of the point order: {first k, end k, voxel id, -} + sort keys that order the segments by length class
 // (longest first).  The chain hands segments to quads in that order, so the 16 quads of a wavefront walk segments of
 // similar length (a wavefront issues for as long as its longest segment lasts) and the longest voxels start first.
-__global__ __launch_bounds__(TPB) void k_seg_bounds(const int64_t *bscal, const int64_t *dscal, int64_t n_bound,
-                                                    const int32_t *__restrict__ run_heads,
-                                                    const uint32_t *__restrict__ rkey_sorted,
-                                                    const int32_t *__restrict__ run_len,
-                                                    const int32_t *__restrict__ run_off, int4 *__restrict__ seg_info,
+__global__ __launch_bounds__(TPB) void k_seg_bounds(const int64_t *bscal, int64_t n_bound, const int32_t *__restrict__ seg_k0,
+                                                    const int32_t *__restrict__ seg_vid, int4 *__restrict__ seg_info,
                                                     uint32_t *__restrict__ okey, uint32_t *__restrict__ oval)
 {
-    const int64_t nseg = bscal[0], R = dscal[DS_B_NRUN];
+    const int64_t nseg = bscal[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < n_bound; s += (int64_t)gridDim.x * TPB) {
         uint32_t key = 63u;
         if (s < nseg) {
-            const int32_t h = run_heads[s];
-            const int32_t k0 = run_off[h];
-            const int32_t k1 = s + 1 < nseg ? run_off[run_heads[s + 1]] : run_off[R - 1] + run_len[R - 1];
-            seg_info[s] = make_int4(k0, k1, (int32_t)rkey_sorted[h], 0);
+            const int32_t k0 = seg_k0[s];
+            const int32_t k1 = s + 1 < nseg ? seg_k0[s + 1] : (int32_t)bscal[2];
+            seg_info[s] = make_int4(k0, k1, seg_vid[s], 0);
             key = (uint32_t)__clz(k1 - k0);          // 2^(31-key) <= length < 2^(32-key)
         }
         okey[s] = key;
@@ -616,8 +686,9 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         return BSC_E_CAPACITY;
     }
     if (P == 0) return BSC_OK;
-    const dim3 block(TPB), grid((unsigned)((P + TPB - 1) / TPB));
+    const dim3 block(TPB);
     hipStream_t s = x->stream;
+    const bool exact = x->c.mode == BSC_MODE_EXACT;
     // scratch set of this call; the rgb chain of the call before last may still be reading it on the side stream
     const int set = x->cur_set;
     x->cur_set ^= 1;
@@ -626,51 +697,69 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     uint32_t *skey_b = x->skey_b_s[set];
     if (idx)
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
+    BSC_HIP(hipMemsetAsync(x->dscal + DS_B_NNEW, 0, sizeof(int64_t), s));
     GeomConst gc = make_geom_const(x);
-    hipLaunchKernelGGL(k_points, grid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, x->d_transforms,
-                       alpha, P, x->occ, x->p_cell, x->p_patf, p_rec, x->c.mode == BSC_MODE_EXACT ? x->p_r2f : (float *)nullptr);
+    // a run's length travels in the key bits beside the voxel id: the id field is sized for the voxel capacity, the
+    // rest (at most 10 bits: runs end with their 1024-point block) holds length - 1
+    const int vb = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
+    const int lb = 32 - vb < 10 ? 32 - vb : 10;
+    const int cap_mask = (1 << lb) - 1;
     const int64_t nblk = (P + FB - 1) / FB;
     const dim3 fgrid((unsigned)nblk);
-    hipLaunchKernelGGL(k_flags, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_in, x->blk_cnt);
-    BSC_TRY(prim_exclusive_sum_i64(x, x->p_scan_in, x->p_scan_out, (size_t)nblk));
+    const bool all_px_dense = !exact && idx == nullptr && x->geom_fast;     // the patch comes from the pixel: no p_patf
+    uint32_t *patf = all_px_dense ? (uint32_t *)nullptr : x->p_patf;
+    float *r2f = exact ? x->p_r2f : (float *)nullptr;
+    const float inv_w = 1.0f / (float)x->c.width;
+    if (gc.fast)
+        hipLaunchKernelGGL(k_points<true>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
+                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
+                           x->dscal, x->blk_cnt, x->blk_pass);
+    else
+        hipLaunchKernelGGL(k_points<false>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
+                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
+                           x->dscal, x->blk_cnt, x->blk_pass);
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
-    // k_assign reads occ while other blocks overwrite claimed cells with ids: a claim INT_MIN + j can only be
-    // replaced by the id of that same point j, so the flags of every other point are unaffected
-    hipLaunchKernelGGL(k_assign, fgrid, block, 0, s, P, x->p_cell, x->occ, x->p_scan_out, x->dscal, x->c.voxel_capacity,
-                       x->c.grid_size, x->nh, x->rgb_pos, x->c.mode == BSC_MODE_EXACT ? x->pass_list : (int32_t *)nullptr,
-                       x->blk_off, x->run_j0);
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->p_scan_in, x->p_scan_out, x->dscal,
-                       x->c.voxel_capacity, x->bscal_s[set], x->blk_cnt, x->blk_off);
-    BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr));
-    // one small readback per call: voxel count (sort width), pair count (dense modes), passing points (exact mode),
-    // capacity flag.  Everything enqueued so far is the call's front end; the back end is sized from these numbers.
+    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
+                       x->c.voxel_capacity, x->bscal_s[set]);
+    BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr, patf));
+    // one small readback per call: new voxels, runs, pairs (dense modes), passing points (exact mode), capacity flag.
+    // Everything enqueued so far is the call's front end; the back end is sized from these numbers.
     BSC_TRY(read_scalars(x));
+    const int64_t n_new_listed = x->hscal[DS_B_NNEW], n_new = x->hscal[DS_B_NFIRST];
+    // ids of the new voxels: rank of their winning point among the winners (memory_2.py:888-894)
+    if (n_new_listed > 0) {
+        const dim3 ngrid((unsigned)((n_new_listed + TPB - 1) / TPB));
+        hipLaunchKernelGGL(k_new_keys, ngrid, block, 0, s, n_new_listed, x->new_cells, x->occ, x->skey_a, x->sval_a);
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)n_new_listed, 0,
+                                    ceil_log2_u64((uint64_t)P + 1)));
+        hipLaunchKernelGGL(k_new_assign, ngrid, block, 0, s, n_new_listed, n_new, x->run_val_b, x->occ, x->dscal,
+                           x->c.grid_size, x->nh, x->rgb_pos);
+    }
     if (x->hscal[DS_ERROR]) {
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
         return BSC_E_CAPACITY;
     }
-    // ids in use are < max_id; invalid points carry 0xffffffff, which must still sort last under the bit mask
-    const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
     // their expansion is the per-voxel point order
     const int64_t R = x->hscal[DS_B_NRUN];
-    const dim3 rgrid((unsigned)((R + TPB - 1) / TPB));
     uint32_t *sj = x->sval_b_s[set];
-    hipLaunchKernelGGL(k_run_keys, rgrid, block, 0, s, x->dscal, x->run_j0, x->p_cell, x->occ, x->skey_a, x->sval_a);
-    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits));
-    hipLaunchKernelGGL(k_run_len, rgrid, block, 0, s, x->dscal, P, skey_b, x->run_val_b, x->run_j0, x->run_len);
-    BSC_TRY(prim_exclusive_sum_i32(x, x->run_len, x->run_off, (size_t)R));
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)((R + TPB - 1) / TPB)), block, 0, s, x->dscal, x->run_val_b, x->run_j0,
-                       x->run_len, x->run_off, sj);
-    BSC_TRY(compact_heads_u32(x, skey_b, R, x->run_heads, x->bscal_s[set]));
+    hipLaunchKernelGGL(k_runs, fgrid, block, 0, s, P, vb, cap_mask, x->p_cell, x->occ, x->blk_off, x->blk_pass_off, x->skey_a,
+                       x->sval_a, exact ? x->pass_list : (int32_t *)nullptr);
+    // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
+    const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
+    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+    BSC_TRY(prim_scan_runs(x, skey_b, vb, x->run_scan, (size_t)R));
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((R + TPB - 1) / TPB)), block, 0, s, R, vb, skey_b, x->run_val_b, x->run_scan, sj,
+                       x->seg_k0, x->seg_vid, x->bscal_s[set]);
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
     if (n_bound > seg_cap) n_bound = seg_cap;
-    hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, s, x->bscal_s[set], x->dscal, n_bound, x->run_heads, skey_b,
-                       x->run_len, x->run_off, x->seg_info_s[set], x->skey_a, x->sval_a);
+    hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, s, x->bscal_s[set], n_bound, x->seg_k0, x->seg_vid,
+                       x->seg_info_s[set], x->skey_a, x->sval_a);
     if (n_bound > 0)
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->run_len, x->sval_a, (uint32_t *)x->run_off, (size_t)n_bound, 0, 6));
-    hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->run_off, x->seg_info_s[set]);
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
+    hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->seg_vid, x->seg_info_s[set]);
     // rgb chain + top-down map on the side stream: sequential-latency bound, so it overlaps the
     // HBM-bound dense reduce of this call and whatever the caller enqueues next (the next batch's encoder)
     BSC_HIP(hipEventRecord(x->ev_ready[set], s));

@@ -279,3 +279,73 @@ def test_very_long_voxel_chains_against_oracle():
     segment (prefetch pipeline, longest-first queue, segments far longer than the wavefront count) — bit-exact rgb."""
     longest, n_vox = _dense_vs_oracle(480, 640, 14, 32, 32, 1.0, -16.0, 16.0, F=6, per_call=6, seed=9, vcap=40_000)
     assert longest > 100_000 and n_vox < 2000
+
+
+@pytest.mark.parametrize("hw,g", [((480, 640), 14), ((240, 320), 16), ((680, 680), 16), ((97, 131), 7)])
+def test_fast_geometry_equals_generic_chain(hw, g):
+    """k_points' fast path (pinhole collapse of the fma chains, x / cs through the exact reciprocal form, shared
+    reciprocal of p2, per-pixel patch tables) against the generic per-point chains (BSC_GENERIC_GEOMETRY=1 forces them;
+    they are what the geometry goldens pin): identical ids, rgb bytes, weights, top-down map, counts and feature rows,
+    every pixel and sub-sampled."""
+    import os
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import synthetic
+    H, W = hw
+    D, gs, F = 16, 256, 3
+    poses = synthetic.random_walk_poses(5, F)
+    rgb, depth, _ = synthetic.make_frames(5, F, H, W, "room", poses=poses)
+    depth[1] = synthetic.make_frames(6, 1, H, W, "iid")[1][0]          # one frame of worst-case depth
+    tok = torch.randn((F, g, g, D), device="cuda")
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    rs = np.random.RandomState(0)
+    idxs = [np.sort(rs.permutation(H * W)[:H * W // 3]).astype(np.int32) for _ in range(F)]
+    off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
+    idx = torch.from_numpy(np.concatenate(idxs)).cuda()
+
+    def build(generic):
+        if generic:
+            os.environ["BSC_GENERIC_GEOMETRY"] = "1"
+        try:
+            e = B.VoxelEngine(H, W, gs, 0.1, -12.8, 12.8, g, D, mode="max", voxel_capacity=500_000, max_points=F * H * W)
+        finally:
+            os.environ.pop("BSC_GENERIC_GEOMETRY", None)
+        e.ingest(depth, rgb, tok, Ts)
+        e.ingest(depth, rgb, tok, Ts, idx, off)
+        out = e.export_rgb() + e.export_heightmap() + e.export_dense()
+        e.close()
+        return out
+
+    a, b = build(False), build(True)
+    assert len(a[0]) > 1000
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_cold_start_every_voxel_new_and_capacity_boundary():
+    """A first call in which every voxel is new (claims, new-cell list, id ranking) against the oracle at a size where
+    thousands of points race for each cell, then a call that hits the voxel capacity exactly at its boundary."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    H, W, g, D, gs, F = 240, 320, 14, 8, 64, 4
+    rgb, depth, poses = synth.make_frames(12, F, H, W, "iid")
+    tokens = synth.make_tokens(12, F, g, D)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.2, -6.4, 6.4, g, D, mode=1), voxel_capacity=300_000)
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f])
+    n = om.counters()["max_id"]
+    d, c, t = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    eng = B.VoxelEngine(H, W, gs, 0.2, -6.4, 6.4, g, D, mode="mean", voxel_capacity=n, max_points=F * H * W)   # exactly enough
+    eng.ingest(d, c, t, Ts)
+    assert eng.counters()["max_id"] == n and np.array_equal(eng.export_rgb()[0], om.export_rgb()[0])
+    assert np.array_equal(eng.export_dense()[1], om.export_dense()[1])
+    eng.close()
+    small = B.VoxelEngine(H, W, gs, 0.2, -6.4, 6.4, g, D, mode="mean", voxel_capacity=n - 1, max_points=F * H * W)
+    with pytest.raises(B._lib.BscError, match="capacity"):
+        small.ingest(d, c, t, Ts)
+    small.close()
