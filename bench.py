@@ -2,20 +2,27 @@
 """bench.py — RGB-D frames/s into the voxel feature memory (BASELINE.json metric), one rank per GPU.
 
 A step = one batch of synthetic 640x480 RGB-D frames through the hot path, inputs resident in HBM:
-    ViT-B/16 patch features (random weights, bf16 MFMA via PyTorch-ROCm)  ->  libbscnav bsc_ingest
-    (fp64 unprojection, first-touch voxel ids, rgb chain, top-down map, dense per-voxel feature reduce).
-Workload: BASELINE.json configs[1] — 640x480 frames, 768-D tokens (14x14 patch grid), 256^3 grid of 0.1 m
-cells, every pixel ingested (depth_sample_rate 1), "room" depth (camera random-walking inside an 8x3x6 m box).
+    ViT patch features (random weights, bf16 MFMA via PyTorch-ROCm/hipBLASLt + libbscnav's fused kernels)
+    -> libbscnav bsc_ingest (fp64 unprojection, first-touch voxel ids, rgb chain, top-down map, dense per-voxel
+       feature reduce).
+Headline workload (`value`): BASELINE.json configs[1] — 640x480 frames, ViT-B/16 768-D tokens (14x14 patch grid), 256^3
+grid of 0.1 m cells, every pixel ingested (depth_sample_rate 1), "room" depth (camera random-walking inside an 8x3x6 m
+box).  The K timed steps are repeated (engine reset in between) and the MEDIAN repeat is reported.
 With N>1 ranks each rank ingests its own frame shard (weak scaling) and the per-rank maps are merged by one
 RCCL reduce-scatter at the end of the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (k_dense_reduce, HBM
-bound): algorithmic bytes / HIP-event time measured live; `cpu_baseline` is the plain-C oracle (port of
-the reference loop) timed on this box's host cores over a bounded sample of the same frames.
+Prints ONE JSON line (rank 0) carrying, beside the contract keys:
+  roofline        the whole bsc_ingest call priced per SURVEY.md §8(d) (algorithmic bytes of the batch / HIP-event time
+                  of the call's main-stream work), dominant kernel named; roofline_kernels: every stage with its own bytes
+  workloads       the same pipeline on "hall" (24 x 24 m, 10^5..10^6 voxels) and "iid" (one voxel per point) depth:
+                  frames/s, voxels, U/P, fraction of the §8(d) HBM bound
+  configs         BASELINE configs[2] per GPU (ViT-L/14, 1024-D, 512^3) and configs[3]/[4] localize at 2^20 x 1024
+  cpu_baseline    the plain-C oracle (port of the reference loop) on this box's host cores: 1 core and all cores
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -40,19 +47,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-
-
-def pmc_traffic():
-    """HBM bytes per k_dense_reduce launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_ingest_kernels.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- gfx950 FETCH_SIZE counts wide
-    coalesced reads at half (MI355X_MICROARCH.md, HBM).  None when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_ingest_kernels.json")) as f:
-            ks = json.load(f)["kernels"]
-        k = next(v for name, v in ks.items() if name.startswith("void k_dense_reduce<"))
-        return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
-    except Exception:
-        return None
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_F32_PEAK_TF = 157.3
+STAGES = {2: "k_points", 3: "k_keys_pairs", 4: "ids+point_order", 5: "pair_sort", 0: "k_dense_reduce", 6: "bsc_ingest",
+          7: "k_chain"}
 
 
 def parse():
@@ -61,24 +59,297 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=384, help="frames per step (per rank); 8 steps x 384 = 3072 frames")
-    ap.add_argument("--tokens", choices=["bf16", "f32"], default="f32",
-                    help="dtype the encoder hands to bsc_ingest: f32 like the reference's _get_patch_token, or its "
-                         "native bf16 (bsc_ingest_typed widens it exactly on load)")
-    ap.add_argument("--kind", default="room", choices=["room", "iid"])
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K timed steps; the median is reported")
+    ap.add_argument("--tokens", choices=["bf16", "f32"], default="bf16",
+                    help="dtype the encoder hands to bsc_ingest: its native bf16 (bsc_ingest_typed widens it exactly on "
+                         "load) or f32 like the reference's _get_patch_token")
+    ap.add_argument("--kind", default="room", choices=["room", "hall", "iid"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the encoder eagerly instead of a HIP graph")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap encoder(s+1) with ingest(s)")
     ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
     ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
-    ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurement")
-    ap.add_argument("--no-iid", action="store_true", help="skip the iid-depth (HBM-bound regime) measurement of k_dense_reduce")
+    ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurements")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the hall / iid workloads and the C3 leg")
     return ap.parse_args()
+
+
+def ingest_alg_bytes(F, N, g, D, tok_bytes, U, P_sampled=0):
+    """SURVEY.md §8(d) bytes of a batch of F frames: depth + RGBA once, patch tokens once, RMW of the feature row and
+    count of every voxel the batch touches, its rgb / weight / position, the sample indices."""
+    return F * (8 * N + g * g * D * tok_bytes) + U * (2 * D * 4 + 8) + U * 2 * (3 + 4 + 12) + 4 * P_sampled
+
+
+def pmc_traffic():
+    """HBM bytes per bsc_ingest call from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r02_pmc_ingest_kernels.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the call's kernels —
+    gfx950 FETCH_SIZE counts wide coalesced reads at half, MI355X_MICROARCH.md, HBM).  The file names the commit it was
+    measured at; None when it is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_ingest_kernels.json")) as f:
+            d = json.load(f)
+        tot = sum(2.0 * v.get("FETCH_SIZE_KiB_per_launch", 0.0) * v.get("launches_per_call", 1.0) +
+                  v.get("WRITE_SIZE_KiB_per_launch", 0.0) * v.get("launches_per_call", 1.0)
+                  for k, v in d["kernels"].items() if v.get("ingest"))
+        return tot * 1024.0, d.get("commit")
+    except Exception:
+        return None, None
+
+
+class Pipeline:
+    """Encoder (own stream, HIP graph) + bsc_ingest (main stream), tokens double-buffered; frames resident in HBM."""
+
+    def __init__(self, a, kind, arch, grid, batch, n_steps, rank, local_rank, vit=None, vcap=None):
+        import bsc_nav_amd as B
+        from bsc_nav_amd import synthetic, encoder
+        self.B, self.a, self.kind, self.batch, self.n_steps = B, a, kind, batch, n_steps
+        H, W, cs = a.height, a.width, 0.1
+        self.H, self.W, self.N = H, W, H * W
+        self.vit = vit if vit is not None else encoder.RandomViT(arch, image_size=224, seed=0).cuda()
+        self.g, self.D = self.vit.grid, self.vit.out_dim
+        half = grid * cs / 2.0
+        n_frames = n_steps * batch
+        if vcap is None:
+            vcap = {"room": 3_000_000, "hall": 3_000_000}.get(kind, min(grid ** 3, 6_000_000))
+        self.eng = B.VoxelEngine(H, W, grid, cs, -half, half, self.g, self.D, mode=a.mode, voxel_capacity=vcap,
+                                 max_points=batch * self.N, device=local_rank)
+        poses = synthetic.make_poses(kind, 1000 + rank, n_frames)
+        chain = B.PoseChain()
+        self.Ts = np.stack([chain.pc_transform(p) for p in poses])
+        self.rgbs, self.depths = [], []
+        for s in range(n_steps):
+            r, d, _ = synthetic.make_frames(17 + 1000 * rank + s, batch, H, W, kind, device="cuda",
+                                            poses=poses[s * batch:(s + 1) * batch])
+            self.rgbs.append(r)
+            self.depths.append(d)
+        self.NBUF = a.prefetch + 1
+        bf16 = a.tokens == "bf16"
+        if a.no_graph:
+            self.encs = [lambda r: self.vit.patch_tokens(r, bf16)] * self.NBUF
+        else:
+            self.encs = [encoder.GraphedEncoder(self.vit, batch, H, W, 4, bf16) for _ in range(self.NBUF)]
+        self.enc_stream = torch.cuda.Stream()
+        self.main_stream = torch.cuda.current_stream()
+        self.tok_ready = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.tok_free = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.pending = {}
+        for b in range(self.NBUF):
+            self.tok_free[b].record(self.main_stream)
+
+    def _encode_async(self, s):
+        b = s % self.NBUF
+        with torch.cuda.stream(self.enc_stream):
+            self.enc_stream.wait_event(self.tok_free[b])          # ingest of batch s-NBUF no longer reads this token buffer
+            tok = self.encs[b](self.rgbs[s])
+            if self.a.no_graph:
+                tok.record_stream(self.main_stream)               # eager mode: the allocator must not recycle it early
+            self.pending[s] = tok
+            self.tok_ready[b].record(self.enc_stream)
+
+    def step(self, s, stop):
+        for k in range(0 if self.a.no_overlap else self.NBUF):
+            if s + k < stop and s + k not in self.pending:
+                self._encode_async(s + k)
+        if s not in self.pending:
+            self._encode_async(s)
+        b = s % self.NBUF
+        self.main_stream.wait_event(self.tok_ready[b])
+        self.eng.ingest(self.depths[s], self.rgbs[s], self.pending.pop(s), self.Ts[s * self.batch:(s + 1) * self.batch])
+        self.tok_free[b].record(self.main_stream)
+
+    def run(self, lo, hi):
+        for s in range(lo, hi):
+            self.step(s, hi)
+
+    def reset_stats(self):
+        for w in STAGES:
+            self.eng.kernel_stats(w, reset=True)
+
+    def stage_ms(self):
+        out = {}
+        for w, name in STAGES.items():
+            k = self.eng.kernel_stats(w)
+            out[name] = k["ms"] / max(1, k["launches"])
+        return out
+
+    def isolated(self, lo, hi):
+        """Untimed extra pass: the encoder alone, then bsc_ingest alone (un-contended stage times)."""
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        enc = self.encs[0]
+        tok = enc(self.rgbs[lo])
+        e0.record()
+        for s in range(lo, hi):
+            tok = enc(self.rgbs[s])
+        e1.record()
+        torch.cuda.synchronize()
+        c0 = self.eng.counters()
+        self.reset_stats()
+        for s in range(lo, hi):
+            self.eng.ingest(self.depths[s], self.rgbs[s], tok, self.Ts[s * self.batch:(s + 1) * self.batch])
+        e2.record()
+        self.eng.sync()
+        torch.cuda.synchronize()
+        k = hi - lo
+        c1 = self.eng.counters()
+        return dict(encoder_ms=e0.elapsed_time(e1) / k, ingest_wall_ms=e1.elapsed_time(e2) / k, stages=self.stage_ms(),
+                    U=(c1["voxel_rmw"] - c0["voxel_rmw"]) / k, U_new=(c1["max_id"] - c0["max_id"]) / k,
+                    P=(c1["points_passed"] - c0["points_passed"]) / k, pairs=(c1["pairs"] - c0["pairs"]) / k)
+
+    def close(self):
+        self.eng.close()
+        self.rgbs, self.depths, self.encs = [], [], []
+        torch.cuda.empty_cache()
+
+
+def stage_rooflines(p, iso, tok_bytes):
+    """Every stage with its own algorithmic bytes (what it must read / write once) and measured HIP-event time."""
+    F, N, g, D = p.batch, p.N, p.g, p.D
+    U, U_new, pairs, P = iso["U"], iso["U_new"], iso["pairs"], F * N
+    st = iso["stages"]
+    byts = {
+        "k_points": 8.0 * P,                                                   # depth f32 + RGBA u8 read once
+        "k_keys_pairs": 4.0 * P + 12.0 * pairs,                                # cells in, pairs out
+        "pair_sort": 2 * 12.0 * pairs,                                         # pairs in / out once
+        "k_dense_reduce": (2 * U - U_new) * D * 4 + 8 * U + F * g * g * D * tok_bytes + 12 * pairs,
+        "ids+point_order": 4.0 * P + 4.0 * P,                                  # cells in, per-voxel point order out
+        "k_chain": 16.0 * P + 19.0 * U,                                        # order index + record per point, voxel state
+    }
+    out = {}
+    for name, b in byts.items():
+        ms = st.get(name, 0.0)
+        if ms > 0:
+            out[name] = {"ms_per_call": ms, "bytes_per_call": b, "GBs": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
+    return out
+
+
+def localize_leg(B, a, local_rank, D, V=1 << 20, gL=512):
+    g = 16
+    engL = B.VoxelEngine(a.height, a.width, gL, 0.1, -gL * 0.05, gL * 0.05, g, D, mode="mean", voxel_capacity=V + 8,
+                         max_points=1024, device=local_rank)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    codes = torch.randperm(gL ** 3, device="cuda", generator=gen)[:V]
+    keys = torch.stack([codes // (gL * gL), (codes // gL) % gL, codes % gL], dim=1).to(torch.int32).contiguous()
+    rows = torch.randn((V, D), device="cuda", generator=gen)
+    engL.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
+    loc = {"voxels": V, "dim": D, "K": 100, "grid": gL}
+    for Q in (1, 8, 256):
+        q = torch.randn(Q, D, device="cuda", generator=gen)
+        pos, sim, cnt = engL.localize(q, K=100)
+        if Q == 1:      # correctness at this size, inside the bench: the top-1 of an independent fp64 scan
+            rn = rows.double() / rows.double().norm(dim=1, keepdim=True)
+            ref = (rn @ (q[0].double() / q[0].double().norm())).argmax().item()
+            assert pos[0, 0].tolist() == keys[ref].tolist(), "localize top-1 differs from the fp64 scan"
+            del rn
+        engL.kernel_stats(1, reset=True)
+        lats = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            engL.localize(q, K=100)
+            torch.cuda.synchronize()
+            lats.append(time.perf_counter() - t)
+        ls = engL.kernel_stats(1)
+        ms = ls["ms"] / max(1, ls["launches"])
+        e = {"latency_ms": statistics.median(lats) * 1e3, "cosine_ms": ms}
+        if Q >= 16:     # fp32-MFMA GEMM path: priced against the 157.3 TFLOP/s fp32 matrix peak
+            tf = 2.0 * V * D * Q / (ms * 1e-3) / 1e12
+            e.update({"cosine_TFLOPs": tf, "cosine_frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TF})
+        else:
+            gbs = ls["bytes"] / max(1, ls["launches"]) / (ms * 1e-3) / 1e9
+            e.update({"cosine_GBs": gbs, "cosine_frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+        loc[f"q{Q}"] = e
+    engL.close()
+    del rows
+    torch.cuda.empty_cache()
+    return loc
+
+
+# ---- CPU baseline (the only place bench.py touches oracle/) ------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_worker(job):
+    """One host process: its frame shard through the plain-C oracle into a private map -> (keys, acc, cnt)."""
+    from oracle import oracle as orc
+    lo, hi, vcap = job
+    H, W, gs, half, g, D, mode, Ts, dep, rgb, tok = _CPU["args"]
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -half, half, g, D, mode=mode), voxel_capacity=vcap)
+    t = time.perf_counter()
+    for f in range(lo, hi):
+        om.ingest_frame(dep[f], rgb[f], None, Ts[f], tok[f])
+    dt = time.perf_counter() - t
+    pos = om.export_rgb()[0]
+    acc, cnt = om.export_dense()
+    return dt, pos, acc, cnt
+
+
+def cpu_baseline(a, p, seconds):
+    """1 core: first frames of the workload, sequential.  All cores: frame-sharded private maps (one process per hardware
+    thread) + a NumPy merge by voxel key — the CPU counterpart of the multi-GPU path."""
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    H, W, g, D = p.H, p.W, p.g, p.D
+    gs = p.eng.cfg.grid_size
+    half = gs * 0.05
+    mode = 1 if a.mode == "mean" else 2
+    nb = min(p.n_steps, 4)
+    tok = np.concatenate([p.vit.patch_tokens(p.rgbs[s]).float().cpu().numpy() for s in range(nb)])
+    rgb = np.concatenate([p.rgbs[s].cpu().numpy() for s in range(nb)])
+    dep = np.concatenate([p.depths[s].cpu().numpy() for s in range(nb)])
+    Ts = p.Ts[:len(dep)]
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -half, half, g, D, mode=mode), voxel_capacity=2_000_000)
+    nf, cdt = 0, 0.0
+    while nf < len(dep) and (cdt < seconds or nf < 2):
+        t = time.perf_counter()
+        om.ingest_frame(dep[nf], rgb[nf], None, Ts[nf], tok[nf])
+        cdt += time.perf_counter() - t
+        nf += 1
+    del om
+    one = {"value": nf / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"first {nf} frames of the same workload through oracle/bsc_oracle.c (memory path only: geometry + "
+                     f"voxel scatter, encoder excluded), {cdt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    # all cores
+    ncpu = os.cpu_count() or 1
+    per = max(1, min(len(dep) // ncpu, int(one["value"] * seconds)))         # frames per worker: ~`seconds` of work each
+    W_ = min(ncpu, len(dep) // per)
+    vcap = 400_000
+    try:
+        free_kb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1])
+        W_ = max(1, min(W_, int(free_kb * 1024 * 0.5 / (vcap * D * 4 + gs * gs * p.eng.nh * 4))))
+    except Exception:
+        pass
+    _CPU["args"] = (H, W, gs, half, g, D, mode, Ts, dep, rgb, tok)
+    jobs = [(w * per, (w + 1) * per, vcap) for w in range(W_)]
+    ctx = mp.get_context("fork")                       # children share the staged frames copy-on-write; they never touch HIP
+    with ctx.Pool(W_) as pool:
+        pool.map(abs, range(W_))                       # workers up before the clock starts
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
+        t_ingest = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    keys = np.concatenate([r[1] for r in res]).astype(np.int64)
+    code = (keys[:, 0] << 42) | (keys[:, 1] << 21) | keys[:, 2]
+    order = np.argsort(code, kind="stable")
+    starts = np.flatnonzero(np.concatenate([[True], code[order][1:] != code[order][:-1]]))
+    rows = np.concatenate([r[2] for r in res])[order]
+    acc = np.add.reduceat(rows, starts, axis=0) if mode == 1 else np.maximum.reduceat(rows, starts, axis=0)
+    cnt = np.add.reduceat(np.concatenate([r[3] for r in res]).astype(np.int64)[order], starts)
+    uniq = starts
+    assert acc.shape[0] == len(starts) == len(cnt)
+    t_merge = time.perf_counter() - t1
+    _CPU.clear()
+    allc = {"value": W_ * per / (t_ingest + t_merge), "unit": "frames/s", "cores": W_, "kind": "port",
+            "sample": f"{W_} processes x {per} frames of the same workload, private maps + NumPy merge by voxel key "
+                      f"({t_ingest:.1f} s ingest incl. map allocation, {t_merge:.1f} s merge of {len(uniq)} voxels); "
+                      f"{ncpu} hardware threads on the box"}
+    return one, allc
 
 
 def main():
@@ -100,63 +371,16 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     import bsc_nav_amd as B
-    from bsc_nav_amd import synthetic, encoder, dist as bdist
+    from bsc_nav_amd import dist as bdist
 
-    H, W, gs, cs = a.height, a.width, a.grid, 0.1
-    vit = encoder.RandomViT(a.arch, image_size=224, seed=0).cuda()
-    g, D = vit.grid, vit.out_dim
-    half = gs * cs / 2.0
-    N = H * W
-    n_steps = a.steps + a.warmup
-    n_frames = n_steps * a.batch
-    vcap = 3_000_000 if a.kind == "room" else min(gs ** 3, max(3_000_000, n_frames * N))
     # the ingest is the latency-critical stage of the pipeline: its stream (and the library's side stream) are
     # high priority, the MFMA-bound encoder fills the rest of the machine from a normal-priority stream
     ing_stream = torch.cuda.Stream(priority=-1 if a.priority else 0)
     torch.cuda.set_stream(ing_stream)
-    eng = B.VoxelEngine(H, W, gs, cs, -half, half, g, D, mode=a.mode, voxel_capacity=vcap, max_points=a.batch * N,
-                        device=local_rank)
-    # ---- synthetic frames of this rank's shard, resident in HBM before the clock starts ----
-    poses = synthetic.random_walk_poses(1000 + rank, n_frames)
-    chain = B.PoseChain()
-    Ts = np.stack([chain.pc_transform(p) for p in poses])
-    rgbs, depths = [], []
-    for s in range(n_steps):
-        r, d, _ = synthetic.make_frames(17 + 1000 * rank + s, a.batch, H, W, a.kind, device="cuda",
-                                        poses=poses[s * a.batch:(s + 1) * a.batch])
-        rgbs.append(r)
-        depths.append(d)
-    # Two-stage software pipeline: the encoder of batch s+1 (MFMA-bound) runs on its own HIP stream while
-    # bsc_ingest of batch s (HBM / latency-bound) runs on the main stream; tokens are double-buffered.
-    NBUF = a.prefetch + 1   # token buffers: the encoder runs `prefetch` batches ahead of bsc_ingest
-    if a.no_graph:
-        encs = [lambda r: vit.patch_tokens(r, a.tokens == "bf16")] * NBUF
-    else:
-        encs = [encoder.GraphedEncoder(vit, a.batch, H, W, 4, a.tokens == "bf16") for _ in range(NBUF)]
-    enc = encs[0]
-    enc_stream = torch.cuda.Stream()
-    main_stream = torch.cuda.current_stream()
-    tok_ready = [torch.cuda.Event() for _ in range(NBUF)]
-    tok_free = [torch.cuda.Event() for _ in range(NBUF)]
-    pending = {}
-
-    def encode_async(s):
-        b = s % NBUF
-        with torch.cuda.stream(enc_stream):
-            enc_stream.wait_event(tok_free[b])          # ingest of batch s-2 no longer reads this token buffer
-            pending[s] = encs[b](rgbs[s])
-            tok_ready[b].record(enc_stream)
-
-    def step(s, stop):
-        for k in range(0 if a.no_overlap else NBUF):
-            if s + k < stop and s + k not in pending:
-                encode_async(s + k)
-        if s not in pending:
-            encode_async(s)
-        b = s % NBUF
-        main_stream.wait_event(tok_ready[b])
-        eng.ingest(depths[s], rgbs[s], pending.pop(s), Ts[s * a.batch:(s + 1) * a.batch])
-        tok_free[b].record(main_stream)
+    n_steps = a.steps + a.warmup
+    p = Pipeline(a, a.kind, a.arch, a.grid, a.batch, n_steps, rank, local_rank)
+    g, D, N = p.g, p.D, p.N
+    tok_bytes = 2 if a.tokens == "bf16" else 4
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,27 +389,32 @@ def main():
         torch.cuda.synchronize()
 
     bdist.warmup_collectives(torch.device("cuda", local_rank))
-    for b in range(NBUF):
-        tok_free[b].record(main_stream)
-    for s in range(a.warmup):
-        step(s, a.warmup)
-    barrier()
-    c0 = eng.counters()
-    eng.kernel_stats(0, reset=True)
-    t0 = time.perf_counter()
-    for s in range(a.warmup, n_steps):
-        step(s, n_steps)
-    merge_info = None
-    if world > 1:
-        merge_info = bdist.merge_dense_maps(eng)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ks = eng.kernel_stats(0)
-    c1 = eng.counters() if world == 1 else None
+    p.run(0, a.warmup)
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks; repeated, median ----
+    times, merge_info, stage_timed, c0, c1 = [], None, None, None, None
+    for rep in range(max(1, a.repeats)):
+        if rep > 0:                       # identical work in every repeat: empty map, same frames
+            p.eng.reset()
+            p.run(0, a.warmup)
+        barrier()
+        c0 = p.eng.counters()
+        p.reset_stats()
+        t0 = time.perf_counter()
+        p.run(a.warmup, n_steps)
+        if world > 1:
+            merge_info = bdist.merge_dense_maps(p.eng)
+        p.eng.sync()                      # incl. the rgb chain of the last step, which the library launches lazily
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        times.append(dt)
+        if world == 1:
+            stage_timed = p.stage_ms()
+            c1 = p.eng.counters()
+    dt = statistics.median(times)
 
     out = None
     if rank == 0:
@@ -193,150 +422,99 @@ def main():
         out = {
             "metric": "RGB-D frames/sec into voxel feature memory", "value": frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry / f32 features" + (" (bf16 tokens in)" if a.tokens == "bf16" else ""),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"bf16 encoder (MFMA, f32 accumulate; the reference's DINOv2 runs f32) -> {a.tokens} tokens; "
+                     "f64 geometry, u8/f32 rgb chain, f32 feature accumulation",
             "data": "synthetic",
-            "config": {"workload": f"{a.batch * a.steps} synthetic {W}x{H} RGB-D frames per GPU ({a.kind} depth, every "
-                                   f"pixel), {a.arch} random weights {D}-D tokens {g}x{g}, {gs}^3 grid of {cs} m cells, "
+            "repeats": len(times), "seconds_per_repeat": times, "timed_seconds_total": sum(times),
+            "config": {"workload": f"{a.batch * a.steps} synthetic {p.W}x{p.H} RGB-D frames per GPU ({a.kind} depth, every "
+                                   f"pixel), {a.arch} random weights {D}-D tokens {g}x{g}, {a.grid}^3 grid of 0.1 m cells, "
                                    f"dense {a.mode} reduce" + (", + RCCL reduce-scatter merge" if world > 1 else ""),
                        "frames_per_step": a.batch, "parallelism": f"frames sharded x{world}"},
         }
         if merge_info:
             out["config"]["merge"] = merge_info
-    # ---- per-stage split (untimed extra pass) and roofline of the dominant hand-written kernel ----
     if rank == 0 and world == 1:
-        launches = max(1, ks["launches"])
-        tok_bytes = 2 if a.tokens == "bf16" else 4
-        U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per launch
-        U_new = (c1["max_id"] - c0["max_id"]) / a.steps
-        P_pass = (c1["points_passed"] - c0["points_passed"]) / a.steps
-        n_pairs = (c1["pairs"] - c0["pairs"]) / a.steps
-        # algorithmic bytes of one k_dense_reduce launch: accumulator rows RMW (new rows are
-        # written only) + counts + token tile once + the sorted (voxel,frame,patch) pair list (key 8 B + count 4 B)
-        alg = (2 * U - U_new) * D * 4 + 8 * U + a.batch * g * g * D * tok_bytes + 12 * n_pairs
-        ms = ks["ms"] / launches
-        achieved = alg / (ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_dense_reduce", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                           "bytes_per_launch": alg, "ms_per_launch": ms, "voxel_rows_per_launch": U,
-                           "points_per_launch": P_pass, "pairs_per_launch": n_pairs}
-        # stage split (untimed extra pass): the encoder alone, then bsc_ingest alone.  The second half doubles as an
-        # un-contended measurement of k_dense_reduce (in the timed region it shares the chip with the encoder's GEMMs).
-        torch.cuda.synchronize()
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        lo, hi = a.warmup, min(n_steps, a.warmup + 8)
-        tok = enc(rgbs[lo])
-        e0.record()
-        for s in range(lo, hi):
-            tok = enc(rgbs[s])
-        e1.record()
-        ci0 = eng.counters()
-        eng.kernel_stats(0, reset=True)
-        for s in range(lo, hi):
-            eng.ingest(depths[s], rgbs[s], tok, Ts[s * a.batch:(s + 1) * a.batch])
-        e2.record()
-        torch.cuda.synchronize()
-        k = hi - lo
-        ksi, ci1 = eng.kernel_stats(0), eng.counters()
-        Ui = (ci1["voxel_rmw"] - ci0["voxel_rmw"]) / k
-        alg_i = (2 * Ui - (ci1["max_id"] - ci0["max_id"]) / k) * D * 4 + 8 * Ui + a.batch * g * g * D * tok_bytes \
-            + 12 * (ci1["pairs"] - ci0["pairs"]) / k
-        ms_i = ksi["ms"] / max(1, ksi["launches"])
-        out["roofline_isolated"] = {"kernel": "k_dense_reduce", "note": "same workload, bsc_ingest running alone",
-                                    "achieved": alg_i / (ms_i * 1e-3) / 1e9, "unit": "GB/s",
-                                    "frac": alg_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_i,
-                                    "bytes_per_launch": alg_i}
-        enc_ms, ing_ms = e0.elapsed_time(e1) / k, e1.elapsed_time(e2) / k
-        out["stages"] = {"encoder_ms_per_step": enc_ms, "ingest_ms_per_step": ing_ms,
-                         "encoder_tflops": vit.flops_per_frame() * a.batch / (enc_ms * 1e-3) / 1e12,
+        U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per call
+        iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8))
+        alg = ingest_alg_bytes(a.batch, N, g, D, tok_bytes, U)
+        ing_ms = stage_timed["bsc_ingest"]
+        single = {k: v for k, v in stage_timed.items() if k in ("k_points", "k_keys_pairs", "k_dense_reduce")}
+        dom = max(single, key=single.get)
+        traffic, traffic_commit = pmc_traffic()
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "bsc_ingest: every kernel of one call, main stream (SURVEY.md 8d bytes of the batch)",
+            "achieved": alg / ing_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": None if traffic is None else f"profiles/r02_pmc_ingest_kernels.json @ {traffic_commit}",
+            "bytes_per_call": alg, "ms_per_call": ing_ms, "ms_per_call_isolated": iso["stages"]["bsc_ingest"],
+            "frac_isolated": alg / iso["stages"]["bsc_ingest"] / 1e6 / HBM_PEAK_GBS,
+            "voxel_rows_per_call": U, "points_per_call": (c1["points_passed"] - c0["points_passed"]) / a.steps,
+            "pairs_per_call": (c1["pairs"] - c0["pairs"]) / a.steps, "U_over_P": U / max(1.0, a.batch * N),
+            "dominant_kernel": dom, "dominant_kernel_ms": single[dom], "stage_ms_in_pipeline": stage_timed,
+        }
+        out["roofline_kernels"] = {"note": "bsc_ingest running alone (no encoder beside it); own algorithmic bytes per stage",
+                                   **stage_rooflines(p, iso, tok_bytes)}
+        enc_tf = p.vit.flops_per_frame() * a.batch / (iso["encoder_ms"] * 1e-3) / 1e12
+        out["stages"] = {"encoder_ms_per_step": iso["encoder_ms"], "ingest_ms_per_step": iso["ingest_wall_ms"],
+                         "chain_ms_per_step_side_stream": iso["stages"]["k_chain"],
+                         "encoder_tflops": enc_tf, "encoder_frac_of_bf16_mfma_peak": enc_tf / MFMA_BF16_PEAK_TF,
                          "voxels": c1["max_id"]}
-        if not a.no_iid:
-            # The same kernel in the regime the HBM roofline describes: "iid" depth (one voxel per point,
-            # U ~ P), where it is a pure accumulator read-modify-write stream instead of an L2-resident token re-read.
-            Fi, calls = 16, 4
-            engI = B.VoxelEngine(H, W, gs, cs, -half, half, g, D, mode=a.mode, voxel_capacity=min(gs ** 3, calls * Fi * N),
-                                 max_points=Fi * N, device=local_rank)
-            pi = synthetic.random_walk_poses(77, calls * Fi)
-            chain_i = B.PoseChain()
-            Ti = np.stack([chain_i.pc_transform(p) for p in pi])
-            toki = torch.randn((Fi, g, g, D), device="cuda")
-            fr = [synthetic.make_frames(900 + s, Fi, H, W, "iid", device="cuda", poses=pi[s * Fi:(s + 1) * Fi])
-                  for s in range(calls)]
-            engI.ingest(fr[0][1], fr[0][0], toki, Ti[:Fi])              # first call: every voxel is new (write-only rows)
+        # ---- CPU baseline on the same frames (before they are freed) ----
+        if not a.no_cpu_baseline:
+            one, allc = cpu_baseline(a, p, a.cpu_seconds)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = allc
+        vit = p.vit
+        p.close()
+        # ---- the same pipeline on the other depth distributions, and BASELINE configs[2] per GPU ----
+        if not a.no_workloads:
+            out["workloads"] = {"room": {"frames_per_s": out["value"], "voxels": out["stages"]["voxels"], "U_over_P": out["roofline"]["U_over_P"],
+                                         "ingest_ms_per_step": out["roofline"]["ms_per_call"], "frac_of_hbm_bound": out["roofline"]["frac"]}}
+            for kind, steps in (("hall", 8), ("iid", 4)):
+                q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
+                q.run(0, 2)
+                torch.cuda.synchronize()
+                k0 = q.eng.counters()
+                q.reset_stats()
+                t0 = time.perf_counter()
+                q.run(2, steps + 2)
+                q.eng.sync()
+                torch.cuda.synchronize()
+                dtk = time.perf_counter() - t0
+                k1, st = q.eng.counters(), q.stage_ms()
+                Uk = (k1["voxel_rmw"] - k0["voxel_rmw"]) / steps
+                algk = ingest_alg_bytes(a.batch, N, g, D, tok_bytes, Uk)
+                out["workloads"][kind] = {
+                    "frames_per_s": steps * a.batch / dtk, "steps": steps, "voxels": k1["max_id"], "U_over_P": Uk / (a.batch * N),
+                    "pairs_per_call": (k1["pairs"] - k0["pairs"]) / steps, "ingest_ms_per_step": st["bsc_ingest"],
+                    "bytes_per_call": algk, "frac_of_hbm_bound": algk / st["bsc_ingest"] / 1e6 / HBM_PEAK_GBS, "stage_ms": st}
+                q.close()
+            # configs[2] (C3) per GPU: ViT-L/14 tokens (16x16x1024) into a 512^3 grid
+            a3 = argparse.Namespace(**vars(a))
+            b3, s3 = 128, 4
+            q = Pipeline(a3, "hall", "vit_l14", 512, b3, s3 + 2, rank, local_rank, vcap=3_000_000)
+            q.run(0, 2)
             torch.cuda.synchronize()
-            cj0 = engI.counters()
-            engI.kernel_stats(0, reset=True)
-            for s in range(1, calls):
-                engI.ingest(fr[s][1], fr[s][0], toki, Ti[s * Fi:(s + 1) * Fi])
+            q.reset_stats()
+            t0 = time.perf_counter()
+            q.run(2, s3 + 2)
+            q.eng.sync()
             torch.cuda.synchronize()
-            ksj, cj1 = engI.kernel_stats(0), engI.counters()
-            kk = calls - 1
-            Uj = (cj1["voxel_rmw"] - cj0["voxel_rmw"]) / kk
-            alg_j = (2 * Uj - (cj1["max_id"] - cj0["max_id"]) / kk) * D * 4 + 8 * Uj + Fi * g * g * D * 4 \
-                + 12 * (cj1["pairs"] - cj0["pairs"]) / kk
-            ms_j = ksj["ms"] / max(1, ksj["launches"])
-            out["roofline_iid"] = {"kernel": "k_dense_reduce", "note": f"iid depth, {Fi} frames per call, bsc_ingest alone",
-                                   "achieved": alg_j / (ms_j * 1e-3) / 1e9, "unit": "GB/s",
-                                   "frac": alg_j / (ms_j * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_j,
-                                   "bytes_per_launch": alg_j, "voxel_rows_per_launch": Uj}
-            engI.close()
-            del fr, toki
+            dtk = time.perf_counter() - t0
+            iso3 = q.isolated(2, s3 + 2)
+            tf3 = q.vit.flops_per_frame() * b3 / (iso3["encoder_ms"] * 1e-3) / 1e12
+            out["configs"] = {"C3_vit_l14_1024d_grid512_per_gpu": {
+                "frames_per_s": s3 * b3 / dtk, "frames_per_step": b3, "steps": s3, "encoder_ms_per_step": iso3["encoder_ms"],
+                "ingest_ms_per_step": iso3["stages"]["bsc_ingest"], "encoder_tflops": tf3,
+                "encoder_frac_of_bf16_mfma_peak": tf3 / MFMA_BF16_PEAK_TF, "voxels": q.eng.counters()["max_id"], "depth": "hall"}}
+            q.close()
+        del vit
+        torch.cuda.empty_cache()
         if not a.no_localize:
-            # second half of the metric: localize top-K latency over a 2^20-voxel x D map (BASELINE configs[3]/[4] size)
-            V = 1 << 20
-            gL = 512
-            engL = B.VoxelEngine(H, W, gL, cs, -gL * cs / 2, gL * cs / 2, g, D, mode="mean", voxel_capacity=V + 8,
-                                 max_points=1024, device=local_rank)
-            gen = torch.Generator(device="cuda").manual_seed(5)
-            codes = torch.randperm(gL ** 3, device="cuda", generator=gen)[:V]
-            keys = torch.stack([codes // (gL * gL), (codes // gL) % gL, codes % gL], dim=1).to(torch.int32).contiguous()
-            rows = torch.randn((V, D), device="cuda", generator=gen)
-            engL.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
-            del rows
-            loc = {"voxels": V, "dim": D, "K": 100}
-            for Q in (1, 8, 256):
-                q = torch.randn(Q, D, device="cuda", generator=gen)
-                engL.localize(q, K=100)
-                engL.kernel_stats(1, reset=True)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                reps = 10
-                for _ in range(reps):
-                    engL.localize(q, K=100)
-                torch.cuda.synchronize()
-                lat = (time.perf_counter() - t) / reps
-                ls = engL.kernel_stats(1)
-                loc[f"q{Q}"] = {"latency_ms": lat * 1e3, "cosine_ms": ls["ms"] / max(1, ls["launches"]),
-                                "cosine_GBs": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9,
-                                "cosine_frac_of_hbm_peak": ls["bytes"] / max(1e-9, ls["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                if Q >= 16:     # fp32-MFMA GEMM path: price it against the 157.3 TFLOP/s fp32 matrix peak instead
-                    tf = 2.0 * V * D * Q / max(1e-9, ls["ms"] / max(1, ls["launches"]) * 1e-3) / 1e12
-                    loc[f"q{Q}"].update({"cosine_TFLOPs": tf, "cosine_frac_of_f32_mfma_peak": tf / 157.3})
-                    loc[f"q{Q}"].pop("cosine_GBs"), loc[f"q{Q}"].pop("cosine_frac_of_hbm_peak")
-            out["localize"] = loc
-            engL.close()
-    # ---- CPU baseline: the plain-C oracle (port of the reference loop) on a bounded sample ----
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import oracle as orc
-        oc = orc.make_config(H, W, gs, cs, -half, half, g, D, mode=1 if a.mode == "mean" else 2)
-        om = orc.OracleMemory(oc, voxel_capacity=2_000_000)
-        host = []
-        for s in range(min(n_steps, 2)):                # up to 256 frames staged on the host, outside the CPU clock
-            host.append((vit.patch_tokens(rgbs[s]).cpu().numpy(), rgbs[s].cpu().numpy(), depths[s].cpu().numpy()))
-        nf, cdt = 0, 0.0
-        for s, (tok_h, rgb_h, dep_h) in enumerate(host):
-            for f in range(a.batch):
-                t = time.perf_counter()
-                om.ingest_frame(dep_h[f], rgb_h[f], None, Ts[s * a.batch + f], tok_h[f])
-                cdt += time.perf_counter() - t
-                nf += 1
-                if cdt >= a.cpu_seconds and nf >= 2:
-                    break
-            if cdt >= a.cpu_seconds and nf >= 2:
-                break
-        out["cpu_baseline"] = {"value": nf / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"first {nf} frames of the same workload through oracle/bsc_oracle.c "
-                                         f"(memory path only: geometry + voxel scatter, encoder excluded), "
-                                         f"{cdt:.1f} s on 1 of {os.cpu_count()} host cores"}
+            # second half of the metric: localize top-K latency over a 2^20-voxel map (BASELINE configs[3]/[4] size)
+            out["localize"] = localize_leg(B, a, local_rank, D)
+            if D != 1024:
+                out.setdefault("configs", {})["C4_C5_localize_2pow20_x_1024_grid512"] = localize_leg(B, a, local_rank, 1024)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -13,6 +13,18 @@ struct PointRec {
     uint32_t rgbv;     // rgb[py, px] packed r | g << 8 | b << 16   (memory_2.py:870)
 };
 #define BSC_EV_RING 512
+// timed stages (bsc_kernel_stats `which`)
+enum {
+    BSC_STAT_DENSE = 0,    // k_dense_reduce
+    BSC_STAT_COSINE = 1,   // cosine scan of bsc_localize
+    BSC_STAT_POINTS = 2,   // k_points
+    BSC_STAT_PAIRS = 3,    // k_keys_pairs + tile scan + k_pair_compact
+    BSC_STAT_ORDER = 4,    // new-voxel ids, k_runs, run sort, scan, k_expand, segment order (everything the rgb chain needs)
+    BSC_STAT_PAIRSORT = 5, // pair sort + segment heads
+    BSC_STAT_INGEST = 6,   // main-stream work of one bsc_ingest call, first to last kernel
+    BSC_STAT_CHAIN = 7,    // k_chain + k_hwin (side stream)
+    BSC_STAT_SLOTS = 8
+};
 
 // device scalar block indices (int64 each)
 enum {
@@ -54,6 +66,11 @@ struct bsc_ctx {
     // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
     bool geom_fast;
     uint8_t *pat_x, *pat_y;   // (W), (H): patch column / row of a pixel column / row, 255 = outside the patch grid
+    // patch-aligned pair tiles (dense.hip): pixel rectangle {x0, width, y0, pixels} of every patch and the start of its
+    // staging slice inside a frame; valid when every patch covers at most 3328 pixels
+    bool patch_tiles;
+    int32_t *pt_rect, *pt_off;
+    int pair_path;            // how the pairs of the batch in flight were built: 0 generic tiles, 1 patch tiles
     int64_t *dscal;    // DS_COUNT device scalars
     int64_t *hscal;    // pinned host mirror for readbacks
     // exact mode
@@ -80,6 +97,7 @@ struct bsc_ctx {
     int32_t *new_cells;                 // cells claimed for the first time in this batch (one entry per new voxel)
     int32_t *blk_cnt, *blk_off;         // per 1024-point block: runs (count / exclusive prefix); also head compaction
     int32_t *blk_pass, *blk_pass_off;   // per block: passing points
+    int32_t *hb_cnt, *hb_off;           // segment-head compaction (dense.hip compact_heads): per-block counts / offsets
     int64_t nblk_cap;
     uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id | (length - 1) << id bits, value = first point
     uint32_t *skey_b_s[2];              // sorted run keys
@@ -96,6 +114,9 @@ struct bsc_ctx {
     hipStream_t side;          // rgb chain + top-down map run here, overlapped with the dense reduce / next encoder
     hipEvent_t ev_ready[2], ev_done[2];
     bool ev_done_valid[2];
+    bool chain_pending;        // the last call's rgb chain / top-down map kernels are still to be launched (deferred)
+    int chain_set;
+    int64_t chain_order_base;
     u64 *pair_key_a, *pair_key_b;   // dense: voxel id << cb | frame << pb | patch
     u64 *pstage_key;                // per-tile staging of the LDS-aggregated pairs
     uint32_t *pstage_cnt;
@@ -138,10 +159,10 @@ struct bsc_ctx {
     size_t prim_tmp_bytes;
     // bookkeeping
     int64_t order_base; // global point counter (top-down map tie order)
-    // HIP-event ring around the dominant kernels (0: dense feature reduce, 1: cosine scan)
-    hipEvent_t ev[2][2 * BSC_EV_RING];
-    int ev_n[2];
-    double stat_bytes[2];
+    // HIP-event rings around the stages of the path (BSC_STAT_*), recorded on the stream the stage is launched on
+    hipEvent_t ev[BSC_STAT_SLOTS][2 * BSC_EV_RING];
+    int ev_n[BSC_STAT_SLOTS];
+    double stat_bytes[BSC_STAT_SLOTS];
     bool timing;
 };
 
@@ -169,6 +190,8 @@ bsc_status prim_sort_pairs_onesweep(bsc_ctx *x, const u64 *kin, u64 *kout, const
                                     int begin_bit, int end_bit);
 bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                                size_t n, int begin_bit, int end_bit);
+bsc_status prim_sort_pairs_u32_onesweep(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                                        size_t n, int begin_bit, int end_bit);
 bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
 bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
 bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
@@ -194,6 +217,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                         const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
                         const double *alpha, bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
+bsc_status launch_pending_chain(bsc_ctx *x);
 bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels, const uint32_t *p_patf);
 bsc_status frontier_mask_impl(bsc_ctx *x, const uint8_t *navigable_host, uint8_t *mask_host);
 bsc_status frontier_clusters_impl(bsc_ctx *x, const uint8_t *frontier_host, int32_t min_cluster_size, int32_t ig_radius,
@@ -211,14 +235,14 @@ bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T
 bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the main stream)
 bsc_status sync_all(bsc_ctx *x);     // main + side stream
 // record the start / stop event of launch number ev_n[which] (ring; older launches are overwritten)
-static inline void stat_begin(bsc_ctx *x, int which)
+static inline void stat_begin(bsc_ctx *x, int which, hipStream_t s = nullptr)
 {
-    if (x->timing) (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING)], x->stream);
+    if (x->timing) (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING)], s ? s : x->stream);
 }
-static inline void stat_end(bsc_ctx *x, int which, double bytes)
+static inline void stat_end(bsc_ctx *x, int which, double bytes, hipStream_t s = nullptr)
 {
     if (x->timing) {
-        (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING) + 1], x->stream);
+        (void)hipEventRecord(x->ev[which][2 * (x->ev_n[which] % BSC_EV_RING) + 1], s ? s : x->stream);
         x->ev_n[which]++;
         x->stat_bytes[which] += bytes;
     }

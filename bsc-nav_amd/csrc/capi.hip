@@ -24,6 +24,7 @@ extern "C" const char *bsc_version(void) { return "bscnav 0.1 (gfx950)"; }
 
 bsc_status sync_all(bsc_ctx *x)
 {
+    BSC_TRY(launch_pending_chain(x));          // the rgb chain of the last ingest is deferred until someone needs it
     BSC_HIP(hipStreamSynchronize(x->stream));
     BSC_HIP(hipStreamSynchronize(x->side));
     return BSC_OK;
@@ -65,6 +66,7 @@ static void fill(bsc_ctx *x, T *p, int64_t n, T v)
 static bsc_status reset_state(bsc_ctx *x)
 {
     hipStream_t s = x->stream;
+    x->chain_pending = false;                  // the state it would update is being cleared
     if (x->side) BSC_HIP(hipStreamSynchronize(x->side));
     x->ev_done_valid[0] = x->ev_done_valid[1] = false;
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
@@ -168,6 +170,38 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
             e = hipMemcpy(x->pat_x, tx, c.width, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(x->pat_y, ty, c.height, hipMemcpyHostToDevice);
         }
+        // pixel rectangle of every patch (the tables are monotone: a patch is a contiguous range of columns x rows)
+        const int g = c.patch_grid, g2 = g * g;
+        ALLOC(x->pt_rect, 4 * g2);
+        ALLOC(x->pt_off, g2 + 1);
+        x->patch_tiles = x->geom_fast && c.mode != BSC_MODE_EXACT;
+        if (x->patch_tiles) {
+            int32_t *rect = (int32_t *)calloc(4 * g2, sizeof(int32_t)), *off = (int32_t *)calloc(g2 + 1, sizeof(int32_t));
+            int32_t *xs = (int32_t *)calloc(2 * g, sizeof(int32_t)), *ys = (int32_t *)calloc(2 * g, sizeof(int32_t));
+            for (int k = 0; k < g; ++k) { xs[2 * k] = ys[2 * k] = -1; }
+            for (int i = 0; i < c.width; ++i) if (tx[i] != 255) { if (xs[2 * tx[i]] < 0) xs[2 * tx[i]] = i; xs[2 * tx[i] + 1] = i + 1; }
+            for (int i = 0; i < c.height; ++i) if (ty[i] != 255) { if (ys[2 * ty[i]] < 0) ys[2 * ty[i]] = i; ys[2 * ty[i] + 1] = i + 1; }
+            int64_t total = 0;
+            for (int py = 0; py < g; ++py)
+                for (int px = 0; px < g; ++px) {
+                    const int p = py * g + px;
+                    const int w = xs[2 * px] < 0 ? 0 : xs[2 * px + 1] - xs[2 * px], h = ys[2 * py] < 0 ? 0 : ys[2 * py + 1] - ys[2 * py];
+                    rect[4 * p] = w ? xs[2 * px] : 0; rect[4 * p + 1] = w; rect[4 * p + 2] = h ? ys[2 * py] : 0; rect[4 * p + 3] = w * h;
+                    off[p] = (int32_t)total;
+                    total += (int64_t)w * h;
+                    if (w * h > 3328) x->patch_tiles = false;   // PP_R * TPB of dense.hip
+                }
+            off[g2] = (int32_t)total;
+            if (total > (int64_t)c.width * c.height) x->patch_tiles = false;
+            if (x->patch_tiles) {
+                e = hipMemcpy(x->pt_rect, rect, sizeof(int32_t) * 4 * g2, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(x->pt_off, off, sizeof(int32_t) * (g2 + 1), hipMemcpyHostToDevice);
+            }
+            free(rect); free(off); free(xs); free(ys);
+        }
+        if (getenv("BSC_DEBUG"))
+            fprintf(stderr, "bsc_create: %dx%d g=%d fast geometry %d, patch-aligned pair tiles %d\n", c.width, c.height,
+                    c.patch_grid, (int)x->geom_fast, (int)x->patch_tiles);
         free(tx); free(ty);
         if (e != hipSuccess) { bsc_set_error("bsc_create: patch tables: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
     }
@@ -195,6 +229,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
     ALLOC(x->blk_pass, x->nblk_cap); ALLOC(x->blk_pass_off, x->nblk_cap);
+    ALLOC(x->hb_cnt, x->nblk_cap); ALLOC(x->hb_off, x->nblk_cap);
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
         ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
@@ -215,7 +250,10 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         const int64_t fmax = (np + npix - 1) / npix;
         const int64_t t2d = fmax * ((c.width + 31) / 32) * ((c.height + 31) / 32), t1d = (np + 1023) / 1024;
         x->max_tiles = (t2d > t1d ? t2d : t1d) + 1;
-        ALLOC(x->pstage_key, x->max_tiles * 1024); ALLOC(x->pstage_cnt, x->max_tiles * 1024);
+        const int64_t pt_tiles = fmax * c.patch_grid * c.patch_grid + 1;        // patch-aligned tiles: g^2 per frame
+        if (pt_tiles > x->max_tiles) x->max_tiles = pt_tiles;
+        const int64_t stage_n = x->max_tiles * 1024 > fmax * npix ? x->max_tiles * 1024 : fmax * npix;
+        ALLOC(x->pstage_key, stage_n); ALLOC(x->pstage_cnt, stage_n);
         ALLOC(x->tile_cnt, x->max_tiles); ALLOC(x->tile_off, x->max_tiles);
     }
     ALLOC(x->d_transforms, (int64_t)x->max_frames * 16);
@@ -229,7 +267,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
     hipError_t e = hipMalloc(&x->prim_tmp, x->prim_tmp_bytes);
     if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < BSC_STAT_SLOTS; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i) BSC_HIP(hipEventCreate(&x->ev[w][i]));
     x->timing = true;
     bsc_status st = reset_state(x);
@@ -245,9 +283,9 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     hipSetDevice(x->device);
     if (x->side) hipStreamSynchronize(x->side);
     hipStreamSynchronize(x->stream);
-    void *ptrs[] = {x->pat_x, x->pat_y, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
+    void *ptrs[] = {x->pat_x, x->pat_y, x->pt_rect, x->pt_off, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
-                    x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->new_cells, x->run_scan, x->seg_k0, x->seg_vid, x->blk_pass, x->blk_pass_off,
+                    x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->new_cells, x->run_scan, x->seg_k0, x->seg_vid, x->blk_pass, x->blk_pass_off, x->hb_cnt, x->hb_off,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
                     x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_info_s[0], x->seg_info_s[1], x->run_val_b,
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
@@ -265,7 +303,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
         if (x->ev_ready[k]) hipEventDestroy(x->ev_ready[k]);
         if (x->ev_done[k]) hipEventDestroy(x->ev_done[k]);
     }
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < BSC_STAT_SLOTS; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i)
             if (x->ev[w][i]) hipEventDestroy(x->ev[w][i]);
     free(x);
@@ -278,6 +316,13 @@ extern "C" bsc_status bsc_reset(bsc_ctx *x)
     BSC_TRY(reset_state(x));
     BSC_HIP(hipStreamSynchronize(x->stream));
     return BSC_OK;
+}
+
+extern "C" bsc_status bsc_sync(bsc_ctx *x)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    return sync_all(x);
 }
 
 extern "C" bsc_status bsc_ingest_typed(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,
@@ -767,7 +812,7 @@ extern "C" bsc_status bsc_dense_gather_rgb(bsc_ctx *x, int64_t n, const int32_t 
     if (!x || !keys_dev || !rgb_dev || !weight_dev) { bsc_set_error("bsc_dense_gather_rgb: null argument"); return BSC_E_INVALID; }
     if (n <= 0) return BSC_OK;
     BSC_HIP(hipSetDevice(x->device));
-    BSC_HIP(hipStreamSynchronize(x->side));            // the rgb chain of the last ingest writes rgb / weight on the side stream
+    BSC_TRY(sync_all(x));                              // the rgb chain of the last ingest writes rgb / weight on the side stream
     hipLaunchKernelGGL(k_rgb_gather, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, n, keys_dev, x->c.grid_size,
                        x->nh, x->occ, x->rgb, x->weight, rgb_dev, weight_dev);
     BSC_HIP(hipGetLastError());
@@ -854,9 +899,9 @@ extern "C" bsc_status bsc_keys_dev(bsc_ctx *x, const int32_t **keys_dev, int64_t
 
 extern "C" bsc_status bsc_kernel_stats(bsc_ctx *x, int32_t which, int32_t reset, double *out)
 {
-    if (!x || !out || which < 0 || which > 1) return BSC_E_INVALID;
+    if (!x || !out || which < 0 || which >= BSC_STAT_SLOTS) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
-    BSC_HIP(hipStreamSynchronize(x->stream));
+    BSC_TRY(sync_all(x));
     const int n = x->ev_n[which], m = n < BSC_EV_RING ? n : BSC_EV_RING;
     double total = 0.0;
     for (int i = n - m; i < n; ++i) {

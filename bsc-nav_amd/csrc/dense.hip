@@ -178,6 +178,104 @@ __global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int
     if (tile == n_tiles - 1 && threadIdx.x == 0) dscal[DS_B_NPAIR] = off + n;
 }
 
+// ---- patch-aligned tiles (every pixel ingested, fast geometry) -----------------------------------------------------
+// One workgroup per (frame, ViT patch): all pixels of the tile carry the same token row, so the tile's pairs are simply
+// its distinct cells with their point counts — a (voxel, frame, patch) pair can only come from ONE tile.  Consequences:
+// no duplicate pairs to merge, a 32-bit hash key (the cell), and after a STABLE sort by any function of the cell the pairs
+// of a voxel are in (frame, patch) order whatever order the tile listed them in — the reduce is deterministic without
+// sorting the frame / patch bits at all.
+// Pair record: token row (frame * g^2 + patch) << 32 | count; sort key: the cell code (Morton).
+#define PP_HS 4096
+#define PP_R 13                 // rounds of TPB pixels: tiles of up to 3328 pixels (640x480 at 14x14 patches: 46 x 46, and 68 x 46 in
+                                // patch column 0, which int() widens to u in (-1, 1))
+__global__ __launch_bounds__(TPB) void k_patch_pairs(int W, int64_t N, int g, const int32_t *__restrict__ pt_rect,
+                                                     const int32_t *__restrict__ pt_off, CellCode cc,
+                                                     const int32_t *__restrict__ p_cell, u64 *__restrict__ stage_rec,
+                                                     uint32_t *__restrict__ stage_blk, int32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t hkey[PP_HS], hcnt[PP_HS];
+    __shared__ int nloc;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g2 = g * g;
+    const int64_t tile = blockIdx.x;
+    const int64_t f = tile / g2;
+    const int p = (int)(tile - f * g2);
+    const int x0 = pt_rect[4 * p], w = pt_rect[4 * p + 1], y0 = pt_rect[4 * p + 2], n = pt_rect[4 * p + 3];    // n = w * h pixels
+    if (n == 0) {
+        if (tid == 0) tile_cnt[tile] = 0;
+        return;
+    }
+    for (int s = tid; s < PP_HS; s += TPB) { hkey[s] = 0xffffffffu; hcnt[s] = 0u; }
+    if (tid == 0) nloc = 0;
+    __syncthreads();
+    const float inv_w = 1.0f / (float)w;
+    int32_t cell[PP_R];
+#pragma unroll
+    for (int r = 0; r < PP_R; ++r) {                // all loads in flight before the first use (clamped addresses)
+        const int l = tid + r * TPB;
+        const int lc = l < n ? l : 0;
+        int y = (int)((float)lc * inv_w);
+        int x = lc - y * w;
+        if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
+        const int32_t c = p_cell[f * N + (int64_t)(y0 + y) * W + x0 + x];
+        cell[r] = l < n ? c : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < PP_R; ++r) {
+        if (r * TPB >= n) break;
+        // neighbouring pixels share the cell: only the first lane of a stretch inserts, with the stretch's length
+        const int32_t pc = __shfl_up(cell[r], 1);
+        const bool edge = lane == 0 || cell[r] != pc;
+        const u64 em = __ballot(edge);
+        const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
+        const int end = above ? (__ffsll((long long)above) - 1) : 64;
+        if (edge && cell[r] >= 0) {
+            const uint32_t key = (uint32_t)cell[r];
+            uint32_t h = (key * 2654435761u) >> 20;        // 12 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, key);
+                if (old == 0xffffffffu || old == key) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
+                h = (h + 1) & (PP_HS - 1);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t base = f * N + pt_off[p];              // the tile's staging slice: as many slots as it has pixels
+    const u64 row = (u64)(f * g2 + p) << 32;
+    for (int s = tid; s < PP_HS; s += TPB) {
+        const uint32_t key = hkey[s];
+        if (key != 0xffffffffu) {
+            const int li = atomicAdd(&nloc, 1);
+            const uint32_t code = (uint32_t)cell_to_code(cc, (int32_t)key);
+            stage_rec[base + li] = row | (u64)hcnt[s];
+            stage_blk[base + li] = code;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) tile_cnt[tile] = nloc;
+}
+
+__global__ __launch_bounds__(TPB) void k_patch_compact(int64_t n_tiles, int g2, int64_t N, const int32_t *__restrict__ pt_off,
+                                                       const int32_t *__restrict__ tile_cnt, const int32_t *__restrict__ tile_off,
+                                                       const u64 *__restrict__ stage_rec, const uint32_t *__restrict__ stage_blk,
+                                                       u64 *__restrict__ pair_rec, uint32_t *__restrict__ pair_blk,
+                                                       uint32_t *__restrict__ pair_idx, int64_t pair_cap, int64_t *dscal)
+{
+    const int64_t tile = blockIdx.x;
+    const int n = tile_cnt[tile];
+    const int64_t off = tile_off[tile];
+    const int64_t f = tile / g2;
+    const int64_t base = f * N + pt_off[tile - f * g2];
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        if (off + i < pair_cap) {
+            pair_rec[off + i] = stage_rec[base + i];
+            pair_blk[off + i] = stage_blk[base + i];
+            pair_idx[off + i] = (uint32_t)(off + i);
+        }
+    }
+    if (tile == n_tiles - 1 && threadIdx.x == 0) dscal[DS_B_NPAIR] = off + n;
+}
+
 // ---- deterministic, ORDERED compaction of segment heads: per-block counts, exclusive scan, ranked write ------
 #define HB 1024   // elements per block
 template <typename K>
@@ -241,12 +339,18 @@ static bsc_status compact_heads(bsc_ctx *x, const K *keys, int64_t n, int shift,
 {
     const int64_t nb = (n + HB - 1) / HB;
     if (nb > x->nblk_cap) { bsc_set_error("compact_heads: block table too small"); return BSC_E_CAPACITY; }
-    hipLaunchKernelGGL((k_head_count<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->blk_cnt);
-    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nb));
-    hipLaunchKernelGGL((k_head_write<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->blk_off,
+    // own count / offset tables: blk_cnt / blk_off hold the run counts of the batch until k_runs has consumed them
+    hipLaunchKernelGGL((k_head_count<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->hb_cnt);
+    BSC_TRY(prim_exclusive_sum_i32(x, x->hb_cnt, x->hb_off, (size_t)nb));
+    hipLaunchKernelGGL((k_head_write<K>), dim3((unsigned)nb), dim3(TPB), 0, x->stream, keys, n, shift, invalid, x->hb_off,
                        out, count_dev);
     BSC_HIP(hipGetLastError());
     return BSC_OK;
+}
+
+static bsc_status compact_heads_u32(bsc_ctx *x, const uint32_t *keys, int64_t n, int32_t *out, int64_t *count_dev)
+{
+    return compact_heads<uint32_t>(x, keys, n, 0, 0xffffffffu, out, count_dev);
 }
 
 bsc_status compact_heads_u64(bsc_ctx *x, const u64 *keys, int64_t n, int shift, int32_t *out, int64_t *count_dev)
@@ -417,6 +521,97 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
     }
 }
 
+// ---- per-voxel reduce over the pairs of the patch-aligned tiles --------------------------------------------------------
+// The pairs are unique per (voxel, frame, patch) and, sorted by the cell code, contiguous per voxel in (frame, patch)
+// order: one wavefront per voxel walks its pairs 64 at a time, keeps four token rows (NV x 16 B per lane each) in flight
+// and finishes with ONE read-modify-write of the voxel's accumulator row.  No merging, no atomics.
+template <int NV, int MODE, typename TOK>
+__global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__restrict__ code_sorted,
+                                                             const uint32_t *__restrict__ idx_sorted,
+                                                             const u64 *__restrict__ pair_rec, int64_t n_pairs,
+                                                             const uint32_t *__restrict__ seg_start, const int64_t *dscal,
+                                                             const TOK *__restrict__ tokens, int D,
+                                                             float *__restrict__ acc_g, int32_t *__restrict__ acnt,
+                                                             CellCode cc, const int32_t *__restrict__ occ)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nseg = dscal[DS_B_NPSEG];
+    const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
+    const int D4 = D >> 2;
+    // the segment list is in Morton order of the cells: XCD x walks the super-chunks x, x+8, ... (spatial locality inside
+    // each, so an XCD's working set of token rows fits its L2; heavy regions spread over all XCDs)
+    const int xcd = blockIdx.x & 7;
+    const int64_t w_local = (int64_t)(blockIdx.x >> 3) * (TPB / 64) + (threadIdx.x >> 6);
+    const int64_t w_per_xcd = (int64_t)(gridDim.x >> 3) * (TPB / 64);
+    const int64_t chunk = (nseg + 63) / 64;
+    for (int64_t it = w_local; it < 8 * chunk; it += w_per_xcd) {
+        const int64_t s = (xcd + 8 * (it / chunk)) * chunk + (it % chunk);
+        if (s >= nseg) continue;
+        const int64_t i0 = seg_start[s];
+        const uint32_t code = code_sorted[i0];
+        const int64_t vid = occ[code_to_cell(cc, (u64)code)];
+        float4 a[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+            a[t] = (MODE == BSC_MODE_MAX) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t total = 0;
+        for (int64_t base = i0;; base += 64) {
+            const int64_t k = base + lane;
+            const bool in = k < n_pairs && code_sorted[k < n_pairs ? k : 0] == code;
+            const u64 rec = in ? pair_rec[idx_sorted[k]] : 0ull;
+            const int n = __popcll(__ballot(in));
+            const uint32_t row_l = (uint32_t)(rec >> 32), cnt_l = (uint32_t)rec & 0xffffffu;
+            for (int j = 0; j < n; j += 4) {
+                float4 xv[4][NV];
+                float m[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jj = j + q < n ? j + q : j;                  // padding repeats pair j with multiplicity 0
+                    const TOK *row = tokens + (int64_t)__builtin_amdgcn_readlane((int)row_l, jj) * D;
+                    m[q] = j + q < n ? (float)(uint32_t)__builtin_amdgcn_readlane((int)cnt_l, jj) : 0.f;
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        const int v = lane + 64 * t;
+                        xv[q][t] = (v < D4) ? load_tok4(row, v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        if (MODE == BSC_MODE_MAX) {         // padding repeats a real row: max is idempotent
+                            a[t].x = fmaxf(a[t].x, xv[q][t].x); a[t].y = fmaxf(a[t].y, xv[q][t].y);
+                            a[t].z = fmaxf(a[t].z, xv[q][t].z); a[t].w = fmaxf(a[t].w, xv[q][t].w);
+                        } else {
+                            a[t].x = fmaf(m[q], xv[q][t].x, a[t].x); a[t].y = fmaf(m[q], xv[q][t].y, a[t].y);
+                            a[t].z = fmaf(m[q], xv[q][t].z, a[t].z); a[t].w = fmaf(m[q], xv[q][t].w, a[t].w);
+                        }
+                    }
+            }
+            uint32_t cs = in ? cnt_l : 0u;
+            for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
+            total += cs;
+            if (n < 64) break;
+        }
+        const bool is_new = vid >= max_id_prev;
+        float4 *dst = (float4 *)(acc_g + vid * D);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int v = lane + 64 * t;
+            if (v < D4) {
+                float4 o = a[t];
+                if (!is_new) {
+                    const float4 old = dst[v];
+                    if (MODE == BSC_MODE_MAX) { o.x = fmaxf(o.x, old.x); o.y = fmaxf(o.y, old.y); o.z = fmaxf(o.z, old.z); o.w = fmaxf(o.w, old.w); }
+                    else { o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                }
+                dst[v] = o;
+            }
+        }
+        if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)total;
+    }
+}
+
 __global__ void k_dense_counters(int64_t *dscal)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -439,7 +634,13 @@ static CellCode make_cell_code(const bsc_ctx *x, int cb)
     return cc;
 }
 static inline int cell_code_bits(const CellCode &cc) { return cc.ab ? 3 * cc.ab : 31; }
-
+// the patch-tile path keeps the code in 32 bits
+static CellCode make_cell_code32(const bsc_ctx *x)
+{
+    CellCode cc = make_cell_code(x, 0);
+    if (cc.ab > 10) cc.ab = 0;
+    return cc;
+}
 template <int MODE, typename TOK>
 static void launch_dense(bsc_ctx *x, int64_t n_pairs, const TOK *tokens, int pb, int cb)
 {
@@ -463,6 +664,23 @@ bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixel
 {
     if (x->c.mode == BSC_MODE_EXACT) return BSC_OK;
     const int H = x->c.height, W = x->c.width;
+    x->pair_path = 0;
+    if (all_pixels && p_patf == nullptr && x->patch_tiles) {
+        // patch-aligned tiles: pairs unique by construction, sort key = block of 2^bb Morton-adjacent cells
+        x->pair_path = 1;
+        const int g2 = x->g2;
+        const int64_t tiles = (int64_t)n_frames * g2, N = (int64_t)H * W;
+        if (tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
+        const dim3 grid((unsigned)tiles), block(TPB);
+        uint32_t *pair_idx = (uint32_t *)x->pair_key_b;
+        hipLaunchKernelGGL(k_patch_pairs, grid, block, 0, x->stream, W, N, x->c.patch_grid, x->pt_rect, x->pt_off,
+                           make_cell_code32(x), x->p_cell, x->pstage_key, x->pstage_cnt, x->tile_cnt);
+        BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
+        hipLaunchKernelGGL(k_patch_compact, grid, block, 0, x->stream, tiles, g2, N, x->pt_off, x->tile_cnt, x->tile_off,
+                           x->pstage_key, x->pstage_cnt, x->pair_key_a, x->pair_cnt_a, pair_idx, x->pair_cap, x->dscal);
+        BSC_HIP(hipGetLastError());
+        return BSC_OK;
+    }
     const int tx_n = (W + 31) / 32, ty_n = (H + 31) / 32;
     const int64_t tiles = all_pixels ? (int64_t)n_frames * tx_n * ty_n : (P + PT_TILE - 1) / PT_TILE;
     if (tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
@@ -486,12 +704,45 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         return BSC_E_CAPACITY;
     }
     if (n_pairs == 0) return BSC_OK;
+    if (x->pair_path == 1) {
+        // pairs of the patch-aligned tiles: sort by the cell code alone (stable: a voxel's pairs stay in frame / patch
+        // order), segment heads, one wavefront per voxel
+        const int D = x->c.token_dim, nv = (D / 4 + 63) / 64;
+        const CellCode cc = make_cell_code32(x);
+        uint32_t *pair_idx = (uint32_t *)x->pair_key_b, *idx_sorted = pair_idx + x->pair_cap;
+        stat_begin(x, BSC_STAT_PAIRSORT);
+        BSC_TRY(prim_sort_pairs_u32_onesweep(x, x->pair_cnt_a, x->pair_cnt_b, pair_idx, idx_sorted, (size_t)n_pairs, 0, cell_code_bits(cc)));
+        BSC_TRY(compact_heads_u32(x, x->pair_cnt_b, n_pairs, x->pseg_start, x->dscal + DS_B_NPSEG));
+        stat_end(x, BSC_STAT_PAIRSORT, 0.0);
+        stat_begin(x, BSC_STAT_DENSE);
+        const dim3 grid(256 * 8), block(TPB);
+#define LV(NVV, MODEV, TOKT)                                                                                                   \
+    hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
+                       n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ)
+#define LVM(NVV)                                                                                   \
+    do {                                                                                           \
+        if (token_dtype == BSC_TOK_BF16) {                                                         \
+            if (x->c.mode == BSC_MODE_MEAN) LV(NVV, BSC_MODE_MEAN, bf16_t); else LV(NVV, BSC_MODE_MAX, bf16_t); \
+        } else {                                                                                   \
+            if (x->c.mode == BSC_MODE_MEAN) LV(NVV, BSC_MODE_MEAN, float); else LV(NVV, BSC_MODE_MAX, float);   \
+        }                                                                                          \
+    } while (0)
+        if (nv <= 1) LVM(1); else if (nv == 2) LVM(2); else if (nv == 3) LVM(3); else if (nv == 4) LVM(4); else LVM(8);
+#undef LVM
+#undef LV
+        stat_end(x, BSC_STAT_DENSE, 0.0);
+        hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);
+        BSC_HIP(hipGetLastError());
+        return BSC_OK;
+    }
     const int pb = code_patch_bits(x), cb = code_bits(x, n_frames);
+    stat_begin(x, BSC_STAT_PAIRSORT);
     BSC_TRY(prim_sort_pairs_onesweep(x, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, (size_t)n_pairs, 0,
                                      cb + cell_code_bits(make_cell_code(x, cb))));
     // voxel segments of the sorted list, already in Morton order of the cells
     BSC_TRY(compact_heads_u64(x, x->pair_key_b, n_pairs, cb, x->pseg_start, x->dscal + DS_B_NPSEG));
-    stat_begin(x, 0);
+    stat_end(x, BSC_STAT_PAIRSORT, 0.0);
+    stat_begin(x, BSC_STAT_DENSE);
     if (token_dtype == BSC_TOK_BF16) {
         if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, (const bf16_t *)tokens, pb, cb);
         else launch_dense<BSC_MODE_MAX>(x, n_pairs, (const bf16_t *)tokens, pb, cb);
@@ -499,7 +750,7 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         if (x->c.mode == BSC_MODE_MEAN) launch_dense<BSC_MODE_MEAN>(x, n_pairs, (const float *)tokens, pb, cb);
         else launch_dense<BSC_MODE_MAX>(x, n_pairs, (const float *)tokens, pb, cb);
     }
-    stat_end(x, 0, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, pairs)
+    stat_end(x, BSC_STAT_DENSE, 0.0);   // bytes are derived from the device counters (voxel rows, new rows, pairs)
     hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);
     BSC_HIP(hipGetLastError());
     return BSC_OK;

@@ -399,7 +399,8 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
         w = act ? (float)den : w;                               /* :899 */                         \
     }
 
-__global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
+#define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
+__global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
                                               const int4 *__restrict__ seg_info,
                                               const PointRec *__restrict__ p_rec,
                                               const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ sj, i
 {
     // a handful of long-lived wavefronts beside throughput kernels: take the SIMD's issue slots whenever ready
     __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int q = lane & 3;
     const int ch = q < 3 ? q : 2;
     const int sh = 8 * ch;
@@ -675,6 +676,34 @@ bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *
     return BSC_OK;
 }
 
+// launches the rgb chain + top-down map kernels of the last ingest call, if they have not been launched yet
+bsc_status launch_pending_chain(bsc_ctx *x)
+{
+    if (!x->chain_pending) return BSC_OK;
+    x->chain_pending = false;
+    const int set = x->chain_set;
+    BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
+    // 512 wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner (the
+    // longest voxel bounds the kernel) and only take registers and issue slots from the kernels running beside it:
+    // measured with 2048 / 512 wavefronts, chain 4.4 / 3.0 ms, concurrent k_dense_reduce 0.59 / 0.28 ms.
+    // They are launched as 128 workgroups of 4 (one wavefront per SIMD of a CU): the queue hands the longest segments to the
+    // first workgroups, so the chain's long tail sits on a few CUs instead of one SIMD in each of ~100 — a CU with a
+    // resident chain wavefront cannot take a 512-register GEMM wavefront of the caller's encoder (measured: the encoder
+    // runs 2.2x slower beside 512 single-wave workgroups that spin, unchanged beside 16).  Two wavefronts per SIMD
+    // (workgroups of 8) slow the tail itself: 6 -> 9 ms.
+    stat_begin(x, BSC_STAT_CHAIN, x->side);
+    hipLaunchKernelGGL(k_chain, dim3(512 * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
+                       x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
+                       x->chain_order_base);
+    hipLaunchKernelGGL(k_hwin, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],
+                       x->rgb_pos, x->hmap, x->p_rec_s[set], x->cv_map, x->c.grid_size, x->chain_order_base);
+    stat_end(x, BSC_STAT_CHAIN, 0.0, x->side);
+    BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
+    x->ev_done_valid[set] = true;
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
 bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,
                         const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
                         const double *alpha, bsc_draw_fn draw, void *user)
@@ -689,6 +718,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     const dim3 block(TPB);
     hipStream_t s = x->stream;
     const bool exact = x->c.mode == BSC_MODE_EXACT;
+    BSC_TRY(launch_pending_chain(x));          // the previous call's rgb chain runs beside this call's front end
     // scratch set of this call; the rgb chain of the call before last may still be reading it on the side stream
     const int set = x->cur_set;
     x->cur_set ^= 1;
@@ -710,6 +740,8 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     uint32_t *patf = all_px_dense ? (uint32_t *)nullptr : x->p_patf;
     float *r2f = exact ? x->p_r2f : (float *)nullptr;
     const float inv_w = 1.0f / (float)x->c.width;
+    stat_begin(x, BSC_STAT_INGEST);
+    stat_begin(x, BSC_STAT_POINTS);
     if (gc.fast)
         hipLaunchKernelGGL(k_points<true>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
                            x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
@@ -718,11 +750,14 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         hipLaunchKernelGGL(k_points<false>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
                            x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
                            x->dscal, x->blk_cnt, x->blk_pass);
+    stat_end(x, BSC_STAT_POINTS, 0.0);
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
                        x->c.voxel_capacity, x->bscal_s[set]);
+    stat_begin(x, BSC_STAT_PAIRS);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr, patf));
+    stat_end(x, BSC_STAT_PAIRS, 0.0);
     // one small readback per call: new voxels, runs, pairs (dense modes), passing points (exact mode), capacity flag.
     // Everything enqueued so far is the call's front end; the back end is sized from these numbers.
     BSC_TRY(read_scalars(x));
@@ -740,6 +775,11 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
         return BSC_E_CAPACITY;
     }
+    // dense feature reduce first: it only needs the ids.  The rgb chain is launched at the very end of the call, so that
+    // its bulk phase (thousands of quads stepping at raised priority) overlaps the head of the NEXT call instead of
+    // this call's pair sort and reduce (measured: the first pair-sort pass 0.05 -> 0.84 ms beside a starting chain).
+    if (!exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    stat_begin(x, BSC_STAT_ORDER);
     // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
     // their expansion is the per-voxel point order
     const int64_t R = x->hscal[DS_B_NRUN];
@@ -760,20 +800,19 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (n_bound > 0)
         BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
     hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->seg_vid, x->seg_info_s[set]);
-    // rgb chain + top-down map on the side stream: sequential-latency bound, so it overlaps the
-    // HBM-bound dense reduce of this call and whatever the caller enqueues next (the next batch's encoder)
+    stat_end(x, BSC_STAT_ORDER, 0.0);
+    // rgb chain + top-down map: sequential-latency bound, on the library's side stream — and DEFERRED: the
+    // call only marks its point order ready; the kernels are launched at the start of the next bsc_ingest (or by whatever
+    // needs their result first: exports, merges, resets — sync_all).  The chain's long tail (one voxel seen in every frame
+    // is a single dependent sequence of ~10^5 steps) then overlaps the next call's memory-bound front end instead of the
+    // caller's encoder: its few resident wavefronts are harmless beside streaming kernels, but a library GEMM that splits
+    // its work statically over all 256 CUs (stream-K) runs up to twice as long while any CU is held by a chain wavefront
+    // (measured: 26.4 -> 22.3 ms per 384-frame step without the chain beside the encoder).
     BSC_HIP(hipEventRecord(x->ev_ready[set], s));
-    BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
-    // 512 wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner (the
-    // longest voxel bounds the kernel) and only take registers and issue slots from the kernels running beside it:
-    // measured with 2048 / 512 wavefronts, chain 4.4 / 3.0 ms, concurrent k_dense_reduce 0.59 / 0.28 ms.
-    hipLaunchKernelGGL(k_chain, dim3(512), dim3(64), 0, x->side, sj, x->bscal_s[set], x->seg_info_s[set], p_rec,
-                       x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size, x->order_base);
-    hipLaunchKernelGGL(k_hwin, dim3(256), block, 0, x->side, x->bscal_s[set], x->seg_info_s[set],
-                       x->seg_last_s[set], x->rgb_pos, x->hmap, p_rec, x->cv_map, x->c.grid_size, x->order_base);
-    BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
-    x->ev_done_valid[set] = true;
-    if (x->c.mode != BSC_MODE_EXACT) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    x->chain_pending = true;
+    x->chain_set = set;
+    x->chain_order_base = x->order_base;
+    stat_end(x, BSC_STAT_INGEST, 0.0);
     BSC_HIP(hipGetLastError());
     x->order_base += P;
     if (x->c.mode == BSC_MODE_EXACT) {

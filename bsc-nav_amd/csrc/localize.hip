@@ -85,6 +85,30 @@ __global__ __launch_bounds__(64) void k_normalize_q(const float *__restrict__ q,
     for (int k = lane; k < D; k += 64) qn[(int64_t)blockIdx.x * D + k] = src[k] / nrm;
 }
 
+// Wave-wide sums of QT per-lane values at once (QT = 2, 4, 8): every butterfly step over a lane bit also halves the number
+// of values a lane carries (the half of the wavefront with the bit set keeps the upper values), so QT sums cost
+// QT - 1 + log2(64 / QT) exchanges instead of 6 QT.  The pairs added at each distance are those of wave_sum, so every
+// sum is bit-identical to wave_sum of that value.  Returns the sum of value `q` in the lanes whose bits 5.. select q:
+// q = lane >> (6 - log2 QT); all lanes of that group hold it.
+template <int QT>
+__device__ __forceinline__ float multi_wave_sum(float (&v)[QT], int lane)
+{
+    int mask = 32;
+#pragma unroll
+    for (int keep = QT >> 1; keep >= 1; keep >>= 1) {
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < keep; ++i) {
+            const float mine = hi ? v[i + keep] : v[i], theirs = hi ? v[i] : v[i + keep];
+            v[i] = mine + __shfl_xor(theirs, mask);
+        }
+        mask >>= 1;
+    }
+    float r = v[0];
+    for (; mask > 0; mask >>= 1) r += __shfl_xor(r, mask);
+    return r;
+}
+
 // sims[qi * n_rows + row] = dot(q^[qi], x[row]) / max(|x[row]|, 1e-8).
 // One wavefront per row (grid-stride), NV float4 per lane; the row is loaded once and reused for QT queries.
 template <int NV, int QT>
@@ -117,14 +141,22 @@ __global__ __launch_bounds__(TPB) void k_cosine(const float *__restrict__ rows, 
         for (int t = 0; t < NV; ++t) n2 += xv[t].x * xv[t].x + xv[t].y * xv[t].y + xv[t].z * xv[t].z + xv[t].w * xv[t].w;
         n2 = wave_sum(n2);
         const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-8f);
+        float dsum[QT];
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
-            float dsum = 0.f;
+            float d = 0.f;
 #pragma unroll
             for (int t = 0; t < NV; ++t)
-                dsum += xv[t].x * qv[qi][t].x + xv[t].y * qv[qi][t].y + xv[t].z * qv[qi][t].z + xv[t].w * qv[qi][t].w;
-            dsum = wave_sum(dsum);
-            if (lane == 0) sims[(int64_t)(q0 + qi) * sims_stride + r] = dsum * inv;
+                d += xv[t].x * qv[qi][t].x + xv[t].y * qv[qi][t].y + xv[t].z * qv[qi][t].z + xv[t].w * qv[qi][t].w;
+            dsum[qi] = d;
+        }
+        if (QT == 1) {
+            const float d = wave_sum(dsum[0]);
+            if (lane == 0) sims[(int64_t)q0 * sims_stride + r] = d * inv;
+        } else {
+            // the wavefront's QT groups of 64 / QT lanes end up with one query's sum each; their first lanes store
+            const float d = multi_wave_sum<QT>(dsum, lane);
+            if ((lane & (64 / QT - 1)) == 0) sims[(int64_t)(q0 + lane / (64 / QT)) * sims_stride + r] = d * inv;
         }
     }
 }

@@ -40,6 +40,9 @@ size_t prim_workspace_bytes(size_t n)
     rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0);
     best = b > best ? b : best;
+    rocprim::radix_sort_pairs<onesweep_always>(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                               (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0);
+    best = b > best ? b : best;
     rocprim::exclusive_scan(nullptr, b, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, n,
                             rocprim::plus<int64_t>(), (hipStream_t)0);
     best = b > best ? b : best;
@@ -94,6 +97,14 @@ bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, 
 {
     if (n == 0) return BSC_OK;
     PRIM_CALL(rocprim::radix_sort_pairs(x->prim_tmp, bytes, kin, kout, vin, vout, n, b0, b1, x->stream));
+    return BSC_OK;
+}
+
+bsc_status prim_sort_pairs_u32_onesweep(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                                        size_t n, int b0, int b1)
+{
+    if (n == 0) return BSC_OK;
+    PRIM_CALL(rocprim::radix_sort_pairs<onesweep_always>(x->prim_tmp, bytes, kin, kout, vin, vout, n, b0, b1, x->stream));
     return BSC_OK;
 }
 

@@ -102,6 +102,10 @@ class VoxelEngine:
     def reset(self):
         _lib.check(self.lib.bsc_reset(self.h))
 
+    def sync(self):
+        """Everything ingest() has started or deferred (the rgb chain of the last call is launched lazily) is complete."""
+        _lib.check(self.lib.bsc_sync(self.h))
+
     def ingest(self, depth, rgb, tokens, transforms, sample_idx=None, offsets=None, alpha=None):
         """depth (F,H,W) f32, rgb (F,H,W,C) u8, tokens (F,g,g,D) f32 or bf16 (widened exactly): contiguous CUDA
         tensors.  transforms (F,4,4) float64 NumPy.  sample_idx int32 CUDA + offsets (F+1) int64 NumPy, or None."""

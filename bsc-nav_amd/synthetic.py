@@ -3,7 +3,9 @@
 
 rgb (F,H,W,4) u8 RGBA, depth (F,H,W) f32 z-depth, poses (F,7) [px,py,pz,qx,qy,qz,qw].
 `room`: analytic ray cast of an axis-aligned 8 x 3 x 6 m box from a camera on a seeded random walk
-(0.25 m steps, 30 degree turns, args.py:33-35); `iid`: U(0.5, 5) m per pixel (worst case, one voxel
+(0.25 m steps, 30 degree turns, args.py:33-35); `hall`: a 24 x 3 x 24 m hall with 36 square pillars (1 m, on a 4 m
+lattice), the camera on a forward-biased walk that covers the whole floor — a scene of 10^5..10^6 surface voxels of
+0.1 m, the size SURVEY.md §7 gives for real scans; `iid`: U(0.5, 5) m per pixel (worst case, one voxel
 per point).  About 2 % of the pixels are pushed outside (min_depth, max_depth).
 """
 import numpy as np
@@ -11,6 +13,41 @@ import torch
 
 ROOM_LO = (-4.0, -1.5, -3.0)
 ROOM_HI = (4.0, 1.5, 3.0)
+
+
+HALL_LO = (-12.0, -1.5, -12.0)
+HALL_HI = (12.0, 1.5, 12.0)
+HALL_PILLARS = tuple((float(cx), float(cz)) for cx in range(-10, 11, 4) for cz in range(-10, 11, 4))   # centres, 1 x 1 m
+
+
+def _hall_free(pos, margin=0.6):
+    if not (HALL_LO[0] + margin < pos[0] < HALL_HI[0] - margin and HALL_LO[2] + margin < pos[2] < HALL_HI[2] - margin):
+        return False
+    return all(max(abs(pos[0] - cx), abs(pos[2] - cz)) > 0.5 + margin for cx, cz in HALL_PILLARS)
+
+
+def hall_walk_poses(seed, n_frames):
+    """Forward-biased walk (70 % forward steps of 0.25 m, 30 degree turns otherwise or when blocked)."""
+    rs = np.random.RandomState(seed)
+    poses = np.zeros((n_frames, 7), dtype=np.float64)
+    pos, k = np.zeros(3), 0
+    for f in range(n_frames):
+        u = rs.uniform()
+        if f > 0:
+            th = k * np.pi / 6.0
+            nxt = pos + np.array([-np.sin(th), 0.0, -np.cos(th)]) * 0.25
+            if u < 0.7 and _hall_free(nxt):
+                pos = nxt
+            else:
+                k += 1 if (u < 0.85 or u >= 0.925) else -1
+        th = k * np.pi / 6.0
+        poses[f, :3] = pos
+        poses[f, 3:] = [0.0, np.sin(th / 2.0), 0.0, np.cos(th / 2.0)]
+    return poses
+
+
+def make_poses(kind, seed, n_frames):
+    return hall_walk_poses(seed, n_frames) if kind == "hall" else random_walk_poses(seed, n_frames)
 
 
 def random_walk_poses(seed, n_frames, start_yaw_steps=0):
@@ -40,11 +77,11 @@ def random_walk_poses(seed, n_frames, start_yaw_steps=0):
 def make_frames(seed, n_frames, H, W, kind="room", device="cuda", invalid_frac=0.02, poses=None):
     gen = torch.Generator(device=device).manual_seed(seed)
     if poses is None:
-        poses = random_walk_poses(seed, n_frames)
+        poses = make_poses(kind, seed, n_frames)
     rgb = torch.randint(0, 255, (n_frames, H, W, 4), dtype=torch.uint8, device=device, generator=gen)
     if kind == "iid":
         depth = torch.rand((n_frames, H, W), device=device, generator=gen) * 4.5 + 0.5
-    elif kind == "room":
+    elif kind in ("room", "hall"):
         fx = W / 2.0
         u = (torch.arange(W, device=device, dtype=torch.float32) + 0.5 - W / 2.0) / fx
         v = (torch.arange(H, device=device, dtype=torch.float32) + 0.5 - H / 2.0) / fx
@@ -57,11 +94,22 @@ def make_frames(seed, n_frames, H, W, kind="room", device="cuda", invalid_frac=0
         rot = torch.stack([torch.stack([c, z, s], -1), torch.stack([z, o, z], -1), torch.stack([-s, z, c], -1)], -2)
         d = torch.einsum("hwk,fjk->fhwj", d_local, rot)                            # (F,H,W,3)
         org = p[:, None, None, :3]
-        lo = torch.tensor(ROOM_LO, device=device)
-        hi = torch.tensor(ROOM_HI, device=device)
+        lo = torch.tensor(ROOM_LO if kind == "room" else HALL_LO, device=device)
+        hi = torch.tensor(ROOM_HI if kind == "room" else HALL_HI, device=device)
         t = torch.where(d > 0, (hi - org) / d, (lo - org) / d)
         t = torch.where(torch.isfinite(t), t, torch.full_like(t, float("inf")))
-        depth = t.min(dim=-1).values + (torch.rand((n_frames, H, W), device=device, generator=gen) - 0.5) * 0.02
+        t = t.min(dim=-1).values
+        if kind == "hall":                     # nearest pillar face in front of the camera (slab test in x and z)
+            inf = torch.full_like(t, float("inf"))
+            dx, dz, ox, oz = d[..., 0], d[..., 2], org[..., 0], org[..., 2]
+            for cx, cz in HALL_PILLARS:
+                ax, bx = (cx - 0.5 - ox) / dx, (cx + 0.5 - ox) / dx
+                az, bz = (cz - 0.5 - oz) / dz, (cz + 0.5 - oz) / dz
+                t0 = torch.maximum(torch.minimum(ax, bx), torch.minimum(az, bz))
+                t1 = torch.minimum(torch.maximum(ax, bx), torch.maximum(az, bz))
+                hit = (t1 >= t0) & (t0 > 0)
+                t = torch.minimum(t, torch.where(hit, t0, inf))
+        depth = t + (torch.rand((n_frames, H, W), device=device, generator=gen) - 0.5) * 0.02
     else:
         raise ValueError(kind)
     r = torch.rand((n_frames, H, W), device=device, generator=gen)

@@ -233,11 +233,20 @@ bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H,
                                       int32_t patch, void *out_dev, const float *mean3_host, const float *std3_host,
                                       void *hip_stream);
 
-/* HIP-event timing of the dominant kernel of each path, recorded on the ctx stream around every launch
- * (which 0: dense feature reduce of bsc_ingest, 1: cosine scan of bsc_localize).
+/* HIP-event timing of the stages of the path, recorded around every launch on the stream the stage runs on.
+ * which: 0 dense feature reduce (k_dense_reduce), 1 cosine scan of bsc_localize, 2 k_points (geometry + claims),
+ *        3 (cell, frame, patch) pair aggregation, 4 voxel ids + per-voxel point order (runs, sort, expansion),
+ *        5 pair sort + segment heads, 6 the main-stream work of one whole bsc_ingest call, 7 rgb chain + top-down map
+ *        (library side stream, overlaps the call's tail and the next call).
  * out[0]=ms summed over the covered launches, out[1]=launches covered (ring of 512), out[2]=algorithmic
  * bytes accumulated (localize; for ingest derive them from bsc_counters), out[3]=launches since reset. */
 bsc_status bsc_kernel_stats(bsc_ctx *ctx, int32_t which, int32_t reset, double *out4_host);
+
+/* Completes everything bsc_ingest has started or deferred: the rgb running mean and the top-down map of the last call
+ * (memory_2.py:888-903) run on a library-owned side stream and are launched lazily — by the next bsc_ingest, by any
+ * export / merge / reset, or here — so that their sequential tail overlaps the next call's front end rather than the
+ * caller's encoder.  Returns when both library streams are idle. */
+bsc_status bsc_sync(bsc_ctx *ctx);
 
 #ifdef __cplusplus
 }

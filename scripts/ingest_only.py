@@ -25,7 +25,9 @@ for rep in range(2):
         rgb, depth, _ = frames[s]
         eng.ingest(depth, rgb, tok, Ts[s * F:(s + 1) * F])
         if sync:
+            eng.sync()
             torch.cuda.synchronize()
+    eng.sync()
     torch.cuda.synchronize()
     c = eng.counters()
     print(f"rep {rep}: {(time.perf_counter() - t0) / calls * 1e3:.2f} ms per call (sync={sync}) kind={kind} voxels={c['max_id']} "
