@@ -170,6 +170,11 @@ __global__ __launch_bounds__(TPB) void k_cosine(const float *__restrict__ rows, 
 // Queries sit on the M axis so that the accumulator columns are rows of X: stores are 128-byte row runs per query.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MF_KC 32
+#ifndef BSC_MFMA_MIN_Q
+#define BSC_MFMA_MIN_Q 5     // up to 4 queries: one wavefront per row on the vector ALUs (k_cosine, 5.6 TB/s); from 5 on the
+                             // VALU dot products no longer hide behind the row stream (8 queries: 3.6 TB/s) and a zero-padded
+                             // 32-query MFMA tile is faster (4.9 TB/s for 5..32 queries over 2^20 x 768)
+#endif
 #define MF_LD 33
 template <int NT>
 __global__ __launch_bounds__(TPB) void k_cosine_mfma(const float *__restrict__ X, int64_t n_rows, int D,
@@ -656,11 +661,13 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     int done = 0;
     stat_begin(x, 1);
     const int64_t sstride = sims_row_stride(n_rows);
-    if (nq >= 16 && D % MF_KC == 0 && n_rows > 0) {
+    int passes = 0;                          // times the row matrix is streamed
+    if (nq >= BSC_MFMA_MIN_Q && D % MF_KC == 0 && n_rows > 0) {
         // batched queries: fp32 MFMA GEMM, 32-query tiles (l_q is zero-padded to a multiple of 32 rows)
         const dim3 mgrid((unsigned)((n_rows + 127) / 128));
         while (done < nq) {
             const int left = nq - done;
+            ++passes;
             if (left > 128) { hipLaunchKernelGGL((k_cosine_mfma<8>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 256; }
             else if (left > 64) { hipLaunchKernelGGL((k_cosine_mfma<4>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 128; }
             else if (left > 32) { hipLaunchKernelGGL((k_cosine_mfma<2>), mgrid, block, 0, s, rows, n_rows, D, x->l_q, done, nq, x->l_sims, sstride); done += 64; }
@@ -670,12 +677,13 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     }
     while (done < nq && n_rows > 0) {      // the row matrix is streamed once per group of up to 8 queries
         const int left = nq - done;
+        ++passes;
         if (left >= 8) { launch_cosine<8>(x, rows, n_rows, done); done += 8; }
         else if (left >= 4) { launch_cosine<4>(x, rows, n_rows, done); done += 4; }
         else if (left >= 2) { launch_cosine<2>(x, rows, n_rows, done); done += 2; }
         else { launch_cosine<1>(x, rows, n_rows, done); done += 1; }
     }
-    stat_end(x, 1, (double)n_rows * D * 4.0 * ((nq + 7) / 8) + (double)nq * n_rows * 4.0);
+    stat_end(x, 1, (double)n_rows * D * 4.0 * passes + (double)nq * n_rows * 4.0);
     CandArgs ca;
     ca.n_cand = n_cand; ca.max_id = max_id; ca.vcap = vcap; ca.cache_size = x->c.cache_size; ca.exact = exact ? 1 : 0;
     ca.use_radius = radius >= 0 ? 1 : 0;
