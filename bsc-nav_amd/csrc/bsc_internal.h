@@ -102,7 +102,7 @@ struct bsc_ctx {
     uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id | (length - 1) << id bits, value = first point
     uint32_t *skey_b_s[2];              // sorted run keys
     uint32_t *run_val_b;                // sorted run values
-    int64_t *run_scan;                  // exclusive scan of (length | segment head << 32) over the sorted runs
+    int64_t *run_scan;                  // per 1024-run block: sum, then exclusive prefix, of (length | segment head << 32)
     int32_t *seg_k0, *seg_vid;          // voxel segments of the point order: first position, voxel id
     uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel (read by the rgb chain)
     int4 *seg_info_s[2];                // per voxel segment: {first k, end k, voxel id, rank in the length-class order}
@@ -195,9 +195,6 @@ bsc_status prim_sort_pairs_u32_onesweep(bsc_ctx *x, const uint32_t *kin, uint32_
 bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
 bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
 bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
-// exclusive scan over sorted run keys (voxel id | (length - 1) << vb; id field all ones = no voxel) of
-// length | (first run of its voxel) << 32
-bsc_status prim_scan_runs(bsc_ctx *x, const uint32_t *keys_sorted, int vb, int64_t *out, size_t n);
 
 // ---- kernels launchers ----
 bsc_status launch_geometry_debug(bsc_ctx *x, const float *depth, const int32_t *idx, int64_t P, uint8_t *flags,

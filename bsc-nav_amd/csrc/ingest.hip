@@ -520,50 +520,99 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
 }
 
 // ---- runs -> per-voxel point order ---------------------------------------------------------------------------------
-// After the stable sort every voxel's runs are contiguous and in order j.  ONE exclusive scan over the sorted runs of the
-// pair (length, first run of its voxel) — packed as length | head << 32 — yields both the position of every run in the
-// per-voxel point order and the ordinal of every voxel segment (prims.hip: prim_scan_runs).
-//
-// point order: sj[off(i) + t] = j0(i) + t.  One wavefront per 64 sorted runs; the outputs of the 64 runs are
-// contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.  The first run of a
-// voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
+// After the stable sort every voxel's runs are contiguous and in order j.  The position of a run in the per-voxel point
+// order is the exclusive prefix of the run lengths, the ordinal of a voxel segment the exclusive prefix of the "first run
+// of its voxel" flags: both ride in one 64-bit value (length | head << 32), summed per block of EB runs (k_run_blocksum),
+// scanned over the ~R / 1024 block sums, and finished inside the block by k_expand — no R-sized scan array.
+#define EB 1024
+__device__ __forceinline__ int64_t run_item(const uint32_t *__restrict__ rkey, int64_t i, int64_t R, uint32_t vmask, int vb)
+{
+    if (i >= R) return 0;
+    const uint32_t key = rkey[i], v = key & vmask;
+    if (v == vmask) return 0;                   // no voxel: takes no room, starts no segment
+    const int64_t head = (i == 0 || (rkey[i - 1] & vmask) != v) ? 1 : 0;
+    return (int64_t)(key >> vb) + 1 + (head << 32);
+}
+
+__global__ __launch_bounds__(TPB) void k_run_blocksum(int64_t R, int vb, const uint32_t *__restrict__ rkey_sorted,
+                                                      int64_t *__restrict__ blk_sum)
+{
+    __shared__ int64_t s_w[TPB / 64];
+    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+    int64_t v = 0;
+#pragma unroll
+    for (int r = 0; r < EB / TPB; ++r) v += run_item(rkey_sorted, (int64_t)blockIdx.x * EB + r * TPB + threadIdx.x, R, vmask, vb);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// point order: sj[off(i) + t] = j0(i) + t.  One wavefront per 64 sorted runs (16 groups of 64 per block); the outputs
+// of the 64 runs are contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.
+// The first run of a voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
 __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_t *__restrict__ rkey_sorted,
-                                                const uint32_t *__restrict__ rval_sorted, const int64_t *__restrict__ scan,
+                                                const uint32_t *__restrict__ rval_sorted, const int64_t *__restrict__ blk_base,
                                                 uint32_t *__restrict__ sj, int32_t *__restrict__ seg_k0,
                                                 int32_t *__restrict__ seg_vid, int64_t *bscal)
 {
     __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
+    __shared__ int64_t s_grp[EB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    const int64_t i = ((int64_t)blockIdx.x * (TPB / 64) + wid) * 64 + lane;
-    int32_t off = INT_MAX, len = 0, j0 = 0;
-    if (i < R) {
-        const uint32_t key = rkey_sorted[i];
-        const int64_t sc = scan[i];
-        const uint32_t v = key & vmask;
-        j0 = (int32_t)rval_sorted[i];
-        off = (int32_t)(sc & 0xffffffffll);
-        if (v != vmask) {
-            len = (int32_t)(key >> vb) + 1;
-            const bool head = i == 0 || (rkey_sorted[i - 1] & vmask) != v;
-            if (head) { seg_k0[sc >> 32] = off; seg_vid[sc >> 32] = (int32_t)v; }
-            if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = (int64_t)off + len; }
-        } else if (i == R - 1) {
-            bscal[0] = sc >> 32; bscal[2] = off;            // invalid runs sort last and take no room
-        }
-    }
-    s_off[wid][lane] = len > 0 ? off : INT_MAX;
-    s_j0[wid][lane] = j0;
-    int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0;
-    for (int o = 32; o > 0; o >>= 1) { begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); }
-    __builtin_amdgcn_wave_barrier();
-    if (begin == INT_MAX) return;
-    for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
-        int lo = 0;                             // largest lo with s_off[lo] <= pnt (offsets ascend; empty runs sort last)
+    // exclusive prefix of (length | head << 32) inside the block: per 64-run group totals, then lanes
+    int64_t item[EB / TPB], incl[EB / TPB];
 #pragma unroll
-        for (int stp = 32; stp > 0; stp >>= 1)
-            if (s_off[wid][lo + stp] <= pnt) lo += stp;
-        sj[pnt] = (uint32_t)(s_j0[wid][lo] + (pnt - s_off[wid][lo]));
+    for (int r = 0; r < EB / TPB; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * EB + (r * (TPB / 64) + wid) * 64 + lane;      // group g = r * 4 + wid
+        item[r] = run_item(rkey_sorted, i, R, vmask, vb);
+        int64_t v = item[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        incl[r] = v;
+        if (lane == 63) s_grp[r * (TPB / 64) + wid] = v;
+    }
+    __syncthreads();
+    const int64_t base = blk_base[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < EB / TPB; ++r) {
+        const int g = r * (TPB / 64) + wid;
+        int64_t pre = base;
+        for (int k = 0; k < g; ++k) pre += s_grp[k];
+        const int64_t sc = pre + incl[r] - item[r];                 // exclusive prefix of this run
+        const int64_t i = (int64_t)blockIdx.x * EB + g * 64 + lane;
+        int32_t off = INT_MAX, len = 0, j0 = 0;
+        if (i < R) {
+            const uint32_t key = rkey_sorted[i];
+            const uint32_t v = key & vmask;
+            j0 = (int32_t)rval_sorted[i];
+            off = (int32_t)(sc & 0xffffffffll);
+            if (v != vmask) {
+                len = (int32_t)(key >> vb) + 1;
+                const bool head = (item[r] >> 32) != 0;
+                if (head) { seg_k0[sc >> 32] = off; seg_vid[sc >> 32] = (int32_t)v; }
+                if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = (int64_t)off + len; }
+            } else if (i == R - 1) {
+                bscal[0] = sc >> 32; bscal[2] = off;            // runs without a voxel sort last and take no room
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        s_off[wid][lane] = len > 0 ? off : INT_MAX;
+        s_j0[wid][lane] = j0;
+        int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0;
+        for (int o = 32; o > 0; o >>= 1) { begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); }
+        __builtin_amdgcn_wave_barrier();
+        if (begin == INT_MAX) continue;
+        for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
+            int lo = 0;                         // largest lo with s_off[lo] <= pnt (offsets ascend; empty runs sort last)
+#pragma unroll
+            for (int stp = 32; stp > 0; stp >>= 1)
+                if (s_off[wid][lo + stp] <= pnt) lo += stp;
+            sj[pnt] = (uint32_t)(s_j0[wid][lo] + (pnt - s_off[wid][lo]));
+        }
     }
 }
 
@@ -789,8 +838,10 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
-    BSC_TRY(prim_scan_runs(x, skey_b, vb, x->run_scan, (size_t)R));
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)((R + TPB - 1) / TPB)), block, 0, s, R, vb, skey_b, x->run_val_b, x->run_scan, sj,
+    const int64_t neb = (R + EB - 1) / EB;
+    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
+    BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
                        x->seg_k0, x->seg_vid, x->bscal_s[set]);
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels

@@ -8,19 +8,6 @@ namespace {
 // small inputs (the pair list, ~1e5) would otherwise take rocPRIM's merge-sort path (~0.3 ms); onesweep is faster
 using onesweep_always = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                    rocprim::default_config, 2048>;
-// sorted run key -> length | (first run of its voxel) << 32; runs without a voxel (id field all ones) count nothing
-struct run_scan_in {
-    const uint32_t *k;
-    uint32_t vmask;
-    int vb;
-    __host__ __device__ int64_t operator()(int64_t i) const
-    {
-        const uint32_t key = k[i], v = key & vmask;
-        if (v == vmask) return 0;
-        const int64_t head = (i == 0 || (k[i - 1] & vmask) != v) ? 1 : 0;
-        return (int64_t)(key >> vb) + 1 + (head << 32);
-    }
-};
 struct max_i32 {
     __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; }
 };
@@ -51,11 +38,6 @@ size_t prim_workspace_bytes(size_t n)
     best = b > best ? b : best;
     rocprim::inclusive_scan(nullptr, b, (const int32_t *)nullptr, (int32_t *)nullptr, n, max_i32(), (hipStream_t)0);
     best = b > best ? b : best;
-    {
-        auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), run_scan_in{nullptr, 0u, 0});
-        rocprim::exclusive_scan(nullptr, b, it, (int64_t *)nullptr, (int64_t)0, n, rocprim::plus<int64_t>(), (hipStream_t)0);
-        best = b > best ? b : best;
-    }
     return best + 256;
 }
 
@@ -129,11 +111,3 @@ bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, s
     return BSC_OK;
 }
 
-bsc_status prim_scan_runs(bsc_ctx *x, const uint32_t *keys_sorted, int vb, int64_t *out, size_t n)
-{
-    if (n == 0) return BSC_OK;
-    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), run_scan_in{keys_sorted, vmask, vb});
-    PRIM_CALL(rocprim::exclusive_scan(x->prim_tmp, bytes, it, out, (int64_t)0, n, rocprim::plus<int64_t>(), x->stream));
-    return BSC_OK;
-}
