@@ -83,6 +83,7 @@ struct bsc_ctx {
     int32_t *store_rows; // (vcap+1,cache_size) pool rows; entry vcap is the grid_0_0_0 group
     int32_t *store_cnt;  // (vcap+1)
     int64_t n_flush;
+    int64_t pool_n_host;   // host mirror of DS_POOL_N (token pool rows in use), exact after every flush / import / reset
     // dense modes
     float *acc;   // (vcap,D)
     int32_t *acnt; // (vcap)

@@ -89,6 +89,7 @@ static bsc_status reset_state(bsc_ctx *x)
     BSC_HIP(hipGetLastError());
     x->iter_id = 0;
     x->n_flush = 0;
+    x->pool_n_host = 0;
     x->order_base = 0;
     x->names_dirty = true;
     return BSC_OK;
@@ -711,6 +712,7 @@ extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const
     }
     free(occ); free(h_cnt); free(h_rows);
     x->names_dirty = true;
+    if (st == BSC_OK) x->pool_n_host = nt;
     return st;
 }
 

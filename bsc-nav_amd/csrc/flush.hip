@@ -137,6 +137,13 @@ bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user)
     hipStream_t s = x->stream;
     const dim3 block(TPB), grid((n + TPB - 1) / TPB), wgrid((unsigned)(((int64_t)n * 64 + TPB - 1) / TPB));
     const int ebits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
+    // A flush appends at most one pool row per cache row.  Refuse BEFORE anything is changed when the pool could overflow:
+    // the store stays consistent and the caller can grow token_capacity (the reference's HDF5 store is unbounded).
+    if (x->pool_n_host + n > x->c.token_capacity) {
+        bsc_set_error("token store: %lld rows used, a flush may add %d, token_capacity=%lld — create the context with a larger "
+                      "token_capacity", (long long)x->pool_n_host, n, (long long)x->c.token_capacity);
+        return BSC_E_CAPACITY;
+    }
     hipLaunchKernelGGL(k_flush_keys, grid, block, 0, s, n, x->cache_pos, x->occ, x->c.grid_size, x->nh,
                        x->c.voxel_capacity, x->f_keys_a);
     BSC_TRY(prim_sort_keys(x, x->f_keys_a, x->f_keys_b, (size_t)n, 0, 20 + ebits));
@@ -190,5 +197,6 @@ bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user)
     x->iter_id = 0;
     x->n_flush++;
     x->names_dirty = true;
+    x->pool_n_host = x->hscal[DS_POOL_N];
     return BSC_OK;
 }

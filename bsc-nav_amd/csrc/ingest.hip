@@ -400,6 +400,7 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
     }
 
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
+#define CHAIN_WAVES 128
 __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
                                               const int4 *__restrict__ seg_info,
                                               const PointRec *__restrict__ p_rec,
@@ -732,16 +733,15 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     x->chain_pending = false;
     const int set = x->chain_set;
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
-    // 512 wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner (the
-    // longest voxel bounds the kernel) and only take registers and issue slots from the kernels running beside it:
-    // measured with 2048 / 512 wavefronts, chain 4.4 / 3.0 ms, concurrent k_dense_reduce 0.59 / 0.28 ms.
-    // They are launched as 128 workgroups of 4 (one wavefront per SIMD of a CU): the queue hands the longest segments to the
-    // first workgroups, so the chain's long tail sits on a few CUs instead of one SIMD in each of ~100 — a CU with a
-    // resident chain wavefront cannot take a 512-register GEMM wavefront of the caller's encoder (measured: the encoder
-    // runs 2.2x slower beside 512 single-wave workgroups that spin, unchanged beside 16).  Two wavefronts per SIMD
-    // (workgroups of 8) slow the tail itself: 6 -> 9 ms.
+    // CHAIN_WAVES wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner
+    // (the longest voxel bounds the kernel; 2048 quads at ~30 ns per step walk the 1.2e8 points of a 384-frame call in
+    // 1.7 ms) and only take CUs from the kernels running beside it: a CU with a resident chain wavefront (178 VGPRs) cannot
+    // take a 512-register GEMM wavefront of the caller's encoder (measured: the encoder runs 2.2x slower beside 512
+    // single-wave workgroups that spin, unchanged beside 16).  So they are launched as workgroups of 4 (one wavefront per
+    // SIMD of a CU, 32 CUs in all); the queue hands the longest segments to the first workgroups, which keeps the chain's
+    // long tail on one or two CUs.  Two wavefronts per SIMD (workgroups of 8) slow the tail itself: 6 -> 9 ms.
     stat_begin(x, BSC_STAT_CHAIN, x->side);
-    hipLaunchKernelGGL(k_chain, dim3(512 * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
+    hipLaunchKernelGGL(k_chain, dim3(CHAIN_WAVES * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
                        x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
                        x->chain_order_base);
     hipLaunchKernelGGL(k_hwin, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],

@@ -41,7 +41,12 @@ __global__ __launch_bounds__(TPB) void kp(GeomConst gc, const float *__restrict_
         rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
     }
     if (!(ABL & 32)) p_patf[j] = ((uint32_t)f << 16) | o.patch;
-    if (!(ABL & 4)) {
+    if (ABL & 128) {
+        ((uint4 *)p_rec)[j] = make_uint4((uint32_t)__double2loint(o.alpha), (uint32_t)__double2hiint(o.alpha), rgbv, 0u);
+    } else if (ABL & 256) {
+        ((double *)p_rec)[j] = o.alpha;
+        ((uint32_t *)p_rec)[2 * P + j] = rgbv;
+    } else if (!(ABL & 4)) {
         PointRec rec;
         rec.alo = (uint32_t)__double2loint(o.alpha); rec.ahi = (uint32_t)__double2hiint(o.alpha); rec.rgbv = rgbv;
         p_rec[j] = rec;
@@ -90,7 +95,7 @@ int main(int argc, char **argv)
     }
     float *depth; uint8_t *rgb; double *T; int32_t *occ, *cell; uint32_t *patf; PointRec *rec;
     hipMalloc(&depth, P * 4); hipMalloc(&rgb, P * 4); hipMalloc(&T, F * 16 * 8); hipMalloc(&occ, (size_t)gs * gs * 256 * 4);
-    hipMalloc(&cell, P * 4); hipMalloc(&patf, P * 4); hipMalloc(&rec, P * 12);
+    hipMalloc(&cell, P * 4); hipMalloc(&patf, P * 4); hipMalloc(&rec, P * 16);
     for (int f = 0; f < F; ++f) {
         if (vary) for (int64_t i = 0; i < N; i += 7) hd[i] += 0.003f;
         hipMemcpy(depth + f * N, hd.data(), N * 4, hipMemcpyHostToDevice);
@@ -103,6 +108,8 @@ int main(int argc, char **argv)
 #define RUN(A, name) run<A>(name, gc, depth, rgb, T, P, occ, cell, patf, rec)
     RUN(0, "full");
     RUN(8, "T through readfirstlane (scalar loads)");
+    RUN(8 | 128, "scalar T + 16-byte records (dwordx4)");
+    RUN(8 | 256, "scalar T + SoA records (8 B alpha, 4 B rgb)");
     RUN(1, "no rgb gather");
     RUN(2, "no occ read");
     RUN(4, "no rec store");

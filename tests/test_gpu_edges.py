@@ -349,3 +349,34 @@ def test_cold_start_every_voxel_new_and_capacity_boundary():
     with pytest.raises(B._lib.BscError, match="capacity"):
         small.ingest(d, c, t, Ts)
     small.close()
+
+
+def test_token_capacity_refusal_leaves_the_store_consistent():
+    """A flush that could overflow the token pool is refused before anything is changed: the error is loud, the store
+    exported afterwards is the store from before, and the same context keeps answering queries."""
+    import random
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    H, W, g, D, F = 48, 64, 16, 16, 3
+    rgb, depth, poses = synth.make_frames(4, F, H, W, "room")
+    tokens = synth.make_tokens(4, F, g, D)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    eng = B.VoxelEngine(H, W, 128, 0.1, -6.4, 6.4, g, D, mode="exact", iter_size=2000, voxel_capacity=20_000,
+                        token_capacity=7000, max_points=H * W)
+    random.seed(0)
+    d, c, t = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    eng.ingest(d[:1], c[:1], t[:1], Ts[:1])                  # ~3000 points: one in-call flush of 2000 rows, ~1000 rows cached
+    assert eng.counters()["flushes"] == 1
+    eng.ingest(d[1:2], c[1:2], t[1:2], Ts[1:2])              # two more flushes: up to 6000 rows, still within 7000
+    mid = eng.export_store()
+    assert eng.counters()["flushes"] == 3 and len(mid[2]) > 5000
+    with pytest.raises(B._lib.BscError, match="token_capacity"):
+        eng.ingest(d[2:3], c[2:3], t[2:3], Ts[2:3])          # the fourth could need 8000 > 7000: refused
+    after = eng.export_store()
+    for a, b in zip(mid, after):
+        assert np.array_equal(a, b)
+    p, s, n = eng.localize(torch.randn(1, D, device="cuda"), K=5)
+    assert n[0] == 5
+    eng.close()
