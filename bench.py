@@ -139,6 +139,7 @@ class Pipeline:
         self.tok_ready = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.tok_free = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.pending = {}
+        self.enc_events = []              # (start, end) per encoder run, on the encoder's stream
         for b in range(self.NBUF):
             self.tok_free[b].record(self.main_stream)
 
@@ -146,7 +147,11 @@ class Pipeline:
         b = s % self.NBUF
         with torch.cuda.stream(self.enc_stream):
             self.enc_stream.wait_event(self.tok_free[b])          # ingest of batch s-NBUF no longer reads this token buffer
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.enc_stream)
             tok = self.encs[b](self.rgbs[s])
+            e1.record(self.enc_stream)
+            self.enc_events.append((e0, e1))
             if self.a.no_graph:
                 tok.record_stream(self.main_stream)               # eager mode: the allocator must not recycle it early
             self.pending[s] = tok
@@ -168,6 +173,7 @@ class Pipeline:
             self.step(s, hi)
 
     def reset_stats(self):
+        self.enc_events = []
         for w in STAGES:
             self.eng.kernel_stats(w, reset=True)
 
@@ -176,6 +182,9 @@ class Pipeline:
         for w, name in STAGES.items():
             k = self.eng.kernel_stats(w)
             out[name] = k["ms"] / max(1, k["launches"])
+        if self.enc_events:
+            torch.cuda.synchronize()
+            out["encoder"] = sum(a.elapsed_time(b) for a, b in self.enc_events) / len(self.enc_events)
         return out
 
     def isolated(self, lo, hi):

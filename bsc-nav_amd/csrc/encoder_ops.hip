@@ -519,13 +519,19 @@ __device__ __forceinline__ void att_issue_loads(typename u32vec<4 * NLD>::type &
 }
 
 // NT key tiles of 16 (even): sequence length <= 16 * NT.  NW wavefronts, each takes the query strips w, w + NW, ...
-// Persistent workgroups: a workgroup walks the (image, head) items i, i + gridDim, ... and issues the global loads of
-// its NEXT item (K, V and its wavefronts' query strips, into registers) before it computes the current one out of LDS,
-// so the HBM-bound load phase and the issue-bound compute phase overlap instead of alternating chip-wide.
+// Persistent workgroups: a workgroup walks (image, head) items and issues the global loads of its NEXT item (K, V and
+// its wavefronts' query strips, into registers) before it computes the current one out of LDS, so the HBM-bound load
+// phase and the issue-bound compute phase overlap instead of alternating chip-wide.  Items are handed out by a ticket
+// counter (work[0]; work[1] counts finished workgroups, the last one re-arms both), not by a static stride: a workgroup
+// whose CU is shared with another stream's kernel simply takes fewer items.  With the static stride one slow or late
+// workgroup stretched the whole launch — the rgb chain of libbscnav's own side stream, resident on one or two CUs for
+// milliseconds, cost the 12 attention launches of a ViT-B forward 2.4 ms (bench pipeline 24.7 -> 22.x ms per step).
+// work == nullptr keeps the static stride.
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restrict__ qkv, int T, int H, int items,
-                                                       uint16_t *__restrict__ out)
+                                                       uint16_t *__restrict__ out, int *work)
 {
+    __shared__ int s_ticket;
     constexpr int NTHR = 64 * NW;
     constexpr int TP = NT * 16;
     constexpr int KP = 64 + 8;                              // K row pitch (bf16 elements)
@@ -544,8 +550,14 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
 
     // software pipeline over the workgroup's items; the prefetch past the last item re-reads the last one (harmless)
     int item = blockIdx.x;
+    if (work) {
+        if (tid == 0) s_ticket = atomicAdd(&work[0], 1);
+        __syncthreads();
+        item = s_ticket;
+    }
     att_issue_loads<NLD, NTHR>(k8, v8, q8, qkv, item < items ? item : items - 1, T, H, tid);
-    for (; item < items; item += gridDim.x) {
+    int nxt = item;
+    for (; item < items; item = nxt) {
         const int b = item / H, h = item % H;
         __syncthreads();                                            // the previous item's strips are done with LDS
 #pragma unroll
@@ -571,11 +583,10 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
                 }
             }
         }
+        if (work && tid == 0) s_ticket = atomicAdd(&work[0], 1);    // everyone has read the previous ticket (barrier above)
         __syncthreads();
-        {                                                           // in flight during the strips below
-            const int nxt = item + (int)gridDim.x;
-            att_issue_loads<NLD, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
-        }
+        nxt = work ? s_ticket : item + (int)gridDim.x;
+        att_issue_loads<NLD, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);      // in flight during the strips below
 #pragma unroll
         for (int si = 0; si < NSTRIP; ++si) {
             const int strip = wave + NW * si;
@@ -667,10 +678,19 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
             }
         }
     }
+    // the last workgroup to leave re-arms the counters for the next launch on this stream
+    if (work && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&work[1], 1) == (int)gridDim.x - 1) {
+            work[0] = 0;
+            work[1] = 0;
+            __threadfence();
+        }
+    }
 }
 
-extern "C" bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
-                                        void *out_dev, void *hip_stream)
+extern "C" bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                                            void *out_dev, int32_t *work2_dev, void *hip_stream)
 {
     if (!qkv_dev || !out_dev || B < 1 || T < 1 || heads < 1) return BSC_E_INVALID;
     if (head_dim != 64 || T > 288) {
@@ -688,10 +708,16 @@ extern "C" bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t 
     const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
     if (T <= 224)
         hipLaunchKernelGGL((k_attention<14, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
-                           (uint16_t *)out_dev);
+                           (uint16_t *)out_dev, (int *)work2_dev);
     else
         hipLaunchKernelGGL((k_attention<18, 8>), grid, dim3(64 * 8), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
-                           (uint16_t *)out_dev);
+                           (uint16_t *)out_dev, (int *)work2_dev);
     BSC_HIP(hipGetLastError());
     return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                                        void *out_dev, void *hip_stream)
+{
+    return bsc_enc_attention_dyn(qkv_dev, B, T, heads, head_dim, out_dev, nullptr, hip_stream);
 }

@@ -400,7 +400,7 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
     }
 
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
-#define CHAIN_WAVES 128
+#define CHAIN_WAVES 512
 __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
                                               const int4 *__restrict__ seg_info,
                                               const PointRec *__restrict__ p_rec,
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
                                               float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                               int gs, int64_t order_base)
 {
-    // a handful of long-lived wavefronts beside throughput kernels: take the SIMD's issue slots whenever ready
-    __builtin_amdgcn_s_setprio(3);
+    // default wave priority: raised priority (s_setprio 3) bought the chain nothing (its steps are latency-bound) and cost
+    // the kernels beside it 0.7 ms per 384-frame step
     const int lane = threadIdx.x & 63;
     const int q = lane & 3;
     const int ch = q < 3 ? q : 2;
@@ -733,13 +733,14 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     x->chain_pending = false;
     const int set = x->chain_set;
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
-    // CHAIN_WAVES wavefronts x 16 quads pull segments from the queue, longest first.  More wavefronts finish no sooner
-    // (the longest voxel bounds the kernel; 2048 quads at ~30 ns per step walk the 1.2e8 points of a 384-frame call in
-    // 1.7 ms) and only take CUs from the kernels running beside it: a CU with a resident chain wavefront (178 VGPRs) cannot
-    // take a 512-register GEMM wavefront of the caller's encoder (measured: the encoder runs 2.2x slower beside 512
-    // single-wave workgroups that spin, unchanged beside 16).  So they are launched as workgroups of 4 (one wavefront per
-    // SIMD of a CU, 32 CUs in all); the queue hands the longest segments to the first workgroups, which keeps the chain's
-    // long tail on one or two CUs.  Two wavefronts per SIMD (workgroups of 8) slow the tail itself: 6 -> 9 ms.
+    // CHAIN_WAVES wavefronts x 16 quads pull segments from the queue, longest first, in workgroups of 4 (one wavefront per
+    // SIMD of a CU): the queue hands the longest segments to the first workgroups, which keeps the chain's long tail on one
+    // or two CUs — a CU with a resident chain wavefront (178 VGPRs) cannot take a 512-register GEMM wavefront of the
+    // caller's encoder.  What the kernels beside the chain lose is proportional to how long it runs (384-frame pipeline:
+    // +1.0 ms per step for the 2.6 ms chain of the "hall" scene, +2.5 ms for the 6.2 ms chain of the "room" scene whose
+    // hottest voxel collects 2e5 points per call), so the wave count is the one that finishes a scene without such a voxel
+    // soonest (hall: 128 / 256 / 512 waves = 6.7 / 4.6 / 2.6 ms); a tail-bound call is indifferent to it.  Two wavefronts
+    // per SIMD (workgroups of 8) slow the tail itself: 6 -> 9 ms.
     stat_begin(x, BSC_STAT_CHAIN, x->side);
     hipLaunchKernelGGL(k_chain, dim3(CHAIN_WAVES * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
                        x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
@@ -825,7 +826,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         return BSC_E_CAPACITY;
     }
     // dense feature reduce first: it only needs the ids.  The rgb chain is launched at the very end of the call, so that
-    // its bulk phase (thousands of quads stepping at raised priority) overlaps the head of the NEXT call instead of
+    // its bulk phase (thousands of quads stepping) overlaps the head of the NEXT call instead of
     // this call's pair sort and reduce (measured: the first pair-sort pass 0.05 -> 0.84 ms beside a starting chain).
     if (!exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
     stat_begin(x, BSC_STAT_ORDER);

@@ -45,9 +45,11 @@ class _Block(nn.Module):
             from . import _lib
             qkv = self.qkv(y)
             a = torch.empty((B, T, Wd), dtype=torch.bfloat16, device=y.device)
-            _lib.check(_lib.load().bsc_enc_attention(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
-                                                     C.c_void_p(a.data_ptr()),
-                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if getattr(self, "_att_work", None) is None or self._att_work.device != y.device:
+                self._att_work = torch.zeros(2, dtype=torch.int32, device=y.device)     # ticket / finished counters
+            _lib.check(_lib.load().bsc_enc_attention_dyn(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
+                                                         C.c_void_p(a.data_ptr()), C.c_void_p(self._att_work.data_ptr()),
+                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             return self.proj(a)
         qkv = self.qkv(y).reshape(B, T, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])

@@ -225,6 +225,11 @@ bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *delta_dev, con
  * out_dev (B,T,heads*head_dim) bf16.  head_dim == 64, T <= 288 (ViT-B/16: 197, ViT-L/14 + 4 registers: 261). */
 bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim, void *out_dev,
                              void *hip_stream);
+/* Same, with the (image, head) items handed to the persistent workgroups by a ticket counter instead of a static stride:
+ * work2_dev = two int32 in device memory, zero before the first launch (the kernel re-arms them when it finishes;
+ * consecutive launches on one stream may share them).  Robust when some CUs are busy with another stream's kernels. */
+bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim, void *out_dev,
+                                 int32_t *work2_dev, void *hip_stream);
 
 /* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
  * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM
