@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the encoder eagerly instead of a HIP graph")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap encoder(s+1) with ingest(s)")
+    ap.add_argument("--serial", action="store_true", help="strict alternation on the GPU: encoder(s+1) starts when the main-"
+                    "stream kernels of ingest(s) are done (the two stages time-slice the chip anyway)")
     ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
     ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
     ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurements")
@@ -139,6 +141,7 @@ class Pipeline:
         self.tok_ready = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.tok_free = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.pending = {}
+        self.ing_done = None              # event after the main-stream kernels of the last ingest (--serial)
         self.enc_events = []              # (start, end) per encoder run, on the encoder's stream
         for b in range(self.NBUF):
             self.tok_free[b].record(self.main_stream)
@@ -147,6 +150,9 @@ class Pipeline:
         b = s % self.NBUF
         with torch.cuda.stream(self.enc_stream):
             self.enc_stream.wait_event(self.tok_free[b])          # ingest of batch s-NBUF no longer reads this token buffer
+            if self.a.serial and self.ing_done is not None:
+                self.enc_stream.wait_event(self.ing_done)
+                self.eng.stream_wait_chain(self.enc_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(self.enc_stream)
             tok = self.encs[b](self.rgbs[s])
@@ -167,6 +173,9 @@ class Pipeline:
         self.main_stream.wait_event(self.tok_ready[b])
         self.eng.ingest(self.depths[s], self.rgbs[s], self.pending.pop(s), self.Ts[s * self.batch:(s + 1) * self.batch])
         self.tok_free[b].record(self.main_stream)
+        if self.a.serial:
+            self.ing_done = torch.cuda.Event()
+            self.ing_done.record(self.main_stream)
 
     def run(self, lo, hi):
         for s in range(lo, hi):

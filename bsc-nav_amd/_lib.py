@@ -62,6 +62,7 @@ SIGNATURES = {
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "bsc_kernel_stats": (_I32, [_VP, _I32, _I32, _VP]),
     "bsc_sync": (_I32, [_VP]),
+    "bsc_stream_wait_chain": (_I32, [_VP, _VP]),
     "bsc_enc_embed_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_final_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_attention": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP]),

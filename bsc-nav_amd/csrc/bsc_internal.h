@@ -117,6 +117,7 @@ struct bsc_ctx {
     bool ev_done_valid[2];
     bool chain_pending;        // the last call's rgb chain / top-down map kernels are still to be launched (deferred)
     int chain_set;
+    int last_chain_set;        // scratch set of the most recently launched chain (-1: none since the last reset)
     int64_t chain_order_base;
     u64 *pair_key_a, *pair_key_b;   // dense: voxel id << cb | frame << pb | patch
     u64 *pstage_key;                // per-tile staging of the LDS-aggregated pairs

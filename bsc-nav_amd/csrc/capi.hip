@@ -67,6 +67,7 @@ static bsc_status reset_state(bsc_ctx *x)
 {
     hipStream_t s = x->stream;
     x->chain_pending = false;                  // the state it would update is being cleared
+    x->last_chain_set = -1;
     if (x->side) BSC_HIP(hipStreamSynchronize(x->side));
     x->ev_done_valid[0] = x->ev_done_valid[1] = false;
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
@@ -324,6 +325,16 @@ extern "C" bsc_status bsc_sync(bsc_ctx *x)
     if (!x) return BSC_E_INVALID;
     BSC_HIP(hipSetDevice(x->device));
     return sync_all(x);
+}
+
+extern "C" bsc_status bsc_stream_wait_chain(bsc_ctx *x, void *hip_stream)
+{
+    if (!x) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    // the most recently LAUNCHED chain (a deferred one that has not been launched yet is not waited for)
+    const int last = x->last_chain_set;
+    if (last >= 0 && x->ev_done_valid[last]) BSC_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, x->ev_done[last], 0));
+    return BSC_OK;
 }
 
 extern "C" bsc_status bsc_ingest_typed(bsc_ctx *x, int32_t n_frames, const float *depth_dev, const uint8_t *rgb_dev,

@@ -750,6 +750,7 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     stat_end(x, BSC_STAT_CHAIN, 0.0, x->side);
     BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
     x->ev_done_valid[set] = true;
+    x->last_chain_set = set;
     BSC_HIP(hipGetLastError());
     return BSC_OK;
 }

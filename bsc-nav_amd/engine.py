@@ -102,6 +102,10 @@ class VoxelEngine:
     def reset(self):
         _lib.check(self.lib.bsc_reset(self.h))
 
+    def stream_wait_chain(self, stream):
+        """`stream` (torch.cuda.Stream) waits on the GPU for the rgb chain kernels launched so far."""
+        _lib.check(self.lib.bsc_stream_wait_chain(self.h, C.c_void_p(stream.cuda_stream)))
+
     def sync(self):
         """Everything ingest() has started or deferred (the rgb chain of the last call is launched lazily) is complete."""
         _lib.check(self.lib.bsc_sync(self.h))

@@ -252,6 +252,9 @@ bsc_status bsc_kernel_stats(bsc_ctx *ctx, int32_t which, int32_t reset, double *
  * export / merge / reset, or here — so that their sequential tail overlaps the next call's front end rather than the
  * caller's encoder.  Returns when both library streams are idle. */
 bsc_status bsc_sync(bsc_ctx *ctx);
+/* GPU-side: `hip_stream` waits for the rgb chain kernels launched so far (not for a still-deferred one) — for callers that
+ * schedule their own work (an encoder) around the library's side stream without blocking the host. */
+bsc_status bsc_stream_wait_chain(bsc_ctx *ctx, void *hip_stream);
 
 #ifdef __cplusplus
 }
