@@ -65,6 +65,7 @@ struct bsc_ctx {
     uint8_t *cv_map;   // (gs,gs,3)
     // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
     bool geom_fast;
+    bool long_chain;           // segments of >= 64 points go to the wavefront-per-voxel chain (BSC_QUAD_CHAIN_ONLY unsets)
     uint8_t *pat_x, *pat_y;   // (W), (H): patch column / row of a pixel column / row, 255 = outside the patch grid
     // patch-aligned pair tiles (dense.hip): pixel rectangle {x0, width, y0, pixels} of every patch and the start of its
     // staging slice inside a frame; valid when every patch covers at most 3328 pixels

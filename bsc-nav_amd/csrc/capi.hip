@@ -163,6 +163,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->pat_y, c.height);
     {
         uint8_t *tx = (uint8_t *)malloc(c.width), *ty = (uint8_t *)malloc(c.height);
+        x->long_chain = getenv("BSC_QUAD_CHAIN_ONLY") == nullptr;
         x->geom_fast = getenv("BSC_GENERIC_GEOMETRY") == nullptr && c.patch_grid < 255 && pinhole(c.K) && pinhole(c.Kinv) &&
                        pinhole(c.Kpatch) && c.width < (1 << 24) / c.height &&
                        patch_table(c.width, c.Kinv[0], c.Kinv[2], c.Kpatch[0], c.Kpatch[2], c.patch_grid, tx) &&
@@ -235,7 +236,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
         ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
-        ALLOC(x->seg_info_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->seg_last_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->bscal_s[k], 4);
+        ALLOC(x->seg_info_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->seg_last_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->bscal_s[k], 8);
         BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
         BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
     }
