@@ -65,6 +65,7 @@ SIGNATURES = {
     "bsc_stream_wait_chain": (_I32, [_VP, _VP]),
     "bsc_enc_embed_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_final_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "bsc_enc_bias_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_attention": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP]),
     "bsc_enc_attention_dyn": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "bsc_enc_preprocess_patches": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),

@@ -274,6 +274,81 @@ extern "C" bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *del
     return BSC_OK;
 }
 
+// ---- bias-lagged residual stream -----------------------------------------------------------------------------------------
+// With the projection and fc2 GEMMs accumulating straight into the residual stream (D = A*W + C, beta = 1, no bias), what
+// the stream lacks is the sum of the biases of the residual updates so far — a constant vector per position in the stack
+// (f32, computed once from the weights).  LayerNorm adds it on the fly: y = LayerNorm(u + bias_sum).  One read of the
+// stream and one write of y per LayerNorm instead of two reads and two writes (k_add_layernorm), and the residual add
+// itself happens in the GEMM's f32 accumulator (one rounding to bf16 instead of two).
+// SKIP > 0: only rows [skip, T) of every image are normalised and written densely (the final LayerNorm of the patch rows).
+template <int NG, int OUT>      // OUT 0: bf16, 1: f32 (the bf16-rounded value widened)
+__global__ __launch_bounds__(TPB) void k_bias_layernorm(const ushort4 *__restrict__ u, const float4 *__restrict__ bias_sum,
+                                                        const ushort4 *__restrict__ gamma, const ushort4 *__restrict__ beta,
+                                                        void *__restrict__ y, int64_t rows_out, int T, int skip, int width,
+                                                        float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t orow = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (orow >= rows_out) return;
+    const int w4 = width >> 2;
+    int64_t row = orow;
+    if (skip > 0) {
+        const int np = T - skip;
+        const int64_t b = orow / np;
+        row = b * T + skip + (orow - b * np);
+    }
+    float v[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        const ushort4 a = u[row * w4 + c];
+        const float4 bs = bias_sum[c];
+        v[g][0] = bf2f(a.x) + bs.x; v[g][1] = bf2f(a.y) + bs.y; v[g][2] = bf2f(a.z) + bs.z; v[g][3] = bf2f(a.w) + bs.w;
+    }
+    float mean, rstd;
+    ln_stats<NG>(v, width, eps, mean, rstd);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = lane + 64 * g;
+        const ushort4 ga = gamma[c], be = beta[c];
+        ushort4 o;
+        o.x = f2bf((v[g][0] - mean) * rstd * bf2f(ga.x) + bf2f(be.x));
+        o.y = f2bf((v[g][1] - mean) * rstd * bf2f(ga.y) + bf2f(be.y));
+        o.z = f2bf((v[g][2] - mean) * rstd * bf2f(ga.z) + bf2f(be.z));
+        o.w = f2bf((v[g][3] - mean) * rstd * bf2f(ga.w) + bf2f(be.w));
+        if (OUT) ((float4 *)y)[orow * w4 + c] = make_float4(bf2f(o.x), bf2f(o.y), bf2f(o.z), bf2f(o.w));
+        else ((ushort4 *)y)[orow * w4 + c] = o;
+    }
+}
+
+extern "C" bsc_status bsc_enc_bias_layernorm(const void *u_dev, const void *bias_sum_f32_dev, const void *gamma_dev,
+                                             const void *beta_dev, void *y_dev, int32_t out_f32, int32_t B, int32_t T,
+                                             int32_t skip, int32_t width, float eps, void *hip_stream)
+{
+    if (!u_dev || !bias_sum_f32_dev || !gamma_dev || !beta_dev || !y_dev || B < 1 || skip < 0 || T <= skip ||
+        width % 256 != 0 || width < 256 || width > 2048) {
+        bsc_set_error("bsc_enc_bias_layernorm: invalid argument");
+        return BSC_E_INVALID;
+    }
+    const int64_t rows = (int64_t)B * (T - skip);
+    const dim3 grid((unsigned)((rows * 64 + TPB - 1) / TPB)), block(TPB);
+#define BL(NG)                                                                                                                  \
+    do {                                                                                                                        \
+        if (out_f32)                                                                                                            \
+            hipLaunchKernelGGL((k_bias_layernorm<NG, 1>), grid, block, 0, (hipStream_t)hip_stream, (const ushort4 *)u_dev,      \
+                               (const float4 *)bias_sum_f32_dev, (const ushort4 *)gamma_dev, (const ushort4 *)beta_dev, y_dev,  \
+                               rows, T, skip, width, eps);                                                                      \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_bias_layernorm<NG, 0>), grid, block, 0, (hipStream_t)hip_stream, (const ushort4 *)u_dev,      \
+                               (const float4 *)bias_sum_f32_dev, (const ushort4 *)gamma_dev, (const ushort4 *)beta_dev, y_dev,  \
+                               rows, T, skip, width, eps);                                                                      \
+    } while (0)
+    ENC_NG_SWITCH(width / 256, BL)
+#undef BL
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Frame pre-processing of the patch-feature provider (memory_2.py:733-736 + transform_ :71-74) in one pass:
 //   u8 (B,H,W,C) -> /255 -> antialiased bilinear resize to (S,S) -> ImageNet normalise -> bf16 patch matrix

@@ -37,20 +37,29 @@ class _Block(nn.Module):
         self.fc1 = nn.Linear(width, mlp)
         self.fc2 = nn.Linear(mlp, width)
 
+    def attn_heads(self, y):
+        """fused attention (bsc_enc_attention) of LayerNorm'd rows y: (B, T, width) before the output projection"""
+        from . import _lib
+        B, T, Wd = y.shape
+        hd = Wd // self.heads
+        qkv = self.qkv(y)
+        a = torch.empty((B, T, Wd), dtype=torch.bfloat16, device=y.device)
+        if getattr(self, "_att_work", None) is None or self._att_work.device != y.device:
+            self._att_work = torch.zeros(2, dtype=torch.int32, device=y.device)     # ticket / finished counters
+        _lib.check(_lib.load().bsc_enc_attention_dyn(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
+                                                     C.c_void_p(a.data_ptr()), C.c_void_p(self._att_work.data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return a
+
+    def can_fuse_attention(self, y):
+        return y.shape[-1] // self.heads == 64 and y.shape[1] <= 288 and y.dtype == torch.bfloat16 and y.is_cuda
+
     def attn(self, y, fused=False):
         B, T, Wd = y.shape
         hd = Wd // self.heads
-        if fused and hd == 64 and T <= 288 and y.dtype == torch.bfloat16 and y.is_cuda:
+        if fused and self.can_fuse_attention(y):
             # (B,T,3,heads,64) straight out of the qkv GEMM -> bsc_enc_attention (K, V of a head resident in LDS)
-            from . import _lib
-            qkv = self.qkv(y)
-            a = torch.empty((B, T, Wd), dtype=torch.bfloat16, device=y.device)
-            if getattr(self, "_att_work", None) is None or self._att_work.device != y.device:
-                self._att_work = torch.zeros(2, dtype=torch.int32, device=y.device)     # ticket / finished counters
-            _lib.check(_lib.load().bsc_enc_attention_dyn(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
-                                                         C.c_void_p(a.data_ptr()), C.c_void_p(self._att_work.data_ptr()),
-                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            return self.proj(a)
+            return self.proj(self.attn_heads(y))
         qkv = self.qkv(y).reshape(B, T, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         return self.proj(a.transpose(1, 2).reshape(B, T, Wd))
@@ -68,6 +77,7 @@ class RandomViT(nn.Module):
         super().__init__()
         self.fused = fused
         self.fused_attention = fused and os.environ.get("BSC_ENC_ATTENTION", "1") == "1"   # 0: library SDPA
+        self.lagged = os.environ.get("BSC_ENC_LAGGED", "1") == "1"     # 0: residual adds in the LayerNorm kernel
         s = VIT_SHAPES[arch]
         self.arch, self.image_size, self.patch = arch, image_size, s["patch"]
         self.grid = image_size // s["patch"]
@@ -139,6 +149,8 @@ class RandomViT(nn.Module):
                 t = torch.cat([t[:, :1], self.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
             t = t.contiguous()
             t, y = self._add_ln(t, None, self.blocks[0].ln1, fuse)
+        if fuse and self.lagged and self.head is None and self.fused_attention and self.blocks[0].can_fuse_attention(y):
+            return {"x_norm_patchtokens": self._forward_lagged(t, y, keep_dtype)}
         # pre-LN transformer with every residual add fused into the LayerNorm that follows it
         last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
@@ -160,6 +172,52 @@ class RandomViT(nn.Module):
         if self.head is not None:
             t = self.head(t)
         return {"x_norm_patchtokens": t if keep_dtype else t.float()}
+
+    def _bias_sums(self, device):
+        """f32 running sums of the biases of the residual updates (proj, fc2 of every block): row k = what the stream lacks
+        after k updates"""
+        if getattr(self, "_bsum", None) is None or self._bsum.device != device:
+            acc, rows = torch.zeros(self.width, dtype=torch.float32, device=device), []
+            for blk in self.blocks:
+                for lin in (blk.proj, blk.fc2):
+                    acc = acc + lin.bias.float()
+                    rows.append(acc)
+            self._bsum = torch.stack(rows).contiguous()
+        return self._bsum
+
+    def _forward_lagged(self, u, y, keep_dtype):
+        """The transformer stack on a bias-lagged residual stream: the projection and fc2 GEMMs accumulate into the stream
+        (D = A W^T + C, beta = 1, no bias — the add happens in the GEMM's f32 accumulator), LayerNorm adds the running bias
+        sum on the fly (bsc_enc_bias_layernorm): one read + one write per LayerNorm instead of two + two."""
+        from . import _lib
+        lib = _lib.load()
+        B, T, Wd = u.shape
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        bsum = self._bias_sums(u.device)
+        u2 = u.view(B * T, Wd)
+        last = len(self.blocks) - 1
+        skip = 1 + self.registers
+
+        def bias_ln(k, ln, final):
+            if final:
+                out = torch.empty((B, T - skip, Wd), dtype=torch.bfloat16 if keep_dtype else torch.float32, device=u.device)
+            else:
+                out = torch.empty_like(u)
+            _lib.check(lib.bsc_enc_bias_layernorm(
+                C.c_void_p(u.data_ptr()), C.c_void_p(bsum[k].data_ptr()), C.c_void_p(ln.weight.data_ptr()),
+                C.c_void_p(ln.bias.data_ptr()), C.c_void_p(out.data_ptr()), 0 if (keep_dtype or not final) else 1, B, T,
+                skip if final else 0, Wd, float(ln.eps), stream))
+            return out
+
+        for i, blk in enumerate(self.blocks):
+            a = blk.attn_heads(y)
+            torch.addmm(u2, a.view(B * T, Wd), blk.proj.weight.t(), out=u2)
+            y = bias_ln(2 * i, blk.ln2, False)
+            h = torch._addmm_activation(blk.fc1.bias, y.view(B * T, Wd), blk.fc1.weight.t(), use_gelu=True)
+            torch.addmm(u2, h, blk.fc2.weight.t(), out=u2)
+            if i == last:
+                return bias_ln(2 * i + 1, self.norm, True)
+            y = bias_ln(2 * i + 1, self.blocks[i + 1].ln1, False)
 
     def _add_ln(self, x, delta, ln, fuse):
         """(x + delta, LayerNorm(x + delta)); one HIP kernel (bsc_enc_add_layernorm) when `fuse`."""

@@ -220,6 +220,15 @@ bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *delta_dev, con
                                    void *out_dev, int32_t out_f32, int32_t B, int32_t T, int32_t skip, int32_t width,
                                    float eps, void *hip_stream);
 
+/* LayerNorm of a bias-lagged residual stream (bf16 rows u, f32 vector bias_sum of `width`): y = LayerNorm(u + bias_sum).
+ * The stream is the one the projection / fc2 GEMMs accumulate into with beta = 1 and no bias (encoder.py), bias_sum the sum
+ * of the biases of the residual updates so far; same place in the reference's path as bsc_enc_add_layernorm
+ * (memory_2.py:739, the ViT behind forward_features).  skip > 0 normalises rows [skip, T) of every image only and writes
+ * them densely (final LayerNorm of the patch rows); out_f32 selects f32 output (bf16-rounded values widened). */
+bsc_status bsc_enc_bias_layernorm(const void *u_dev, const void *bias_sum_f32_dev, const void *gamma_dev,
+                                  const void *beta_dev, void *y_dev, int32_t out_f32, int32_t B, int32_t T, int32_t skip,
+                                  int32_t width, float eps, void *hip_stream);
+
 /* Encoder helper: softmax(Q K^T / sqrt(d)) V for the short sequences of the ViT provider, one workgroup per (image, head)
  * with K and V of the head resident in LDS.  qkv_dev (B,T,3,heads,head_dim) bf16 as the fused qkv GEMM writes it,
  * out_dev (B,T,heads*head_dim) bf16.  head_dim == 64, T <= 288 (ViT-B/16: 197, ViT-L/14 + 4 registers: 261). */
