@@ -226,7 +226,8 @@ def test_bf16_tokens_equal_widened_f32_tokens(mode):
         assert np.array_equal(a, b)
 
 
-def _dense_vs_oracle(H, W, g, D, gs, cs, lo, hi, F, per_call, seed, vcap, kind="room", depth_override=None):
+def _dense_vs_oracle(H, W, g, D, gs, cs, lo, hi, F, per_call, seed, vcap, kind="room", depth_override=None,
+                     alpha_override=None):
     """Dense mean mode, every pixel, host alpha: ids, positions, rgb bytes, weights, top-down map, counts bit-exact and
     feature sums within 1e-3 against the sequential oracle."""
     import torch
@@ -246,6 +247,8 @@ def _dense_vs_oracle(H, W, g, D, gs, cs, lo, hi, F, per_call, seed, vcap, kind="
     for f in range(F):
         gm = orc.geometry(oc, depth[f], None, Ts[f])
         al = np.exp(-gm["r2"] / (2 * 0.6))
+        if alpha_override is not None:
+            al = alpha_override(f, al)
         alphas.append(al)
         om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f], al)
     d_depth, d_rgb, d_tok = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
@@ -279,6 +282,32 @@ def test_very_long_voxel_chains_against_oracle():
     segment (prefetch pipeline, longest-first queue, segments far longer than the wavefront count) — bit-exact rgb."""
     longest, n_vox = _dense_vs_oracle(480, 640, 14, 32, 32, 1.0, -16.0, 16.0, F=6, per_call=6, seed=9, vcap=40_000)
     assert longest > 100_000 and n_vox < 2000
+
+
+def test_long_chains_of_old_voxels_over_several_calls():
+    """The same scene in three calls: from the second call on the long segments belong to voxels that already carry a
+    large weight (no early part on the quad chain; the speculating kernel starts from the stored state, crosses weight
+    binades inside a round and keeps colours that almost never change)."""
+    longest, n_vox = _dense_vs_oracle(480, 640, 14, 32, 32, 1.0, -16.0, 16.0, F=6, per_call=2, seed=10, vcap=40_000)
+    assert longest > 100_000
+
+
+def test_weight_ties_and_saturation_against_oracle():
+    """A handful of 50 m cells take every point.  alpha = 1 until the f32 weights pass 2^23 (one ulp = 1), then values
+    from {0.25, 0.5, 0.75, 1}: 0.5 is an exact tie whose rounding depends on the parity of the running weight (the
+    speculating kernel's prefix prediction cannot know it, its check must catch it), and past 2^24 every addition is lost
+    or a tie (memory_2.py:896-899 in f32).  rgb bytes and weights bit-exact against the sequential oracle."""
+    rs = np.random.RandomState(4)
+    H, W = 240, 320
+
+    def alphas(f, al):
+        if f < 125:
+            return np.ones_like(al)
+        return rs.choice(np.array([0.25, 0.5, 0.75, 1.0]), size=al.shape)
+
+    longest, n_vox = _dense_vs_oracle(H, W, 16, 16, 4, 50.0, -100.0, 100.0, F=260, per_call=65, seed=12, vcap=64,
+                                      alpha_override=alphas)
+    assert longest > (1 << 24) and n_vox <= 8         # a voxel collected more points than an f32 weight can count
 
 
 @pytest.mark.parametrize("hw,g", [((480, 640), 14), ((240, 320), 16), ((680, 680), 16), ((97, 131), 7)])
