@@ -6,7 +6,7 @@ kernels of the memory path (libbscnav's own + the rocPRIM sorts / scans and fill
 bench.py sums (2 x FETCH + WRITE) x launches_per_call over the ingest kernels for `roofline.traffic`."""
 import collections, csv, json, os, sys
 root, out_path, commit = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "unknown")
-ENCODER = ("k_attention", "k_add_layernorm", "k_embed_layernorm", "k_final_layernorm", "k_preprocess", "k_pp_taps", "Cijk", "Custom_Cijk",
+ENCODER = ("k_attention", "k_add_layernorm", "k_bias_layernorm", "k_embed_layernorm", "k_final_layernorm", "k_preprocess", "k_pp_taps", "Cijk", "Custom_Cijk",
            "at::native", "__amd_rocclr_copyBuffer", "k_cosine", "k_cand", "k_block_topk", "k_gather", "k_normalize_q", "k_name", "k_pool")
 out, calls = {}, None
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
