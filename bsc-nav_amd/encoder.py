@@ -20,6 +20,12 @@ VIT_SHAPES = {
     "vit_b16": dict(patch=16, width=768, depth=12, heads=12, mlp=3072, registers=0),
     "vit_l14": dict(patch=14, width=1024, depth=24, heads=16, mlp=4096, registers=4),
     "vit_tiny_test": dict(patch=16, width=64, depth=2, heads=4, mlp=128, registers=0),
+    # DINOv2 hub shapes (the reference loads args.dino_size = dinov2_vitl14_reg, args.py:50); ViT-g uses SwiGLU: not covered
+    "vit_s14": dict(patch=14, width=384, depth=12, heads=6, mlp=1536, registers=0),
+    "vit_b14": dict(patch=14, width=768, depth=12, heads=12, mlp=3072, registers=0),
+    "vit_s14_reg": dict(patch=14, width=384, depth=12, heads=6, mlp=1536, registers=4),
+    "vit_b14_reg": dict(patch=14, width=768, depth=12, heads=12, mlp=3072, registers=4),
+    "vit_l14_noreg": dict(patch=14, width=1024, depth=24, heads=16, mlp=4096, registers=0),
 }
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -73,7 +79,8 @@ class _Block(nn.Module):
 
 
 class RandomViT(nn.Module):
-    def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16, fused=True):
+    def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16, fused=True,
+                 init_weights=True):
         super().__init__()
         self.fused = fused
         self.fused_attention = fused and os.environ.get("BSC_ENC_ATTENTION", "1") == "1"   # 0: library SDPA
@@ -93,7 +100,7 @@ class RandomViT(nn.Module):
         self.norm = nn.LayerNorm(s["width"], eps=1e-6)
         self.head = nn.Linear(s["width"], out_dim, bias=False) if out_dim and out_dim != s["width"] else None
         self.out_dim = out_dim or s["width"]
-        for p in self.parameters():
+        for p in self.parameters() if init_weights else ():
             if p.dim() > 1:
                 nn.init.trunc_normal_(p, std=0.02, generator=g)
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
@@ -103,6 +110,72 @@ class RandomViT(nn.Module):
         for name, prm in self.named_parameters():
             prm.data = prm.data.to(dtype)
             prm.requires_grad_(False)
+
+    # ---- real weights -------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_dinov2_state_dict(cls, sd, image_size=224, dtype=torch.bfloat16, fused=True, **kw):
+        """A RandomViT of the right shape filled from a DINOv2 `state_dict()` (torch.hub facebookresearch/dinov2, the model
+        the reference passes as `preload_dino`; memory_2.py:43, args.py:50)."""
+        width, p = sd["patch_embed.proj.weight"].shape[0], sd["patch_embed.proj.weight"].shape[-1]
+        depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks.") and k.split(".")[1].isdigit())
+        regs = sd["register_tokens"].shape[1] if "register_tokens" in sd else 0
+        mlp = sd["blocks.0.mlp.fc1.weight"].shape[0] if "blocks.0.mlp.fc1.weight" in sd else None
+        if mlp is None:
+            raise ValueError("SwiGLU feed-forward (DINOv2 ViT-g) is not covered")
+        arch = next((a for a, s in VIT_SHAPES.items() if (s["patch"], s["width"], s["depth"], s["mlp"], s["registers"]) ==
+                     (p, width, depth, mlp, regs)), None)
+        if arch is None:
+            raise ValueError(f"no ViT shape for patch {p}, width {width}, depth {depth}, mlp {mlp}, registers {regs}")
+        vit = cls(arch, image_size=image_size, dtype=dtype, fused=fused, init_weights=False)
+        vit.load_dinov2_state_dict(sd, **kw)
+        return vit
+
+    @torch.no_grad()
+    def load_dinov2_state_dict(self, sd, interpolate_antialias=None, interpolate_offset=None):
+        """Maps DINOv2's parameters onto this module: the patch convolution as the unfolded-patch GEMM, the position
+        embedding resampled to this grid the way `interpolate_pos_encoding` does (bicubic; antialias and no offset for the
+        register models, offset 0.1 otherwise — the hub defaults), LayerScale folded into the projection and fc2 weights
+        and biases (x + g * (a W^T + b) = x + a (g W)^T + g b).  The MLP activation runs as tanh-GELU in the GEMM epilogue
+        (|tanh form - erf form| < 5e-4, below bf16 resolution)."""
+        dev, dt = self.cls.device, self.compute_dtype
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+        put = lambda prm, t: prm.data.copy_(t.to(dt))
+        D, g = self.width, self.grid
+        put(self.patch_embed.weight, f(sd["patch_embed.proj.weight"]).reshape(D, -1))
+        put(self.patch_embed.bias, f(sd["patch_embed.proj.bias"]))
+        put(self.cls, f(sd["cls_token"]))
+        if self.reg is not None:
+            put(self.reg, f(sd["register_tokens"]))
+        pos = f(sd["pos_embed"])
+        n = pos.shape[1] - 1
+        m = int(round(n ** 0.5))
+        if m * m != n:
+            raise ValueError("pos_embed is not a square grid")
+        if m != g:
+            aa = (self.registers > 0) if interpolate_antialias is None else interpolate_antialias
+            off = (0.0 if self.registers > 0 else 0.1) if interpolate_offset is None else interpolate_offset
+            grid = pos[:, 1:].reshape(1, m, m, D).permute(0, 3, 1, 2)
+            if off:
+                sc = float(g + off) / m
+                grid = F.interpolate(grid, scale_factor=(sc, sc), mode="bicubic", antialias=aa)
+            else:
+                grid = F.interpolate(grid, size=(g, g), mode="bicubic", antialias=aa)
+            assert grid.shape[-2:] == (g, g)
+            pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, g * g, D)], dim=1)
+        put(self.pos, pos)
+        for i, blk in enumerate(self.blocks):
+            k = f"blocks.{i}."
+            g1 = f(sd[k + "ls1.gamma"]) if k + "ls1.gamma" in sd else torch.ones(D, device=dev)
+            g2 = f(sd[k + "ls2.gamma"]) if k + "ls2.gamma" in sd else torch.ones(D, device=dev)
+            put(blk.ln1.weight, f(sd[k + "norm1.weight"])); put(blk.ln1.bias, f(sd[k + "norm1.bias"]))
+            put(blk.ln2.weight, f(sd[k + "norm2.weight"])); put(blk.ln2.bias, f(sd[k + "norm2.bias"]))
+            put(blk.qkv.weight, f(sd[k + "attn.qkv.weight"])); put(blk.qkv.bias, f(sd[k + "attn.qkv.bias"]))
+            put(blk.proj.weight, g1[:, None] * f(sd[k + "attn.proj.weight"])); put(blk.proj.bias, g1 * f(sd[k + "attn.proj.bias"]))
+            put(blk.fc1.weight, f(sd[k + "mlp.fc1.weight"])); put(blk.fc1.bias, f(sd[k + "mlp.fc1.bias"]))
+            put(blk.fc2.weight, g2[:, None] * f(sd[k + "mlp.fc2.weight"])); put(blk.fc2.bias, g2 * f(sd[k + "mlp.fc2.bias"]))
+        put(self.norm.weight, f(sd["norm.weight"])); put(self.norm.bias, f(sd["norm.bias"]))
+        self._bsum = None                       # bias sums of the lagged stream follow the new weights
+        return self
 
     @torch.no_grad()
     def preprocess(self, rgb):

@@ -27,7 +27,7 @@ class VoxelTokenMemory:
     def __init__(self, args, memory_path=None, init_state=None, build_map=False, preload_dino=None,
                  preload_yolo=None, need_diffusion=True, *, feature_mode="exact", env=None, imaginer=None,
                  token_dim=None, patch_size=None, voxel_capacity=None, token_capacity=None, gpu=0,
-                 alpha_source=None, max_frames_per_call=1, quiet=True):
+                 alpha_source=None, max_frames_per_call=1, quiet=True, fuse_encoder=False):
         self.args = args
         self.cfg = from_namespace(args)
         self.device = "cuda"                                    # memory_2.py:41
@@ -56,6 +56,11 @@ class VoxelTokenMemory:
         self.n_patch_h = c.query_height // self.patch_h
         if self.n_patch_w != self.n_patch_h:
             raise ValueError("square patch grids only (the reference reshapes to (n_patch_w, n_patch_h))")
+        if fuse_encoder and preload_dino is not None and not hasattr(preload_dino, "patch_tokens"):
+            # opt-in: the hub DINOv2 module's weights run through this library's fused bf16 encoder (encoder.RandomViT:
+            # same architecture, LayerScale folded, ~15x the frames/s of the f32 module); numerics are bf16, not f32
+            from .encoder import RandomViT
+            self.dinov2 = RandomViT.from_dinov2_state_dict(preload_dino.state_dict(), image_size=c.query_height).to(f"cuda:{gpu}")
         self.chain = PoseChain(c.base_forward_axis, c.base_left_axis, c.base_up_axis, c.base2cam_rot, c.sensor_height)
         self.base_transform = self.chain.base_transform
         self.base2cam_tf = self.chain.base2cam_tf

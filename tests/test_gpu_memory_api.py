@@ -314,6 +314,92 @@ def test_fused_encoder_ends_match_pytorch(arch):
         assert e.max().item() < 2.0 * e_plain.max().item() and e.max().item() < 0.25, (lagged, e.max().item())
 
 
+def _dinov2_state_dict(width, depth, heads, mlp, regs, patch=14, pos_grid=37, seed=0):
+    """A state_dict with DINOv2's parameter names and shapes (facebookresearch/dinov2 vision_transformer.py), random values:
+    LayerScale gammas far from 1 and a position embedding on the 37x37 training grid, so that a wrong fold or a wrong
+    resampling shows."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *sh, std=0.02: torch.randn(*sh, generator=g) * std
+    sd = {"patch_embed.proj.weight": rn(width, 3, patch, patch, std=0.05), "patch_embed.proj.bias": rn(width, std=0.1),
+          "cls_token": rn(1, 1, width, std=0.5), "pos_embed": rn(1, 1 + pos_grid * pos_grid, width, std=0.5),
+          "mask_token": rn(1, width), "norm.weight": 1 + rn(width, std=0.2), "norm.bias": rn(width, std=0.2)}
+    if regs:
+        sd["register_tokens"] = rn(1, regs, width, std=0.5)
+    for i in range(depth):
+        k = f"blocks.{i}."
+        sd.update({k + "norm1.weight": 1 + rn(width, std=0.2), k + "norm1.bias": rn(width, std=0.2),
+                   k + "attn.qkv.weight": rn(3 * width, width, std=0.04), k + "attn.qkv.bias": rn(3 * width, std=0.1),
+                   k + "attn.proj.weight": rn(width, width, std=0.04), k + "attn.proj.bias": rn(width, std=0.1),
+                   k + "ls1.gamma": 0.5 + torch.rand(width, generator=g), k + "ls2.gamma": 0.5 + torch.rand(width, generator=g),
+                   k + "norm2.weight": 1 + rn(width, std=0.2), k + "norm2.bias": rn(width, std=0.2),
+                   k + "mlp.fc1.weight": rn(mlp, width, std=0.04), k + "mlp.fc1.bias": rn(mlp, std=0.1),
+                   k + "mlp.fc2.weight": rn(width, mlp, std=0.03), k + "mlp.fc2.bias": rn(width, std=0.1)})
+    return sd
+
+
+def _dinov2_forward_f32(sd, x, heads, regs, antialias, offset):
+    """DinoVisionTransformer.forward_features()['x_norm_patchtokens'] restated with plain f32 PyTorch ops: strided patch
+    convolution, cls + interpolated pos (bicubic), registers after the cls token, pre-LN blocks with LayerScale, erf GELU."""
+    import torch
+    import torch.nn.functional as F
+    sd = {k: v.cuda().float() for k, v in sd.items()}
+    p = sd["patch_embed.proj.weight"].shape[-1]
+    t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=p)
+    B, D, gh, gw = t.shape
+    t = t.flatten(2).transpose(1, 2)
+    pos = sd["pos_embed"]
+    m = int(round((pos.shape[1] - 1) ** 0.5))
+    if m != gh:
+        grid = pos[:, 1:].reshape(1, m, m, D).permute(0, 3, 1, 2)
+        if offset:
+            grid = F.interpolate(grid, scale_factor=((gh + offset) / m, (gw + offset) / m), mode="bicubic", antialias=antialias)
+        else:
+            grid = F.interpolate(grid, size=(gh, gw), mode="bicubic", antialias=antialias)
+        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], dim=1)
+    t = torch.cat([sd["cls_token"].expand(B, -1, -1), t], dim=1) + pos
+    if regs:
+        t = torch.cat([t[:, :1], sd["register_tokens"].expand(B, -1, -1), t[:, 1:]], dim=1)
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    hd = D // heads
+    for i in range(depth):
+        k = f"blocks.{i}."
+        y = F.layer_norm(t, (D,), sd[k + "norm1.weight"], sd[k + "norm1.bias"], 1e-6)
+        qkv = F.linear(y, sd[k + "attn.qkv.weight"], sd[k + "attn.qkv.bias"]).reshape(B, -1, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        a = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * hd ** -0.5, dim=-1) @ qkv[2]
+        a = F.linear(a.transpose(1, 2).reshape(B, -1, D), sd[k + "attn.proj.weight"], sd[k + "attn.proj.bias"])
+        t = t + sd[k + "ls1.gamma"] * a
+        y = F.layer_norm(t, (D,), sd[k + "norm2.weight"], sd[k + "norm2.bias"], 1e-6)
+        h = F.linear(F.gelu(F.linear(y, sd[k + "mlp.fc1.weight"], sd[k + "mlp.fc1.bias"])), sd[k + "mlp.fc2.weight"], sd[k + "mlp.fc2.bias"])
+        t = t + sd[k + "ls2.gamma"] * h
+    t = F.layer_norm(t, (D,), sd["norm.weight"], sd["norm.bias"], 1e-6)
+    return t[:, 1 + regs:]
+
+
+@pytest.mark.parametrize("shape", [dict(width=1024, depth=24, heads=16, mlp=4096, regs=4), dict(width=768, depth=12, heads=12, mlp=3072, regs=0)])
+def test_dinov2_state_dict_runs_through_the_fused_encoder(shape):
+    """RandomViT.from_dinov2_state_dict: a checkpoint in DINOv2's own layout (the reference's `preload_dino`,
+    dinov2_vitl14_reg by default) evaluated by the fused bf16 path equals the architecture restated in f32 to bf16 accuracy —
+    patch convolution as GEMM, pos-embedding resampling (antialiased for the register model, offset 0.1 otherwise),
+    register insertion, LayerScale folded into the weights, lagged residual stream."""
+    import torch
+    from bsc_nav_amd import encoder
+    sd = _dinov2_state_dict(shape["width"], shape["depth"], shape["heads"], shape["mlp"], shape["regs"], seed=3)
+    vit = encoder.RandomViT.from_dinov2_state_dict(sd, image_size=224).cuda()
+    assert vit.arch == ("vit_l14" if shape["regs"] else "vit_b14") and vit.grid == 16
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    ref = _dinov2_forward_f32(sd, x, shape["heads"], shape["regs"], antialias=shape["regs"] > 0, offset=0.0 if shape["regs"] else 0.1)
+    vit.fused = False
+    e_plain = (vit.forward_features(x)["x_norm_patchtokens"] - ref).abs()
+    vit.fused = True
+    out = vit.forward_features(x)["x_norm_patchtokens"]
+    e = (out - ref).abs()
+    assert out.shape == ref.shape == (2, 256, shape["width"])
+    assert e_plain.mean().item() < 0.03 and e.mean().item() < 0.03, (e.mean().item(), e_plain.mean().item())     # outputs are O(1)
+    assert e.mean().item() < 1.15 * e_plain.mean().item() + 1e-3 and e.max().item() < 0.5, (e.mean().item(), e.max().item())
+
+
 def _write_reference_dir(path, z, name, store_arrays=None):
     """A memory directory as the reference leaves it (memory_2.py:1136-1145): npy set + long_memory.json; the token store
     only as feat.h5df (through the stand-in) when `store_arrays` is given."""
