@@ -120,6 +120,7 @@ struct bsc_ctx {
     int chain_set;
     int last_chain_set;        // scratch set of the most recently launched chain (-1: none since the last reset)
     int64_t chain_order_base;
+    int64_t chain_points;      // points of the batch whose chain is pending
     u64 *pair_key_a, *pair_key_b;   // dense: voxel id << cb | frame << pb | patch
     u64 *pstage_key;                // per-tile staging of the LDS-aggregated pairs
     uint32_t *pstage_cnt;

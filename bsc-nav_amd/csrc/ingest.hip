@@ -908,8 +908,11 @@ bsc_status launch_pending_chain(bsc_ctx *x)
                        x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
                        x->chain_order_base);
     static const int long_waves = getenv("BSC_LONG_WAVES") ? atoi(getenv("BSC_LONG_WAVES")) : LONG_WAVES;
+    // a wavefront per ~4096 points of the batch, at most long_waves (a frame-by-frame call launches a handful)
+    int64_t nw = x->chain_points / 4096;
+    nw = nw < 64 ? 64 : (nw > long_waves ? long_waves : nw);
     if (x->long_chain)
-        hipLaunchKernelGGL(k_chain_long, dim3(long_waves * 64 / LONG_WG), dim3(LONG_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
+        hipLaunchKernelGGL(k_chain_long, dim3((unsigned)(nw * 64 / LONG_WG)), dim3(LONG_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
                            x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
                            x->c.grid_size, x->chain_order_base);
     hipLaunchKernelGGL(k_hwin, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],
@@ -1034,6 +1037,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     x->chain_pending = true;
     x->chain_set = set;
     x->chain_order_base = x->order_base;
+    x->chain_points = P;
     stat_end(x, BSC_STAT_INGEST, 0.0);
     BSC_HIP(hipGetLastError());
     x->order_base += P;
