@@ -1,4 +1,5 @@
-"""BASELINE.json configs[2..4] at their real sizes on the HIP path (C3: ViT-L/14 tokens 16x16x1024 into a 512^3 grid;
+"""BASELINE.json configs at their real sizes on the HIP path (C1: one 320x240 frame, ViT-B/16 tokens projected to 512-D,
+128^3 grid — the reference's CPU-runnable case; C3: ViT-L/14 tokens 16x16x1024 into a 512^3 grid;
 C4: localize top-K over a 512^3 x 1024-D map; C5: 2^20 voxels x 1024-D, 256 batched queries, voxel-sharded).
 
 The sequential oracle is affordable for a few full-size frames; the 2^20 x 1024 scans are checked against an
@@ -8,6 +9,61 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def test_c1_single_frame_vit_b16_512d_grid128():
+    """configs[0]: a single 320x240 RGB-D frame, random-weight ViT-B/16 with a 512-D output head, 128^3 grid.  The frame goes
+    through the library's encoder (u8 frame -> fused preprocessing -> ViT -> 14x14x512 tokens) and the same tokens through
+    the sequential oracle: reference-exact mode at depth_sample_rate 1 and 50 (token cache rows, ids, rgb with host alpha,
+    top-down map, then flush + top-K) and the dense mean mode."""
+    import random
+    import torch
+    import bsc_nav_amd as B
+    import golden_util as gu
+    import synth
+    from bsc_nav_amd import encoder
+    from oracle import oracle as orc
+    H, W, g, D, gs = 240, 320, 14, 512, 128
+    rgb, depth, poses = synth.make_frames(41, 1, H, W, "room")
+    vit = encoder.RandomViT("vit_b16", image_size=224, out_dim=D, seed=2).cuda()
+    tok = vit.patch_tokens(torch.from_numpy(rgb).cuda()).contiguous()              # (1, 14, 14, 512) f32
+    assert tok.shape == (1, g, g, D) and tok.dtype == torch.float32
+    tokens = tok.cpu().numpy()
+    T = B.PoseChain().pc_transform(poses[0])
+    for rate in (1, 50):
+        idx = np.random.RandomState(rate).permutation(H * W)[::rate].astype(np.int32)
+        kw = dict(iter_size=5000)
+        eng = B.VoxelEngine(H, W, gs, 0.1, -6.4, 6.4, g, D, mode="exact", voxel_capacity=60_000, token_capacity=200_000,
+                            max_points=H * W, **kw)
+        oc = orc.make_config(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=0, **kw)
+        om = orc.OracleMemory(oc, voxel_capacity=60_000)
+        al = np.exp(-orc.geometry(oc, depth[0], idx, T)["r2"] / (2 * 0.6))
+        random.seed(7); om.ingest_frame(depth[0], rgb[0], idx, T, tokens[0], al); om.flush()
+        random.seed(7)
+        eng.ingest(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), tok, T[None], torch.from_numpy(idx).cuda(),
+                   np.array([0, len(idx)], np.int64), torch.from_numpy(al).cuda())
+        eng.flush()
+        assert eng.counters()["max_id"] == om.counters()["max_id"] > 500
+        for a, b in zip(eng.export_rgb(), om.export_rgb()):
+            assert np.array_equal(a, b)
+        for a, b in zip(eng.export_heightmap(), om.export_heightmap()):
+            assert np.array_equal(a, b)
+        for a, b in zip(eng.export_store(), om.export_store()):
+            assert np.array_equal(a, b)
+        q = torch.from_numpy(tokens[0, 5, 7].copy()).cuda()[None]
+        pos, sim, n = eng.localize(q, K=100)
+        opos, osim = om.localize(tokens[0, 5, 7], K=100)
+        gu.assert_topk_matches(pos[0, :n[0]], sim[0, :n[0]], opos, osim, tol=5e-6)
+        eng.close()
+    eng = B.VoxelEngine(H, W, gs, 0.1, -6.4, 6.4, g, D, mode="mean", voxel_capacity=60_000, max_points=H * W)
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=1), voxel_capacity=60_000)
+    om.ingest_frame(depth[0], rgb[0], None, T, tokens[0])
+    eng.ingest(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), tok, T[None])
+    (acc, cnt), (oacc, ocnt) = eng.export_dense(), om.export_dense()
+    assert np.array_equal(eng.export_rgb()[0], om.export_rgb()[0]) and np.array_equal(cnt, ocnt)
+    c = np.maximum(cnt, 1)[:, None].astype(np.float64)
+    np.testing.assert_allclose(acc / c, oacc / c, rtol=1e-3, atol=1e-3)
+    eng.close()
 
 
 def test_c3_dense_ingest_vit_l14_tokens_grid512_against_oracle():
