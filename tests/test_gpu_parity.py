@@ -200,6 +200,49 @@ def test_device_alpha_within_last_ulp_effects(torch_cuda):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["mean", "max"])
+@pytest.mark.parametrize("name", ["g2_c1_s1000", "g2_mini_s7_yaw", "g2_c1_s50_iid"])      # one flush, at the end: no point loses its token
+def test_dense_rows_equal_reduction_of_the_reference_store(torch_cuda, name, mode):
+    """The dense modes do not exist in the reference, but what they reduce does: a voxel of the reference's token store
+    that never filled up (fewer than cache_size rows, so no random replacement) holds exactly the tokens of the points the
+    reference put into that voxel, one row per point (the goldens carry the source token of every stored row).  The dense
+    mean / max of the HIP path over the same sampled points must be the mean / max of those rows, voxel by voxel — pinned to
+    the reference's own point-to-voxel-to-token assignment, not to the oracle's extension."""
+    import bsc_nav_amd as B
+    torch = torch_cuda
+    z = gu.load(name)
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    N = cfg["H"] * cfg["W"]
+    eng = _engine(cfg, mode=mode, max_points=N, voxel_capacity=max(4096, int(z["max_id"]) + 16))
+    chain = B.PoseChain()
+    np.random.seed(cfg["seed"])                          # the reference's sampling stream (memory_2.py:747-749)
+    d_depth, d_rgb, d_tok = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    for f in range(cfg["F"]):
+        idx = B.sample_indices(N, cfg["s"])
+        eng.ingest(d_depth[f:f + 1], d_rgb[f:f + 1], d_tok[f:f + 1], chain.pc_transform(poses[f])[None],
+                   torch.from_numpy(idx).cuda(), np.array([0, len(idx)]))
+    acc, cnt = eng.export_dense()
+    pos = eng.export_rgb()[0]
+    assert np.array_equal(pos, z["grid_rgb_pos"])
+    vid_of = {tuple(p): i for i, p in enumerate(pos.tolist())}
+    flat = tokens.reshape(-1, cfg["D"])
+    cache_size, checked, start = int(cfg.get("cache_size", 10)), 0, 0
+    for p, c in zip(z["store_pos"].tolist(), z["store_cnt"].tolist()):
+        rows = flat[z["store_src"][start:start + c]]
+        start += c
+        if c >= cache_size or tuple(p) not in vid_of or not rows[:, 1:].any():      # full voxels and the grid_0_0_0 quirk group
+            continue
+        v = vid_of[tuple(p)]
+        assert cnt[v] == c
+        if mode == "max":
+            assert np.array_equal(acc[v], rows.max(axis=0))
+        else:
+            np.testing.assert_allclose(acc[v] / c, rows.astype(np.float64).mean(axis=0), rtol=1e-3, atol=1e-3)
+        checked += 1
+    assert checked > 0.5 * len(pos)
+    eng.close()
+
+
 @pytest.mark.parametrize("mode,omode", [("mean", 1), ("max", 2)])
 @pytest.mark.parametrize("name", ["g2_mini_s1", "g2_c1_s50_iid"])
 def test_dense_modes_match_oracle(torch_cuda, name, mode, omode):
