@@ -420,7 +420,11 @@ def main():
         t0 = time.perf_counter()
         p.run(a.warmup, n_steps)
         if world > 1:
+            p.eng.sync(); torch.cuda.synchronize()
+            tm = time.perf_counter()
             merge_info = bdist.merge_dense_maps(p.eng)
+            torch.cuda.synchronize()
+            merge_info["seconds_inside_timed_region"] = time.perf_counter() - tm
         p.eng.sync()                      # incl. the rgb chain of the last step, which the library launches lazily
         barrier()
         dt = time.perf_counter() - t0

@@ -184,30 +184,49 @@ def merge_dense_maps(engine, group=None):
     `engine` needs: mode, device, keys_tensor(), dense_gather(keys), dense_gather_rgb(keys), export_heightmap(),
     import_heightmap(h, cv), dense_replace(keys, acc, cnt, rgb, weight).  Returns dict(n_union, per_rank, n_local)."""
     rank, world = _world(group)
+    import os, time
+    timing = os.environ.get("BSC_MERGE_TIMING") is not None
+    marks = []
+
+    def mark(name):
+        if timing:
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+
+    mark("start")
     keys = engine.keys_tensor()
+    mark("keys")
     codes = pack_keys(keys) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=keys.device)
     union, n_union, per = global_id_order(codes, group)
+    mark("global_id_order")
     if world == 1:
         return dict(n_union=n_union, per_rank=n_union, n_local=n_union)
     ukeys = unpack_keys(union)
     acc, cnt = engine.dense_gather(ukeys)
     rgb, wgt = engine.dense_gather_rgb(ukeys)
+    mark("gather_rows")
     op = dist.ReduceOp.MAX if engine.mode == "max" else dist.ReduceOp.SUM
     my_acc = reduce_scatter_rows(acc, op, per, group)
     my_cnt = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, per, group)
+    mark("reduce_scatter")
     # colour state: 7 bytes per voxel and rank; every rank gathers the union and merges its own slice
     lo, hi = rank * per, (rank + 1) * per
     all_rgb = torch.stack(_all_gather(rgb, group))[:, lo:hi]
     all_w = torch.stack(_all_gather(wgt, group))[:, lo:hi]
     all_present = torch.stack(_all_gather(cnt, group))[:, lo:hi] > 0
     my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
+    mark("colour")
     # top-down map: gs^2 cells, replicated
     mh, cv = engine.export_heightmap()
     top, colour = merge_heightmaps(_all_gather_np(mh, engine.device, group), _all_gather_np(cv, engine.device, group))
+    mark("heightmap")
     n_local = int((union[lo:hi] < _SENTINEL).sum().item())
     engine.dense_replace(ukeys[lo:lo + n_local].contiguous(), my_acc[:n_local].contiguous(), my_cnt[:n_local].contiguous(),
                          my_rgb[:n_local].contiguous(), my_w[:n_local].contiguous())
     engine.import_heightmap(top, colour)
+    mark("replace")
+    if timing and rank == 0:
+        print("[merge] " + " ".join(f"{n}={1e3 * (t - marks[i][1]):.1f}ms" for i, (n, t) in enumerate(marks[1:])), flush=True)
     return dict(n_union=n_union, per_rank=per, n_local=n_local)
 
 
