@@ -477,7 +477,10 @@ def main():
         out["roofline_kernels"] = {"note": "bsc_ingest running alone (no encoder beside it, a synchronize per call); own algorithmic bytes per stage",
                                    **stage_rooflines(p, iso, tok_bytes)}
         enc_tf = p.vit.flops_per_frame() * a.batch / (iso["encoder_ms"] * 1e-3) / 1e12
-        out["stages"] = {"encoder_ms_per_step": iso["encoder_ms"], "ingest_ms_per_step": iso["ingest_wall_ms"],
+        out["stages"] = {"note": "each stage alone: encoder; bsc_ingest main stream (HIP events); its rgb chain on the side stream; "
+                                 "wall time of a call followed by bsc_sync (main stream, then the chain)",
+                         "encoder_ms_per_step": iso["encoder_ms"], "ingest_ms_per_step": iso["stages"]["bsc_ingest"],
+                         "ingest_plus_chain_wall_ms_per_step": iso["ingest_wall_ms"],
                          "chain_ms_per_step_side_stream": iso["stages"]["k_chain"],
                          "encoder_tflops": enc_tf, "encoder_frac_of_bf16_mfma_peak": enc_tf / MFMA_BF16_PEAK_TF,
                          "voxels": c1["max_id"]}

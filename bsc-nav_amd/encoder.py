@@ -312,21 +312,30 @@ class RandomViT(nn.Module):
             float(ln.eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return xout, y
 
+    def can_fuse_preprocess(self, rgb):
+        return self.fused and rgb.is_cuda and self.compute_dtype == torch.bfloat16 and rgb.is_contiguous()
+
+    @torch.no_grad()
+    def preprocess_patches(self, rgb, out=None):
+        """u8 frames (B,H,W,C) -> normalised, unfolded bf16 patch matrix (B, g*g, 3*p*p) in one pass
+        (bsc_enc_preprocess_patches: /255, antialiased bilinear resize, ImageNet normalise, unfold)."""
+        from . import _lib
+        B, H, W, Cc = rgb.shape
+        g, p = self.grid, self.patch
+        patches = out if out is not None else torch.empty((B, g * g, 3 * p * p), dtype=torch.bfloat16, device=rgb.device)
+        mean = (C.c_float * 3)(*IMAGENET_MEAN)
+        std = (C.c_float * 3)(*IMAGENET_STD)
+        _lib.check(_lib.load().bsc_enc_preprocess_patches(
+            C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mean, std,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return patches
+
     @torch.no_grad()
     def patch_tokens(self, rgb, keep_dtype=False):
         """rgb (B,H,W,C) u8 on the device -> (B, g, g, D) contiguous: fp32 like the reference's _get_patch_token, or
         (keep_dtype) the encoder's own bf16, which bsc_ingest_typed widens exactly on load."""
-        if self.fused and rgb.is_cuda and self.compute_dtype == torch.bfloat16 and rgb.is_contiguous():
-            from . import _lib
-            B, H, W, Cc = rgb.shape
-            g, p = self.grid, self.patch
-            patches = torch.empty((B, g * g, 3 * p * p), dtype=torch.bfloat16, device=rgb.device)
-            mean = (C.c_float * 3)(*IMAGENET_MEAN)
-            std = (C.c_float * 3)(*IMAGENET_STD)
-            _lib.check(_lib.load().bsc_enc_preprocess_patches(
-                C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mean, std,
-                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            t = self._forward_patches(patches, keep_dtype)["x_norm_patchtokens"]
+        if self.can_fuse_preprocess(rgb):
+            t = self._forward_patches(self.preprocess_patches(rgb), keep_dtype)["x_norm_patchtokens"]
         else:
             t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
         return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()
@@ -340,22 +349,37 @@ class RandomViT(nn.Module):
 
 
 class GraphedEncoder:
-    """Replays the encoder for a fixed batch shape from a captured HIP graph (launch-bound at small batch)."""
+    """Replays the encoder for a fixed batch shape from a captured HIP graph (launch-bound at small batch).  The graph starts
+    at the patch matrix: the fused preprocessing kernel runs eagerly on the caller's frames and writes the graph's input, so
+    the frames themselves are never copied."""
 
     def __init__(self, vit, batch, H, W, channels=4, keep_dtype=False):
-        self.vit = vit
-        self.static_in = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
+        self.vit, self.keep_dtype = vit, keep_dtype
+        probe = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
+        self.from_patches = vit.can_fuse_preprocess(probe)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        if self.from_patches:
+            self.static_in = vit.preprocess_patches(probe)
+            run = lambda: vit._forward_patches(self.static_in, keep_dtype)["x_norm_patchtokens"].reshape(
+                batch, vit.grid, vit.grid, -1)
+        else:
+            self.static_in = probe
+            run = lambda: vit.patch_tokens(self.static_in, keep_dtype)
         with torch.cuda.stream(s):
             for _ in range(2):
-                vit.patch_tokens(self.static_in, keep_dtype)
+                run()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = vit.patch_tokens(self.static_in, keep_dtype)
+            self.static_out = run()
 
     def __call__(self, rgb):
-        self.static_in.copy_(rgb)
+        if self.from_patches and self.vit.can_fuse_preprocess(rgb):
+            self.vit.preprocess_patches(rgb, out=self.static_in)
+        elif self.from_patches:
+            self.vit.preprocess_patches(rgb.contiguous(), out=self.static_in)
+        else:
+            self.static_in.copy_(rgb)
         self.graph.replay()
         return self.static_out
