@@ -356,7 +356,7 @@ class GraphedEncoder:
     def __init__(self, vit, batch, H, W, channels=4, keep_dtype=False):
         self.vit, self.keep_dtype = vit, keep_dtype
         probe = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
-        self.from_patches = vit.can_fuse_preprocess(probe)
+        self.from_patches = vit.can_fuse_preprocess(probe) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         if self.from_patches:
