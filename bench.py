@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--tokens", choices=["bf16", "f32"], default="bf16",
                     help="dtype the encoder hands to bsc_ingest: its native bf16 (bsc_ingest_typed widens it exactly on "
                          "load) or f32 like the reference's _get_patch_token")
-    ap.add_argument("--kind", default="room", choices=["room", "hall", "iid"])
+    ap.add_argument("--kind", default="room", choices=["room", "hall", "iid", "room_off"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")
     ap.add_argument("--height", type=int, default=480)
@@ -495,7 +495,7 @@ def main():
         if not a.no_workloads:
             out["workloads"] = {"room": {"frames_per_s": out["value"], "voxels": out["stages"]["voxels"], "U_over_P": out["roofline"]["U_over_P"],
                                          "ingest_ms_per_step": out["roofline"]["ms_per_call"], "frac_of_hbm_bound": out["roofline"]["frac"]}}
-            for kind, steps in (("hall", 8), ("iid", 4)):
+            for kind, steps in (("hall", 8), ("iid", 4), ("room_off", 8)):
                 q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
                 q.run(0, 2)
                 torch.cuda.synchronize()

@@ -234,7 +234,8 @@ __global__ void k_totals(int64_t P, int64_t nblk, const int32_t *blk_runs, const
     bscal[2] = 0;                       // points in the per-voxel order
     bscal[3] = 0;                       // segment queue of the rgb chain (quads: short segments)
     bscal[4] = 0;                       // long segments (k_seg_order): the first bscal[4] of the length-ordered list
-    bscal[5] = 0;                       // segment queue of the wavefront-per-segment chain
+    bscal[5] = 0;                       // (unused)
+    bscal[6] = 0;                       // hot segments (k_seg_order): the first bscal[6] of the long ones, a workgroup each
 }
 
 // ---- ids of the new voxels ---------------------------------------------------------------------------------------
@@ -403,6 +404,7 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
 
 #define LONG_MIN_LOG2 6                          // segments of >= 64 points
 #define LONG_EARLY 512                           // points of a new voxel that the quad chain steps first
+#define HOT_MIN_LOG2 14                          // segments of >= 16384 points are split over the wavefronts of a workgroup
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
 #define CHAIN_WAVES 512
 __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
 // is the sequential one by construction.  A voxel that collects 2e5 points in a call takes ~3000 rounds of ~100
 // instructions instead of 2e5 dependent steps of ~28 (6 ms -> 0.5 ms), and the loads of a round are 64 independent
 // gathers instead of 4.
-#define LONG_WG 256
+#define LONG_WG 512
 #define LONG_WAVES 16384
 __device__ __forceinline__ float wave_incl_sum_f32(float x)
 {
@@ -573,6 +575,130 @@ __device__ __forceinline__ float wave_incl_sum_f32(float x)
 
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+struct ChainState { float w; uint32_t c0, c1, c2; };
+
+// rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
+// after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
+__device__ __forceinline__ void chain_rounds(const uint32_t *__restrict__ sj, const PointRec *__restrict__ p_rec, int64_t k,
+                                             const int64_t k1, const int64_t kend, ChainState &st, const int lane)
+{
+    if (k >= k1) return;
+    float w = st.w;
+    uint32_t c0 = st.c0, c1 = st.c1, c2 = st.c2;
+    // records of round n+1 and order indices of round n+2 are in flight while round n is worked on
+    const int64_t klast = kend - 1;
+    uint32_t j_nxt;
+    PointRec rec, rec_nxt;
+    {
+        const int64_t ka = k + lane, kb = k + 64 + lane;
+        rec = p_rec[sj[ka < kend ? ka : klast]];
+        j_nxt = sj[kb < kend ? kb : klast];
+    }
+    for (; k < k1; k += 64) {
+        rec_nxt = p_rec[j_nxt];
+        {
+            const int64_t kc = k + 128 + lane;
+            j_nxt = sj[kc < kend ? kc : klast];
+        }
+        const bool valid = k + lane < k1;
+        const double a = valid ? __hiloint2double((int)rec.ahi, (int)rec.alo) : 0.0;      // alpha 0 leaves w as it is
+        // ---- weights: predict, check with the recurrence, redo from the first lane that fails ----------------------------
+        float wbase = w, wp = w, wn;
+        int start = 0;
+        for (;;) {
+            const float inc = lane >= start ? (float)((double)wbase + a) - wbase : 0.f;
+            const float incl = wave_incl_sum_f32(inc);
+            if (lane >= start) wp = wbase + (incl - inc);
+            wn = (float)((double)wp + a);                                  // :896,:899 the weight this point leaves
+            const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wn), 0x138, 0xf, 0xf, false));   // wave_shr:1
+            const u64 bad = __ballot(lane > start && left != wp);
+            if (!bad) break;
+            start = __ffsll((unsigned long long)bad) - 1;
+            wbase = readlane_f32(wn, start - 1);
+        }
+        w = readlane_f32(wn, 63);
+        const double den = (double)wp + a;
+        double rd = __builtin_amdgcn_rcp(den);
+        double e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
+        e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
+        // ---- colours: every lane steps from the round's entry colour; the first lane that disagrees sets the new one -------
+        const u64 vmask = __ballot(valid);
+#define BSC_LONG_CHANNEL(cc, shift)                                                                     \
+        {                                                                                               \
+            const double ra = (double)((rec.rgbv >> shift) & 0xffu) * a;                                \
+            u64 pend = vmask;                                                                           \
+            for (;;) {                                                                                  \
+                const double num = (double)((float)cc * wp) + ra;                                       \
+                const double q0 = num * rd;                                                             \
+                const double rr = fma(-den, q0, num);                                                   \
+                const uint32_t t = (uint32_t)fma(rr, rd, q0);                                           \
+                const u64 diff = __ballot(t != cc) & pend;                                              \
+                if (!diff) break;                                                                       \
+                const int f = __ffsll((unsigned long long)diff) - 1;                                    \
+                cc = (uint32_t)__builtin_amdgcn_readlane((int)t, f);                                    \
+                pend &= ~((2ull << f) - 1ull);                                                          \
+            }                                                                                           \
+        }
+        BSC_LONG_CHANNEL(c0, 0)
+        BSC_LONG_CHANNEL(c1, 8)
+        BSC_LONG_CHANNEL(c2, 16)
+#undef BSC_LONG_CHANNEL
+        rec = rec_nxt;
+    }
+    st.w = w; st.c0 = c0; st.c1 = c1; st.c2 = c2;
+}
+
+// sum over the positions [k, k1) of what each point would add to a weight of wbase's binade: f32(f64(wbase) + alpha) - wbase
+// (whole ulps, so the float sums are exact while the weight stays in the binade).  Wave-uniform result.
+__device__ __forceinline__ float chain_inc_sum(const uint32_t *__restrict__ sj, const PointRec *__restrict__ p_rec, int64_t k,
+                                               const int64_t k1, const float wbase, const int lane)
+{
+    constexpr int UN = 16;                      // 1024 points per step: 16 gathers in flight, the next step's indices behind them
+    float acc = 0.f;
+    if (k >= k1) return acc;
+    const double wb = (double)wbase;
+    const int64_t klast = k1 - 1;
+    uint32_t j[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { const int64_t kk = k + 64 * u + lane; j[u] = sj[kk < k1 ? kk : klast]; }
+    for (; k < k1; k += 64 * UN) {
+        uint32_t alo[UN], ahi[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const PointRec r = p_rec[j[u]]; alo[u] = r.alo; ahi[u] = r.ahi; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int64_t kk = k + 64 * (UN + u) + lane; j[u] = sj[kk < k1 ? kk : klast]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool valid = k + 64 * u + lane < k1;
+            const double a = __hiloint2double((int)ahi[u], (int)alo[u]);
+            acc += valid ? (float)(wb + a) - wbase : 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return readlane_f32(acc, 0);
+}
+
+__device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_t vid, const int32_t s, const int64_t klast,
+                                             const uint32_t *__restrict__ sj, const int32_t *__restrict__ rgb_pos,
+                                             uint8_t *__restrict__ rgb, float *__restrict__ weight, u64 *hmap,
+                                             int32_t *__restrict__ seg_last, int gs, int64_t order_base)
+{
+    rgb[3 * (int64_t)vid] = (uint8_t)st.c0; rgb[3 * (int64_t)vid + 1] = (uint8_t)st.c1; rgb[3 * (int64_t)vid + 2] = (uint8_t)st.c2;
+    weight[vid] = st.w;
+    const uint32_t lj = sj[klast];                      // order indices grow along a segment
+    const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
+    atomicMax(&hmap[(int64_t)row * gs + col], ((u64)(h + 1) << 40) | (u64)(order_base + lj));
+    seg_last[s] = (int32_t)lj;
+}
+
+// Hot segments (>= 2^HOT_MIN_LOG2 points: the first bscal[6] of the length-ordered list) are split over the wavefronts of a
+// workgroup, again by prediction and check: (A) every wavefront sums what its chunk would add to the weight — whole ulps
+// that do not depend on the weight inside a binade — so every chunk's entry weight is known after one cheap pass; (B) every
+// wavefront runs its chunk's rounds from that entry weight and the segment's entry colour (a heavy voxel's colour has long
+// settled); (C) chunk k+1's assumed entry must equal chunk k's exit: the first chunk that fails is run again from the true
+// state, and so on down the line.  A binade crossing or a colour change inside the segment costs the rest of it a second
+// run; otherwise a segment of n points takes n / (64 * wavefronts) rounds.
 __global__ __launch_bounds__(LONG_WG) void k_chain_long(const uint32_t *__restrict__ sj, int64_t *bscal,
                                                         const int4 *__restrict__ seg_info,
                                                         const PointRec *__restrict__ p_rec,
@@ -580,17 +706,63 @@ __global__ __launch_bounds__(LONG_WG) void k_chain_long(const uint32_t *__restri
                                                         float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                                         int gs, int64_t order_base)
 {
+    constexpr int NWV = LONG_WG / 64;
+    __shared__ float s_sum[NWV];
+    __shared__ ChainState s_entry[NWV], s_exit[NWV];
     const int lane = threadIdx.x & 63;
-    const int64_t nlong = bscal[4];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nlong = bscal[4], nhot = bscal[6];
     const int64_t max_id_prev = bscal[1];
-    // static schedule over the length-ordered list, back and forth (wave g takes g, 2n-1-g, 2n+g, ...): no queue — an
-    // `if (lane == 0) atomicAdd` at the head of a loop that ends in another `if (lane == 0)` block gets jump-threaded
-    // around the readfirstlane between them, and the wavefront then never leaves the loop
-    const int64_t nwaves = (int64_t)gridDim.x * (LONG_WG / 64);
-    const int64_t wave = (int64_t)blockIdx.x * (LONG_WG / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // ---- hot segments: one workgroup each ---------------------------------------------------------------------------------
+    for (int64_t turn = blockIdx.x; turn < nhot; turn += gridDim.x) {
+        const int32_t s = seg_info[turn].w;
+        const int4 info = seg_info[s];
+        int64_t k = info.x;
+        const int64_t k1 = info.y;
+        const uint32_t vid = (uint32_t)info.z;
+        if ((int64_t)vid >= max_id_prev) k += LONG_EARLY;
+        ChainState st;
+        st.w = readlane_f32(weight[vid], 0);
+        st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
+        st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
+        st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
+        const int64_t chunk = (((k1 - k) + NWV - 1) / NWV + 63) & ~63ll;
+        const int64_t ka = k + wv * chunk < k1 ? k + wv * chunk : k1, kb = ka + chunk < k1 ? ka + chunk : k1;
+        // chunks < first are final; `st` is the true state at the start of chunk `first`
+        for (int first = 0;;) {
+            const float mine = wv >= first ? chain_inc_sum(sj, p_rec, ka, kb, st.w, lane) : 0.f;
+            __syncthreads();                                // the shared arrays are free (previous pass / previous segment)
+            if (lane == 0) s_sum[wv] = mine;
+            __syncthreads();
+            if (wv >= first) {
+                ChainState me = st;
+                for (int i = first; i < wv; ++i) me.w += s_sum[i];
+                if (lane == 0) s_entry[wv] = me;
+                chain_rounds(sj, p_rec, ka, kb, k1, me, lane);
+                if (lane == 0) s_exit[wv] = me;
+            }
+            __syncthreads();
+            int bad = NWV;
+            for (int c = NWV - 1; c > first; --c) {
+                const ChainState have = s_entry[c], real = s_exit[c - 1];
+                if (!(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2)) bad = c;
+            }
+            if (bad == NWV) break;
+            st = s_exit[bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
+            first = bad;
+        }
+        if (threadIdx.x == 0) chain_finish(s_exit[NWV - 1], vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
+    }
+    // ---- the other long segments: one wavefront each, static schedule over the length-ordered list, back and forth (wave g
+    // takes g, 2n-1-g, 2n+g, ...): no queue — an `if (lane == 0) atomicAdd` at the head of a loop that ends in another
+    // `if (lane == 0)` block gets jump-threaded around the readfirstlane between them, and the wavefront then never leaves
+    // the loop
+    const int64_t nwaves = (int64_t)gridDim.x * NWV;
+    const int64_t wave = (int64_t)blockIdx.x * NWV + wv;
+    const int64_t nrest = nlong - nhot;
     for (int64_t pass = 0;; ++pass) {
-        const int64_t turn = pass * nwaves + ((pass & 1) ? nwaves - 1 - wave : wave);
-        if (pass * nwaves >= nlong) break;
+        const int64_t turn = nhot + pass * nwaves + ((pass & 1) ? nwaves - 1 - wave : wave);
+        if (pass * nwaves >= nrest) break;
         if (turn >= nlong) continue;
         const int32_t s = seg_info[turn].w;
         const int4 info = seg_info[s];
@@ -601,79 +773,13 @@ __global__ __launch_bounds__(LONG_WG) void k_chain_long(const uint32_t *__restri
         // on the same stream): its state is in the arrays like that of an old voxel
         if ((int64_t)vid >= max_id_prev) k += LONG_EARLY;
         if (k >= k1) continue;
-        float w = weight[vid];
-        uint32_t c0 = rgb[3 * (int64_t)vid], c1 = rgb[3 * (int64_t)vid + 1], c2 = rgb[3 * (int64_t)vid + 2];
-        w = readlane_f32(w, 0);
-        c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0); c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
-        c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c2);
-        // records of round n+1 and order indices of round n+2 are in flight while round n is worked on
-        const int64_t klast = k1 - 1;
-        uint32_t j_nxt;
-        PointRec rec, rec_nxt;
-        {
-            const int64_t ka = k + lane, kb = k + 64 + lane;
-            rec = p_rec[sj[ka < k1 ? ka : klast]];
-            j_nxt = sj[kb < k1 ? kb : klast];
-        }
-        for (; k < k1; k += 64) {
-            rec_nxt = p_rec[j_nxt];
-            {
-                const int64_t kc = k + 128 + lane;
-                j_nxt = sj[kc < k1 ? kc : klast];
-            }
-            const bool valid = k + lane < k1;
-            const double a = valid ? __hiloint2double((int)rec.ahi, (int)rec.alo) : 0.0;      // alpha 0 leaves w as it is
-            // ---- weights: predict, check with the recurrence, redo from the first lane that fails ------------------------
-            float wbase = w, wp = w, wn;
-            int start = 0;
-            for (;;) {
-                const float inc = lane >= start ? (float)((double)wbase + a) - wbase : 0.f;
-                const float incl = wave_incl_sum_f32(inc);
-                if (lane >= start) wp = wbase + (incl - inc);
-                wn = (float)((double)wp + a);                                  // :896,:899 the weight this point leaves
-                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wn), 0x138, 0xf, 0xf, false));   // wave_shr:1
-                const u64 bad = __ballot(lane > start && left != wp);
-                if (!bad) break;
-                start = __ffsll((unsigned long long)bad) - 1;
-                wbase = readlane_f32(wn, start - 1);
-            }
-            w = readlane_f32(wn, 63);
-            const double den = (double)wp + a;
-            double rd = __builtin_amdgcn_rcp(den);
-            double e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
-            e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
-            // ---- colours: every lane steps from the round's entry colour; the first lane that disagrees sets the new one ---
-            const u64 vmask = __ballot(valid);
-#define BSC_LONG_CHANNEL(cc, shift)                                                                     \
-            {                                                                                           \
-                const double ra = (double)((rec.rgbv >> shift) & 0xffu) * a;                            \
-                u64 pend = vmask;                                                                       \
-                for (;;) {                                                                              \
-                    const double num = (double)((float)cc * wp) + ra;                                   \
-                    const double q0 = num * rd;                                                         \
-                    const double rr = fma(-den, q0, num);                                               \
-                    const uint32_t t = (uint32_t)fma(rr, rd, q0);                                       \
-                    const u64 diff = __ballot(t != cc) & pend;                                          \
-                    if (!diff) break;                                                                   \
-                    const int f = __ffsll((unsigned long long)diff) - 1;                                \
-                    cc = (uint32_t)__builtin_amdgcn_readlane((int)t, f);                                \
-                    pend &= ~((2ull << f) - 1ull);                                                      \
-                }                                                                                       \
-            }
-            BSC_LONG_CHANNEL(c0, 0)
-            BSC_LONG_CHANNEL(c1, 8)
-            BSC_LONG_CHANNEL(c2, 16)
-#undef BSC_LONG_CHANNEL
-            rec = rec_nxt;
-        }
-        if (lane == 0) {
-            rgb[3 * (int64_t)vid] = (uint8_t)c0; rgb[3 * (int64_t)vid + 1] = (uint8_t)c1; rgb[3 * (int64_t)vid + 2] = (uint8_t)c2;
-            weight[vid] = w;
-            const uint32_t lj = sj[klast];                      // order indices grow along a segment
-            const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
-            atomicMax(&hmap[(int64_t)row * gs + col], ((u64)(h + 1) << 40) | (u64)(order_base + lj));
-            seg_last[s] = (int32_t)lj;
-        }
+        ChainState st;
+        st.w = readlane_f32(weight[vid], 0);
+        st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
+        st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
+        st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
+        chain_rounds(sj, p_rec, k, k1, k1, st, lane);
+        if (lane == 0) chain_finish(st, vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
 }
 
@@ -797,7 +903,8 @@ __global__ __launch_bounds__(TPB) void k_seg_bounds(const int64_t *bscal, int64_
 
 __global__ __launch_bounds__(TPB) void k_seg_order(int64_t *bscal, const uint32_t *__restrict__ okey_sorted,
                                                    const uint32_t *__restrict__ oval_sorted, int4 *__restrict__ seg_info,
-                                                   int long_chain)   // log2 of the shortest long segment, 0 = none
+                                                   int long_chain,   // log2 of the shortest long segment, 0 = none
+                                                   int hot_chain)
 {
     const int64_t nseg = bscal[0];
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * TPB) {
@@ -805,6 +912,9 @@ __global__ __launch_bounds__(TPB) void k_seg_order(int64_t *bscal, const uint32_
         // key = clz(length): the segments of >= 2^LONG_MIN_LOG2 points come first
         const bool is_long = okey_sorted[i] <= 31u - long_chain;
         if (long_chain && is_long && (i + 1 == nseg || okey_sorted[i + 1] > 31u - long_chain)) bscal[4] = i + 1;
+        // ... and those of >= 2^HOT_MIN_LOG2 points before them
+        const bool is_hot = okey_sorted[i] <= 31u - HOT_MIN_LOG2;
+        if (long_chain && hot_chain && is_hot && (i + 1 == nseg || okey_sorted[i + 1] > 31u - HOT_MIN_LOG2)) bscal[6] = i + 1;
     }
 }
 
@@ -1024,7 +1134,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
     static const int long_log2 = getenv("BSC_LONG_LOG2") ? atoi(getenv("BSC_LONG_LOG2")) : LONG_MIN_LOG2;
     hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,
-                       x->seg_info_s[set], x->long_chain ? long_log2 : 0);
+                       x->seg_info_s[set], x->long_chain ? long_log2 : 0, getenv("BSC_NO_HOT_SPLIT") ? 0 : 1);
     stat_end(x, BSC_STAT_ORDER, 0.0);
     // rgb chain + top-down map: sequential-latency bound, on the library's side stream — and DEFERRED: the
     // call only marks its point order ready; the kernels are launched at the start of the next bsc_ingest (or by whatever

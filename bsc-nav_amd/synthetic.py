@@ -6,7 +6,10 @@ rgb (F,H,W,4) u8 RGBA, depth (F,H,W) f32 z-depth, poses (F,7) [px,py,pz,qx,qy,qz
 (0.25 m steps, 30 degree turns, args.py:33-35); `hall`: a 24 x 3 x 24 m hall with 36 square pillars (1 m, on a 4 m
 lattice), the camera on a forward-biased walk that covers the whole floor — a scene of 10^5..10^6 surface voxels of
 0.1 m, the size SURVEY.md §7 gives for real scans; `iid`: U(0.5, 5) m per pixel (worst case, one voxel
-per point).  About 2 % of the pixels are pushed outside (min_depth, max_depth).
+per point).  About 2 % of the pixels are pushed outside (min_depth, max_depth).  The walls, floor and ceiling of `room`
+and `hall` lie exactly on boundaries of the 0.1 m voxel grid, so the +-1 cm depth noise flips every surface point between
+two cells — the worst case for everything that works on runs of same-cell points; `room_off` is the same room moved by
+3.7 cm along every axis (surfaces inside their cells), for comparison.
 """
 import numpy as np
 import torch
@@ -46,6 +49,9 @@ def hall_walk_poses(seed, n_frames):
     return poses
 
 
+ROOM_OFF = 0.037
+
+
 def make_poses(kind, seed, n_frames):
     return hall_walk_poses(seed, n_frames) if kind == "hall" else random_walk_poses(seed, n_frames)
 
@@ -81,7 +87,7 @@ def make_frames(seed, n_frames, H, W, kind="room", device="cuda", invalid_frac=0
     rgb = torch.randint(0, 255, (n_frames, H, W, 4), dtype=torch.uint8, device=device, generator=gen)
     if kind == "iid":
         depth = torch.rand((n_frames, H, W), device=device, generator=gen) * 4.5 + 0.5
-    elif kind in ("room", "hall"):
+    elif kind in ("room", "hall", "room_off"):
         fx = W / 2.0
         u = (torch.arange(W, device=device, dtype=torch.float32) + 0.5 - W / 2.0) / fx
         v = (torch.arange(H, device=device, dtype=torch.float32) + 0.5 - H / 2.0) / fx
@@ -94,8 +100,8 @@ def make_frames(seed, n_frames, H, W, kind="room", device="cuda", invalid_frac=0
         rot = torch.stack([torch.stack([c, z, s], -1), torch.stack([z, o, z], -1), torch.stack([-s, z, c], -1)], -2)
         d = torch.einsum("hwk,fjk->fhwj", d_local, rot)                            # (F,H,W,3)
         org = p[:, None, None, :3]
-        lo = torch.tensor(ROOM_LO if kind == "room" else HALL_LO, device=device)
-        hi = torch.tensor(ROOM_HI if kind == "room" else HALL_HI, device=device)
+        lo = torch.tensor(HALL_LO if kind == "hall" else ROOM_LO, device=device) + (ROOM_OFF if kind == "room_off" else 0.0)
+        hi = torch.tensor(HALL_HI if kind == "hall" else ROOM_HI, device=device) + (ROOM_OFF if kind == "room_off" else 0.0)
         t = torch.where(d > 0, (hi - org) / d, (lo - org) / d)
         t = torch.where(torch.isfinite(t), t, torch.full_like(t, float("inf")))
         t = t.min(dim=-1).values
