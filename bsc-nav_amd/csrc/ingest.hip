@@ -404,7 +404,7 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
 
 #define LONG_MIN_LOG2 6                          // segments of >= 64 points
 #define LONG_EARLY 512                           // points of a new voxel that the quad chain steps first
-#define HOT_MIN_LOG2 14                          // segments of >= 16384 points are split over the wavefronts of a workgroup
+#define HOT_MIN_LOG2 16                          // segments of >= 65536 points are split over the wavefronts of a workgroup
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
 #define CHAIN_WAVES 512
 __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(TPB) void k_seg_bounds(const int64_t *bscal, int64_
 __global__ __launch_bounds__(TPB) void k_seg_order(int64_t *bscal, const uint32_t *__restrict__ okey_sorted,
                                                    const uint32_t *__restrict__ oval_sorted, int4 *__restrict__ seg_info,
                                                    int long_chain,   // log2 of the shortest long segment, 0 = none
-                                                   int hot_chain)
+                                                   int hot_chain)    // log2 of the shortest hot segment, 0 = none
 {
     const int64_t nseg = bscal[0];
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * TPB) {
@@ -913,8 +913,8 @@ __global__ __launch_bounds__(TPB) void k_seg_order(int64_t *bscal, const uint32_
         const bool is_long = okey_sorted[i] <= 31u - long_chain;
         if (long_chain && is_long && (i + 1 == nseg || okey_sorted[i + 1] > 31u - long_chain)) bscal[4] = i + 1;
         // ... and those of >= 2^HOT_MIN_LOG2 points before them
-        const bool is_hot = okey_sorted[i] <= 31u - HOT_MIN_LOG2;
-        if (long_chain && hot_chain && is_hot && (i + 1 == nseg || okey_sorted[i + 1] > 31u - HOT_MIN_LOG2)) bscal[6] = i + 1;
+        const bool is_hot = hot_chain && okey_sorted[i] <= 31u - hot_chain;
+        if (long_chain && is_hot && (i + 1 == nseg || okey_sorted[i + 1] > 31u - hot_chain)) bscal[6] = i + 1;
     }
 }
 
@@ -1133,8 +1133,9 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (n_bound > 0)
         BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
     static const int long_log2 = getenv("BSC_LONG_LOG2") ? atoi(getenv("BSC_LONG_LOG2")) : LONG_MIN_LOG2;
+    static const int hot_log2 = getenv("BSC_NO_HOT_SPLIT") ? 0 : (getenv("BSC_HOT_LOG2") ? atoi(getenv("BSC_HOT_LOG2")) : HOT_MIN_LOG2);
     hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,
-                       x->seg_info_s[set], x->long_chain ? long_log2 : 0, getenv("BSC_NO_HOT_SPLIT") ? 0 : 1);
+                       x->seg_info_s[set], x->long_chain ? long_log2 : 0, hot_log2);
     stat_end(x, BSC_STAT_ORDER, 0.0);
     // rgb chain + top-down map: sequential-latency bound, on the library's side stream — and DEFERRED: the
     // call only marks its point order ready; the kernels are launched at the start of the next bsc_ingest (or by whatever
