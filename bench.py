@@ -60,10 +60,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=384, help="frames per step (per rank); 8 steps x 384 = 3072 frames")
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K timed steps; the median is reported")
-    ap.add_argument("--tokens", choices=["bf16", "f32"], default="f32",
-                    help="dtype the encoder hands to bsc_ingest: f32 like the reference's _get_patch_token (the bf16 results "
-                         "widened by the encoder's last kernel; measured faster: the reduce issues one 16-byte load per lane "
-                         "and 4 columns, scripts/ab_tokens.sh), or its native bf16 (bsc_ingest_typed widens it on load)")
+    ap.add_argument("--tokens", choices=["bf16", "f32"], default="bf16",
+                    help="dtype the encoder hands to bsc_ingest: its native bf16 (bsc_ingest_typed; the reduce widens and "
+                         "accumulates a row element with one v_dot2c_f32_bf16) or f32 like the reference's _get_patch_token "
+                         "(the bf16 results widened by the encoder's last kernel); scripts/ab_tokens.sh")
     ap.add_argument("--kind", default="room", choices=["room", "hall", "iid", "room_off"])
     ap.add_argument("--mode", default="mean", choices=["mean", "max"])
     ap.add_argument("--arch", default="vit_b16")

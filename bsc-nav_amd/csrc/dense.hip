@@ -20,6 +20,8 @@
 // Algorithmic HBM bytes of k_dense_reduce per call: (2U - U_new) * D*4 + 8U + F*g^2*D*4 + 12 * n_pairs.
 #include "bsc_internal.h"
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
 #include <math.h>
 
 #define TPB 256
@@ -562,6 +564,44 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
             const int n = __popcll(__ballot(in));
             const uint32_t row_l = (uint32_t)(rec >> 32), cnt_l = (uint32_t)rec & 0xffffffu;
             for (int j = 0; j < n; j += 4) {
+                if constexpr (sizeof(TOK) == 2 && MODE != BSC_MODE_MAX) {
+                    // bf16 rows, sum: v_dot2c_f32_bf16 with (m, 0) / (0, m) as the second operand adds m x one element of the
+                    // pair to the f32 accumulator — widening and multiply-add in one instruction (the row loads are 8 bytes
+                    // per lane; a separate shift / mask per element made this path slower than f32 rows).  m is exact in bf16
+                    // up to 256; a larger multiplicity (a pair holds at most a tile's ~3300 points) goes byte by byte, each part exact.
+                    uint2 xr[4][NV];
+                    uint32_t mi[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int jj = j + q < n ? j + q : j;
+                        const TOK *row = tokens + (int64_t)__builtin_amdgcn_readlane((int)row_l, jj) * D;
+                        mi[q] = j + q < n ? (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, jj) : 0u;
+#pragma unroll
+                        for (int t = 0; t < NV; ++t) {
+                            const int v = lane + 64 * t;
+                            xr[q][t] = (v < D4) ? ((const uint2 *)row)[v] : make_uint2(0u, 0u);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // one exact bf16 factor per byte of the multiplicity (wave-uniform; one pass in the usual case)
+                        for (uint32_t rem = mi[q], sh = 0; rem; rem >>= 8, sh += 8) {
+                            const uint32_t part = (rem & 255u) << sh;
+                            if (!part) continue;
+                            const uint32_t lo = __float_as_uint((float)part) >> 16, hi = lo << 16;
+                            const bf16x2_t blo = __builtin_bit_cast(bf16x2_t, lo), bhi = __builtin_bit_cast(bf16x2_t, hi);
+#pragma unroll
+                            for (int t = 0; t < NV; ++t) {
+                                const bf16x2_t e01 = __builtin_bit_cast(bf16x2_t, xr[q][t].x), e23 = __builtin_bit_cast(bf16x2_t, xr[q][t].y);
+                                a[t].x = __builtin_amdgcn_fdot2_f32_bf16(e01, blo, a[t].x, false);
+                                a[t].y = __builtin_amdgcn_fdot2_f32_bf16(e01, bhi, a[t].y, false);
+                                a[t].z = __builtin_amdgcn_fdot2_f32_bf16(e23, blo, a[t].z, false);
+                                a[t].w = __builtin_amdgcn_fdot2_f32_bf16(e23, bhi, a[t].w, false);
+                            }
+                        }
+                    }
+                    continue;
+                }
                 float4 xv[4][NV];
                 float m[4];
 #pragma unroll
