@@ -226,6 +226,29 @@ def test_bf16_tokens_equal_widened_f32_tokens(mode):
         assert np.array_equal(a, b)
 
 
+def test_bf16_rows_with_large_multiplicities_equal_f32_rows():
+    """Dense mean with bf16 token rows where a (voxel, frame, patch) pair holds many hundreds of points (34x46-pixel patches,
+    0.5 m cells): the reduce feeds the multiplicity to v_dot2c_f32_bf16 byte by byte (exact in bf16), and the sums must be
+    those of the f32 rows (within an ulp-level tolerance: two accumulation steps instead of one above 255), counts equal."""
+    import torch
+    import bsc_nav_amd as B
+    H, W, D, g, F = 240, 320, 256, 7, 4
+    rgb, depth, poses = _frames(F, H, W, seed=8)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    tok16 = torch.randn((F, g, g, D), device="cuda").to(torch.bfloat16)
+    out = []
+    for tok in (tok16.float(), tok16):
+        eng = B.VoxelEngine(H, W, 64, 0.5, -8.0, 8.0, g, D, mode="mean", max_points=F * H * W)
+        eng.ingest(torch.as_tensor(depth).cuda(), torch.as_tensor(rgb).cuda(), tok.contiguous(), Ts)
+        out.append(eng.export_dense())
+        assert eng.counters()["pairs_last_call"] * 100 < F * H * W          # > 100 points per pair on average, whole tiles in one cell
+        eng.close()
+    (a32, c32), (a16, c16) = out
+    assert np.array_equal(c32, c16) and c32.max() > 2000      # voxels of > 2000 points out of 4 frames x a few patches: pairs far above 255
+    np.testing.assert_allclose(a16, a32, rtol=2e-6, atol=1e-4)
+
+
 def _dense_vs_oracle(H, W, g, D, gs, cs, lo, hi, F, per_call, seed, vcap, kind="room", depth_override=None,
                      alpha_override=None):
     """Dense mean mode, every pixel, host alpha: ids, positions, rgb bytes, weights, top-down map, counts bit-exact and
