@@ -496,7 +496,9 @@ def main():
         if not a.no_workloads:
             out["workloads"] = {"room": {"frames_per_s": out["value"], "voxels": out["stages"]["voxels"], "U_over_P": out["roofline"]["U_over_P"],
                                          "ingest_ms_per_step": out["roofline"]["ms_per_call"], "frac_of_hbm_bound": out["roofline"]["frac"]}}
-            for kind, steps in (("hall", 8), ("iid", 4), ("room_off", 8)):
+            # as many steps as the headline where the map keeps growing over the run (a short run is mostly start-up: every
+            # voxel new), half of them for the one-voxel-per-point stress case
+            for kind, steps in (("hall", a.steps), ("iid", max(4, a.steps // 2)), ("room_off", a.steps)):
                 q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
                 q.run(0, 2)
                 torch.cuda.synchronize()
