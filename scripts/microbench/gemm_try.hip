@@ -1,0 +1,173 @@
+// Experiment: own bf16 GEMM with fused bias + GELU epilogue for the encoder's fc1 shape (C[M,N] = act(A[M,K] W[N,K]^T + b)).
+// 256x256x64 tiles, 8 wavefronts (2 x 4, 128 x 64 per wavefront), global_load_lds_dwordx4 into two LDS buffers (swizzle on
+// the source address), raw barriers with counted vmcnt.  Build: hipcc --offload-arch=gfx950 -O3 -o gemm_try gemm_try.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define BM 256
+#define BN 256
+#define BK 64
+#define NTHR 512
+
+__device__ __forceinline__ uint16_t f2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float gelu_tanh(float x)
+{
+    // 0.5 x (1 + tanh(k (x + 0.044715 x^3))) = x * sigmoid(2 k (x + 0.044715 x^3))
+    const float u = 1.5957691216057308f * (x + 0.044715f * x * x * x);      // 2 * sqrt(2/pi)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
+}
+
+// one 16-byte chunk per lane: tile rows of 64 bf16 = 8 chunks; LDS position (r, p) holds source chunk (r, p ^ ((r >> 1) & 7))
+template <int ROWS>
+__device__ __forceinline__ void stage_tile(const uint16_t *__restrict__ src, int64_t ld, int row0, int row_max, int k0,
+                                           uint16_t *lds_tile, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NTHR; ++i) {
+        const int c = i * NTHR + tid;
+        const int r = c >> 3, p = c & 7, q = p ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < row_max ? gr : row_max - 1;
+        const uint16_t *g = src + (int64_t)gr * ld + k0 + q * 8;
+        // wave-uniform LDS base of this instruction: chunk (i * NTHR + wave * 64) ; the hardware adds lane * 16
+        uint16_t *dst = lds_tile + (int64_t)(i * NTHR + (tid & ~63)) * 8;
+        // LDS DMA outside the compiler's waitcnt bookkeeping (it would drain vmcnt to 0 before every LDS read): M0 = the
+        // wave-uniform LDS byte address, written in the same statement that uses it
+        const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(NTHR) void k_gemm(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
+                                               const uint16_t *__restrict__ bias, uint16_t *__restrict__ C, int M, int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // [2][A 256x64 | B 256x64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;                            // 2 x 4 wavefronts: 128 x 64 each
+    const int n16 = lane & 15, g = lane >> 4;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;
+    stage_tile<BM>(A, K, m0, M, 0, lds, tid);
+    stage_tile<BN>(W, K, n0, N, 0, lds + BM * BK, tid);
+    for (int ks = 0; ks < nk; ++ks) {
+        uint16_t *cur = lds + (ks & 1) * (BM + BN) * BK;
+        if (ks + 1 < nk) {
+            uint16_t *nxt = lds + ((ks + 1) & 1) * (BM + BN) * BK;
+            stage_tile<BM>(A, K, m0, M, (ks + 1) * BK, nxt, tid);
+            stage_tile<BN>(W, K, n0, N, (ks + 1) * BK, nxt + BM * BK, tid);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const uint16_t *sa = cur, *sb = cur + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[8], fb[4];
+            const int q = kk * 4 + g;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wm * 128 + i * 16 + n16;
+                fa[i] = *(const bf16x8_t *)(sa + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + n16;
+                fb[j] = *(const bf16x8_t *)(sb + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
+            }
+            // D = W_frag (rows n) x A_frag (cols m): a lane ends up with 4 consecutive n of one row m
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    // epilogue: acc[i][j][r] = C[m0 + wm*128 + i*16 + n16][n0 + wn*64 + j*16 + g*4 + r]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + n16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            const uint2 bb = *(const uint2 *)(bias + n);
+            float v0 = acc[i][j][0] + __uint_as_float(bb.x << 16), v1 = acc[i][j][1] + __uint_as_float(bb.x & 0xffff0000u);
+            float v2 = acc[i][j][2] + __uint_as_float(bb.y << 16), v3 = acc[i][j][3] + __uint_as_float(bb.y & 0xffff0000u);
+            if (ACT) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+            uint2 o;
+            o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+            o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+            *(uint2 *)(C + (int64_t)m * N + n) = o;
+        }
+    }
+}
+
+static float bf2f_h(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf_h(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
+int main(int argc, char **argv)
+{
+    const int M = argc > 1 ? atoi(argv[1]) : 75648, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+    const int act = argc > 4 ? atoi(argv[4]) : 1;
+    std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K), hb(N), hC((size_t)M * N);
+    srand(1);
+    for (auto &v : hA) v = f2bf_h((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+    for (auto &v : hW) v = f2bf_h((rand() / (float)RAND_MAX - 0.5f) * 0.1f);
+    for (auto &v : hb) v = f2bf_h((rand() / (float)RAND_MAX - 0.5f));
+    uint16_t *A, *W, *b, *C;
+    hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&b, hb.size() * 2); hipMalloc(&C, hC.size() * 2);
+    hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+    const size_t lds_bytes = 2 * (BM + BN) * BK * 2;
+    auto kern = act ? k_gemm<1> : k_gemm<0>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const dim3 grid(((M + BM - 1) / BM) * (N / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    hipError_t e = hipDeviceSynchronize();
+    printf("launch: %s\n", hipGetErrorString(e));
+    hipMemcpy(hC.data(), C, hC.size() * 2, hipMemcpyDeviceToHost);
+    // spot check 2000 entries against a host dot product
+    double maxerr = 0;
+    for (int t = 0; t < 2000; ++t) {
+        const int m = (int)((rand() / (double)RAND_MAX) * (M - 1)), n = (int)((rand() / (double)RAND_MAX) * (N - 1));
+        double s = 0;
+        for (int k = 0; k < K; ++k) s += (double)bf2f_h(hA[(size_t)m * K + k]) * bf2f_h(hW[(size_t)n * K + k]);
+        s += bf2f_h(hb[n]);
+        if (act) s = 0.5 * s * (1 + tanh(0.7978845608028654 * (s + 0.044715 * s * s * s)));
+        const double err = fabs(s - bf2f_h(hC[(size_t)m * N + n])) / (fabs(s) + 1.0);
+        if (err > maxerr) maxerr = err;
+    }
+    printf("max rel err (2000 samples, also the last rows): %.4g\n", maxerr);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("M=%d N=%d K=%d act=%d: %.3f ms, %.0f TFLOP/s\n", M, N, K, act, ms, 2.0 * M * N * K / ms / 1e9);
+    return 0;
+}
