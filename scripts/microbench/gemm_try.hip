@@ -52,75 +52,108 @@ __device__ __forceinline__ void stage_tile(const uint16_t *__restrict__ src, int
     }
 }
 
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// persistent workgroups: tile t of a workgroup = blockIdx.x + t * gridDim.x.  The first K-step of the next tile is staged
+// before the epilogue of the current one, whose stores then drain beside the next tile's main loop.
 template <int ACT>
 __global__ __launch_bounds__(NTHR) void k_gemm(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
-                                               const uint16_t *__restrict__ bias, uint16_t *__restrict__ C, int M, int N, int K)
+                                               const uint16_t *__restrict__ bias, uint16_t *__restrict__ C, int M, int N, int K, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // [2][A 256x64 | B 256x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;                            // 2 x 4 wavefronts: 128 x 64 each
     const int n16 = lane & 15, g = lane >> 4;
-    const int tiles_n = N / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int tiles_n = N / BN, ntiles = ((M + BM - 1) / BM) * tiles_n;
     const int nk = K / BK;
-    stage_tile<BM>(A, K, m0, M, 0, lds, tid);
-    stage_tile<BN>(W, K, n0, N, 0, lds + BM * BK, tid);
-    for (int ks = 0; ks < nk; ++ks) {
-        uint16_t *cur = lds + (ks & 1) * (BM + BN) * BK;
-        if (ks + 1 < nk) {
-            uint16_t *nxt = lds + ((ks + 1) & 1) * (BM + BN) * BK;
-            stage_tile<BM>(A, K, m0, M, (ks + 1) * BK, nxt, tid);
-            stage_tile<BN>(W, K, n0, N, (ks + 1) * BK, nxt + BM * BK, tid);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const uint16_t *sa = cur, *sb = cur + BM * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[8], fb[4];
-            const int q = kk * 4 + g;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = wm * 128 + i * 16 + n16;
-                fa[i] = *(const bf16x8_t *)(sa + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wn * 64 + j * 16 + n16;
-                fb[j] = *(const bf16x8_t *)(sb + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
-            }
-            // D = W_frag (rows n) x A_frag (cols m): a lane ends up with 4 consecutive n of one row m
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_barrier();
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        stage_tile<BM>(A, K, m0, M, 0, lds, tid);
+        stage_tile<BN>(W, K, n0, N, 0, lds + BM * BK, tid);
     }
-    // epilogue: acc[i][j][r] = C[m0 + wm*128 + i*16 + n16][n0 + wn*64 + j*16 + g*4 + r]
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        f32x4_t acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + n16;
-        if (m >= M) continue;
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4;
-            const uint2 bb = *(const uint2 *)(bias + n);
-            float v0 = acc[i][j][0] + __uint_as_float(bb.x << 16), v1 = acc[i][j][1] + __uint_as_float(bb.x & 0xffff0000u);
-            float v2 = acc[i][j][2] + __uint_as_float(bb.y << 16), v3 = acc[i][j][3] + __uint_as_float(bb.y & 0xffff0000u);
-            if (ACT) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-            uint2 o;
-            o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-            o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-            *(uint2 *)(C + (int64_t)m * N + n) = o;
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nk; ++ks) {
+            uint16_t *cur = lds + (ks & 1) * (BM + BN) * BK;
+            uint16_t *nxt = lds + ((ks + 1) & 1) * (BM + BN) * BK;
+            if (ks == 0) {
+                // step 0 was staged before the previous tile's epilogue: drain it together with that epilogue's stores
+                // (loads and stores share the counter and do not retire in one order), then put step 1 in flight
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (nk > 1) {
+                    stage_tile<BM>(A, K, m0, M, BK, nxt, tid);
+                    stage_tile<BN>(W, K, n0, N, BK, nxt + BM * BK, tid);
+                }
+            } else if (ks + 1 < nk) {
+                stage_tile<BM>(A, K, m0, M, (ks + 1) * BK, nxt, tid);
+                stage_tile<BN>(W, K, n0, N, (ks + 1) * BK, nxt + BM * BK, tid);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            const uint16_t *sa = cur, *sb = cur + BM * BK;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fa[8], fb[4];
+                const int q = kk * 4 + g;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = wm * 128 + i * 16 + n16;
+                    fa[i] = *(const bf16x8_t *)(sa + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wn * 64 + j * 16 + n16;
+                    fb[j] = *(const bf16x8_t *)(sb + (r * 8 + (q ^ ((r >> 1) & 7))) * 8);
+                }
+                // D = W_frag (rows n) x A_frag (cols m): a lane ends up with 4 consecutive n of one row m
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        // the next tile's first K-step goes in flight now (buffer 0 was last read at an even step, barriers passed)
+        const int ntile = tile + (int)gridDim.x;
+        if (ntile < ntiles) {
+            const int nm0 = (ntile / tiles_n) * BM, nn0 = (ntile % tiles_n) * BN;
+            stage_tile<BM>(A, K, nm0, M, 0, lds, tid);
+            stage_tile<BN>(W, K, nn0, N, 0, lds + BM * BK, tid);
+        }
+        // epilogue: acc[i][j][r] = C[m0 + wm*128 + i*16 + n16][n0 + wn*64 + j*16 + g*4 + r].  v_permlane16_swap trades the odd
+        // 16-lane rows of tile j for the even rows of tile j+1, after which a lane holds 8 consecutive columns: 16-byte stores
+        if (dbg == 1) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm * 128 + i * 16 + n16;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp += 2) {
+                uint32_t d[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = n0 + wn * 64 + (jp + t) * 16 + g * 4;
+                    const uint2 bb = *(const uint2 *)(bias + n);
+                    float v0 = acc[i][jp + t][0] + __uint_as_float(bb.x << 16), v1 = acc[i][jp + t][1] + __uint_as_float(bb.x & 0xffff0000u);
+                    float v2 = acc[i][jp + t][2] + __uint_as_float(bb.y << 16), v3 = acc[i][jp + t][3] + __uint_as_float(bb.y & 0xffff0000u);
+                    if (ACT) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+                    d[t][0] = pack2(v0, v1); d[t][1] = pack2(v2, v3);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+                // rows (g) 0, 2 now hold tile jp (columns 0-7 / 8-15), rows 1, 3 tile jp + 1
+                const int n = n0 + wn * 64 + (jp + (g & 1)) * 16 + (g >> 1) * 8;
+                if (m < M && dbg != 2) *(uint4 *)(C + (int64_t)m * N + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                else if (dbg == 2 && s0[0] == 0x12345678u) C[0] = 1;
+            }
         }
     }
 }
@@ -132,6 +165,7 @@ int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 75648, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
     const int act = argc > 4 ? atoi(argv[4]) : 1;
+    const int dbg = argc > 5 ? atoi(argv[5]) : 0;      // 1: no epilogue stores
     std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K), hb(N), hC((size_t)M * N);
     srand(1);
     for (auto &v : hA) v = f2bf_h((rand() / (float)RAND_MAX - 0.5f) * 2.f);
@@ -144,8 +178,9 @@ int main(int argc, char **argv)
     const size_t lds_bytes = 2 * (BM + BN) * BK * 2;
     auto kern = act ? k_gemm<1> : k_gemm<0>;
     hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    const dim3 grid(((M + BM - 1) / BM) * (N / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    const int ntiles_h = ((M + BM - 1) / BM) * (N / BN);
+    const dim3 grid(ntiles_h < 256 ? ntiles_h : 256);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K, dbg);
     hipError_t e = hipDeviceSynchronize();
     printf("launch: %s\n", hipGetErrorString(e));
     hipMemcpy(hC.data(), C, hC.size() * 2, hipMemcpyDeviceToHost);
@@ -162,10 +197,10 @@ int main(int argc, char **argv)
     }
     printf("max rel err (2000 samples, also the last rows): %.4g\n", maxerr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K, dbg);
     hipEventRecord(e0);
     const int reps = 20;
-    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K);
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds_bytes, 0, A, W, b, C, M, N, K, dbg);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     printf("M=%d N=%d K=%d act=%d: %.3f ms, %.0f TFLOP/s\n", M, N, K, act, ms, 2.0 * M * N * K / ms / 1e9);
