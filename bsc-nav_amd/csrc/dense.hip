@@ -527,7 +527,17 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce(const u64 *__restrict__ pk
 // The pairs are unique per (voxel, frame, patch) and, sorted by the cell code, contiguous per voxel in (frame, patch)
 // order: one wavefront per voxel walks its pairs 64 at a time, keeps four token rows (NV x 16 B per lane each) in flight
 // and finishes with ONE read-modify-write of the voxel's accumulator row.  No merging, no atomics.
-template <int NV, int MODE, typename TOK>
+// float4 slot of accumulator t in a voxel row.  Plain: 4 columns at 4 * (lane + 64 t).  PAIRED (bf16 rows, sum): accumulators
+// 2u and 2u+1 are the two halves of 8 consecutive columns at 8 * (lane + 64 u), which one 16-byte load of a bf16 row
+// delivers — the kernel is bound by the number of row-load instructions it issues, and this halves them (an odd last
+// accumulator keeps the plain slot).
+template <int NV, bool PAIRED> __device__ __forceinline__ int acc_slot(int t, int lane)
+{
+    if (!PAIRED || ((NV & 1) && t == NV - 1)) return lane + 64 * t;
+    return 2 * (lane + 64 * (t >> 1)) + (t & 1);
+}
+
+template <int NV, int MODE, typename TOK, bool PAIRED = false>
 __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__restrict__ code_sorted,
                                                              const uint32_t *__restrict__ idx_sorted,
                                                              const u64 *__restrict__ pair_rec, int64_t n_pairs,
@@ -578,8 +588,16 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                         mi[q] = j + q < n ? (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, jj) : 0u;
 #pragma unroll
                         for (int t = 0; t < NV; ++t) {
-                            const int v = lane + 64 * t;
-                            xr[q][t] = (v < D4) ? ((const uint2 *)row)[v] : make_uint2(0u, 0u);
+                            if (PAIRED && !((NV & 1) && t == NV - 1)) {
+                                if (t & 1) continue;                            // loaded with its even partner
+                                const int v8 = lane + 64 * (t >> 1);            // 8 columns at 8 * v8
+                                const uint4 raw = (2 * v8 + 1 < D4) ? ((const uint4 *)row)[v8] : make_uint4(0u, 0u, 0u, 0u);
+                                xr[q][t] = make_uint2(raw.x, raw.y);
+                                xr[q][t + 1] = make_uint2(raw.z, raw.w);
+                            } else {
+                                const int v = lane + 64 * t;
+                                xr[q][t] = (v < D4) ? ((const uint2 *)row)[v] : make_uint2(0u, 0u);
+                            }
                         }
                     }
 #pragma unroll
@@ -637,7 +655,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
         float4 *dst = (float4 *)(acc_g + vid * D);
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            const int v = lane + 64 * t;
+            const int v = acc_slot<NV, PAIRED>(t, lane);
             if (v < D4) {
                 float4 o = a[t];
                 if (!is_new) {
@@ -756,19 +774,22 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         stat_end(x, BSC_STAT_PAIRSORT, 0.0);
         stat_begin(x, BSC_STAT_DENSE);
         const dim3 grid(256 * 8), block(TPB);
-#define LV(NVV, MODEV, TOKT)                                                                                                   \
-    hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
+#define LVP(NVV, MODEV, TOKT, PAIR)                                                                                            \
+    hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT, PAIR>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
                        n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ)
+#define LV(NVV, MODEV, TOKT) LVP(NVV, MODEV, TOKT, false)
 #define LVM(NVV)                                                                                   \
     do {                                                                                           \
         if (token_dtype == BSC_TOK_BF16) {                                                         \
-            if (x->c.mode == BSC_MODE_MEAN) LV(NVV, BSC_MODE_MEAN, bf16_t); else LV(NVV, BSC_MODE_MAX, bf16_t); \
+            if (x->c.mode == BSC_MODE_MEAN) { if (D % 8 == 0 && !getenv("BSC_REDUCE_PLAIN")) LVP(NVV, BSC_MODE_MEAN, bf16_t, true); else LV(NVV, BSC_MODE_MEAN, bf16_t); } \
+            else LV(NVV, BSC_MODE_MAX, bf16_t); \
         } else {                                                                                   \
             if (x->c.mode == BSC_MODE_MEAN) LV(NVV, BSC_MODE_MEAN, float); else LV(NVV, BSC_MODE_MAX, float);   \
         }                                                                                          \
     } while (0)
         if (nv <= 1) LVM(1); else if (nv == 2) LVM(2); else if (nv == 3) LVM(3); else if (nv == 4) LVM(4); else LVM(8);
 #undef LVM
+#undef LVP
 #undef LV
         stat_end(x, BSC_STAT_DENSE, 0.0);
         hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);

@@ -226,13 +226,16 @@ def test_bf16_tokens_equal_widened_f32_tokens(mode):
         assert np.array_equal(a, b)
 
 
-def test_bf16_rows_with_large_multiplicities_equal_f32_rows():
+@pytest.mark.parametrize("D", [256, 768, 1024, 520])
+def test_bf16_rows_with_large_multiplicities_equal_f32_rows(D):
     """Dense mean with bf16 token rows where a (voxel, frame, patch) pair holds many hundreds of points (34x46-pixel patches,
     0.5 m cells): the reduce feeds the multiplicity to v_dot2c_f32_bf16 byte by byte (exact in bf16), and the sums must be
-    those of the f32 rows (within an ulp-level tolerance: two accumulation steps instead of one above 255), counts equal."""
+    those of the f32 rows (within an ulp-level tolerance: two accumulation steps instead of one above 255), counts equal.
+    D = 256 / 768 / 1024 / 520: one, three, four and a ragged number of 4-column accumulators per lane — 8 consecutive columns
+    of a bf16 row come in with one 16-byte load and feed two accumulators, an odd last accumulator keeps its 8-byte load."""
     import torch
     import bsc_nav_amd as B
-    H, W, D, g, F = 240, 320, 256, 7, 4
+    H, W, g, F = 240, 320, 7, 4
     rgb, depth, poses = _frames(F, H, W, seed=8)
     chain = B.PoseChain()
     Ts = np.stack([chain.pc_transform(p) for p in poses])
