@@ -400,6 +400,61 @@ def test_dinov2_state_dict_runs_through_the_fused_encoder(shape):
     assert e.mean().item() < 1.15 * e_plain.mean().item() + 1e-3 and e.max().item() < 0.5, (e.mean().item(), e.max().item())
 
 
+def test_graphed_encoder_equals_eager_and_does_not_keep_old_frames():
+    """encoder.GraphedEncoder (what bench.py times): the captured graph starts at the patch matrix, the preprocessing kernel
+    runs eagerly on the caller's frames — replaying it on new frames must give the eager result for THOSE frames (bf16 and f32
+    token outputs), also for a non-contiguous view of a larger buffer."""
+    import torch
+    from bsc_nav_amd import encoder
+    vit = encoder.RandomViT("vit_b16", image_size=224, seed=4).cuda()
+    a = torch.randint(0, 255, (3, 120, 160, 4), dtype=torch.uint8, device="cuda")
+    b = torch.randint(0, 255, (6, 120, 160, 4), dtype=torch.uint8, device="cuda")
+    for keep in (True, False):
+        enc = encoder.GraphedEncoder(vit, 3, 120, 160, 4, keep)
+        for frames in (a, b[3:], b[::2]):
+            out = enc(frames).clone()
+            ref = vit.patch_tokens(frames.contiguous(), keep)
+            assert out.dtype == ref.dtype and out.shape == ref.shape == (3, 14, 14, 768)
+            assert torch.equal(out, ref)
+
+
+def test_fuse_encoder_option_takes_a_dinov2_module():
+    """VoxelTokenMemory(preload_dino=<module with DINOv2's state_dict>, fuse_encoder=True): the weights move into the fused
+    encoder, ingest_frames runs through its batch entry, and the map equals the one built from that encoder's own tokens."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from bsc_nav_amd import encoder
+    sd = _dinov2_state_dict(768, 12, 12, 3072, 0, seed=9)
+
+    class HubModule:                                    # what torch.hub returns, as far as this path looks at it
+        def state_dict(self):
+            return sd
+
+        def forward_features(self, x):
+            raise AssertionError("the f32 module must not run when fuse_encoder=True")
+
+    H, W, F = 120, 160, 3
+    args = B.MemoryArgs(width=W, height=H, grid_size=128, cell_size=0.1, floor_height=-6.4, map_height=6.4, depth_sample_rate=1,
+                        query_width=224, query_height=224, memory_path="/tmp", scene_name="fuse", token_dim=768, patch_size=14)
+    mem = B.VoxelTokenMemory(args, preload_dino=HubModule(), need_diffusion=False, feature_mode="mean", fuse_encoder=True,
+                             max_frames_per_call=F, voxel_capacity=200_000)
+    assert isinstance(mem.dinov2, encoder.RandomViT) and mem.dinov2.arch == "vit_b14" and mem.dinov2.grid == 16
+    rgb, depth, poses = synth.make_frames(3, F, H, W, "room")
+    rgb4 = np.concatenate([rgb, np.full(rgb.shape[:3] + (1,), 255, np.uint8)], axis=-1)
+    d_rgb, d_depth = torch.from_numpy(rgb4).cuda(), torch.from_numpy(depth).cuda()
+    mem.ingest_frames(d_rgb, d_depth, poses)
+    acc, cnt = mem.engine.export_dense()
+    tok = mem.dinov2.patch_tokens(d_rgb)
+    eng = B.VoxelEngine(H, W, 128, 0.1, -6.4, 6.4, 16, 768, mode="mean", voxel_capacity=200_000, max_points=F * H * W)
+    Ts = np.stack([mem.chain.pc_transform(p) for p in poses])       # the memory's own pose chain: same anchor, same transforms
+    eng.ingest(d_depth, d_rgb, tok, Ts)
+    acc2, cnt2 = eng.export_dense()
+    assert np.array_equal(cnt, cnt2) and cnt.sum() > 0.9 * F * H * W
+    np.testing.assert_allclose(acc, acc2, rtol=1e-5, atol=1e-4)
+    eng.close()
+
+
 def _write_reference_dir(path, z, name, store_arrays=None):
     """A memory directory as the reference leaves it (memory_2.py:1136-1145): npy set + long_memory.json; the token store
     only as feat.h5df (through the stand-in) when `store_arrays` is given."""
