@@ -331,7 +331,18 @@ def cpu_baseline(a, p, seconds):
         cdt += time.perf_counter() - t
         nf += 1
     del om
-    one = {"value": nf / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+    # the reference's own style of execution: a Python loop over the points with small NumPy calls (oracle/numpy_loop.py,
+    # pinned to the reference's goldens) — a few seconds of it, scaled to the frame's point count
+    from oracle.numpy_loop import NumpyLoopMemory
+    nl = NumpyLoopMemory(H, W, gs, 0.1, -half, half, g, D, iter_size=50000)
+    t = time.perf_counter()
+    npts = nl.ingest_frame(dep[0], rgb[0], None, Ts[0], tok[0], max_points=20000)
+    ldt = time.perf_counter() - t
+    numpy_loop = {"value": (npts / ldt) / (H * W), "unit": "frames/s", "cores": 1, "kind": "port",
+                  "sample": f"first {npts} points of one frame through oracle/numpy_loop.py (per-point Python loop as in "
+                            f"memory_2.py:863-903, {1e3 * ldt / npts:.3f} ms per point), scaled to {H * W} points per frame"}
+    del nl
+    one = {"value": nf / cdt, "unit": "frames/s", "cores": 1, "kind": "port", "numpy_loop": numpy_loop,
            "sample": f"first {nf} frames of the same workload through oracle/bsc_oracle.c (memory path only: geometry + "
                      f"voxel scatter, encoder excluded), {cdt:.1f} s on 1 of {os.cpu_count()} host cores"}
     # all cores

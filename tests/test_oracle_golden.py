@@ -185,3 +185,30 @@ def test_frontier_helpers_match_reference(case):
         assert r["best"] == -1
     else:
         assert np.array_equal(r["centers"][r["best"]], want)
+
+
+@pytest.mark.parametrize("name", ["g2_mini_s7_yaw", "g2_c1_s1000"])
+def test_numpy_loop_restatement_matches_the_reference_goldens(name):
+    """oracle/numpy_loop.py (the reference-style per-point Python loop that bench.py times as `cpu_baseline_numpy_loop`)
+    against goldens produced by the reference's own obs2voxeltoken: cache rows, ids, rgb bytes, weights, top-down map."""
+    from oracle import oracle as orc
+    from oracle.numpy_loop import NumpyLoopMemory
+    z = gu.load(name)
+    cfg, rgb, depth, poses, tokens = gu.ingest_inputs(z)
+    N = cfg["H"] * cfg["W"]
+    mem = NumpyLoopMemory(cfg["H"], cfg["W"], cfg["gs"], cfg["cs"], cfg["floor_height"], cfg["map_height"], cfg["g"], cfg["D"])
+    chain = orc.PoseChain()
+    np.random.seed(cfg["seed"])
+    for f in range(cfg["F"]):
+        T = chain.pc_transform(poses[f])
+        idx = orc.sample_indices(N, cfg["s"])
+        mem.ingest_frame(depth[f], rgb[f], idx, T, tokens[f])
+    assert mem.max_id == int(z["max_id"]) and mem.iter_id == int(z["iter_id"])
+    assert np.array_equal(mem.grid_feat_pos[:mem.iter_id], z["cache_pos"])
+    assert np.array_equal(mem.grid_feat[:mem.iter_id, 0].astype(np.int32), z["cache_src"])
+    assert np.array_equal(mem.grid_feat_dis[:mem.iter_id], z["cache_dis"])
+    assert np.array_equal(mem.grid_rgb_pos[:mem.max_id], z["grid_rgb_pos"])
+    assert np.array_equal(mem.grid_rgb[:mem.max_id], z["grid_rgb"])
+    assert np.array_equal(mem.weight[:mem.max_id], z["weight"])
+    rc = np.argwhere(np.isfinite(mem.max_height)).astype(np.int32)
+    assert np.array_equal(rc, z["map_rc"]) and np.array_equal(mem.cv_map[rc[:, 0], rc[:, 1]], z["map_rgb"])
