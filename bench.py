@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     import shutil
     import tempfile
-    _src = os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
+    _src = os.environ.get("BSC_TUNABLEOP_FILE") or os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")    # A/B: another choice file
     _ord = os.environ.get("LOCAL_RANK", "0")
     _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.getpid()}_.csv")
     if os.path.exists(_src):
