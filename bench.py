@@ -9,7 +9,9 @@ Headline workload (`value`): BASELINE.json configs[1] — 640x480 frames, ViT-B/
 grid of 0.1 m cells, every pixel ingested (depth_sample_rate 1), "room" depth (camera random-walking inside an 8x3x6 m
 box).  The K timed steps are repeated (engine reset in between) and the MEDIAN repeat is reported.
 With N>1 ranks each rank ingests its own frame shard (weak scaling) and the per-rank maps are merged by one
-RCCL reduce-scatter at the end of the timed region.
+RCCL reduce-scatter at the end of the timed region.  `--gpus N` without a torchrun environment launches the N ranks
+itself (python -m torch.distributed.run on 127.0.0.1) and exits non-zero when fewer than N GPUs are visible; under
+torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0) carrying, beside the contract keys:
   roofline        the whole bsc_ingest call priced per SURVEY.md §8(d) (algorithmic bytes of the batch / HIP-event time
@@ -18,11 +20,16 @@ Prints ONE JSON line (rank 0) carrying, beside the contract keys:
                   frames/s, voxels, U/P, fraction of the §8(d) HBM bound
   configs         BASELINE configs[2] per GPU (ViT-L/14, 1024-D, 512^3) and configs[3]/[4] localize at 2^20 x 1024
   cpu_baseline    the plain-C oracle (port of the reference loop) on this box's host cores: 1 core and all cores
+  value_f32_encoder / memory_path_frames_per_s / tokens_bf16_*   the same pipeline at the reference's encoder precision
+                  (f32 weights, activations and tokens), the memory path alone (f64 geometry, f32 accumulate: what the
+                  parity tests cover), and the error of the stored feature means of the timed bf16 configuration against it
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -79,6 +86,7 @@ def parse():
     ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
     ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
     ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurements")
+    ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32 encoder) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the hall / iid workloads and the C3 leg")
     return ap.parse_args()
 
@@ -248,6 +256,118 @@ def stage_rooflines(p, iso, tok_bytes):
     return out
 
 
+def reference_precision_leg(a, p, local_rank, steps=3):
+    """The pipeline at the reference's encoder precision (memory_2.py:43,738-739: DINOv2 runs f32): the same architecture and
+    the same random weights NOT rounded to bf16, f32 activations through PyTorch-ROCm's f32 GEMMs, f32 tokens into
+    bsc_ingest — frames/s of `steps` steps after one warm-up, encoder and ingest back to back on one stream.  And what the
+    bf16 configuration that `value` times costs in accuracy: the stored per-voxel feature means of one batch ingested with
+    the bf16 encoder + bf16 tokens against the f32 encoder + f32 tokens (same frames, same voxels)."""
+    B = p.B
+    from bsc_nav_amd import encoder
+    vit32 = encoder.RandomViT(a.arch, image_size=224, seed=0, dtype=torch.float32).cuda()
+    half = a.grid * 0.05
+
+    def eng():
+        return B.VoxelEngine(p.H, p.W, a.grid, 0.1, -half, half, p.g, p.D, mode=a.mode, voxel_capacity=3_000_000,
+                             max_points=p.batch * p.N, device=local_rank)
+    e32 = eng()
+    n = min(steps + 1, p.n_steps)
+    e32.ingest(p.depths[0], p.rgbs[0], vit32.patch_tokens(p.rgbs[0]), p.Ts[:p.batch])
+    acc32, cnt32 = e32.export_dense()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(1, n):
+        e32.ingest(p.depths[s], p.rgbs[s], vit32.patch_tokens(p.rgbs[s]), p.Ts[s * p.batch:(s + 1) * p.batch])
+    e32.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    vit32.patch_tokens(p.rgbs[0])
+    ev[1].record()
+    torch.cuda.synchronize()
+    enc_ms = ev[0].elapsed_time(ev[1])
+    e32.close()
+    e16 = eng()
+    e16.ingest(p.depths[0], p.rgbs[0], p.vit.patch_tokens(p.rgbs[0], True), p.Ts[:p.batch])
+    acc16, cnt16 = e16.export_dense()
+    e16.close()
+    del vit32
+    torch.cuda.empty_cache()
+    assert np.array_equal(cnt16, cnt32)
+    c = np.maximum(cnt32, 1)[:, None].astype(np.float32)
+    m16, m32 = acc16 / c if a.mode == "mean" else acc16, acc32 / c if a.mode == "mean" else acc32
+    d = np.abs(m16 - m32)
+    return {"value_f32_encoder": (n - 1) * p.batch / dt, "f32_encoder_ms_per_step": enc_ms,
+            "f32_encoder_tflops": p.vit.flops_per_frame() * p.batch / (enc_ms * 1e-3) / 1e12,
+            "tokens_bf16_max_abs_err": float(d.max()), "tokens_bf16_mean_abs_err": float(d.mean()),
+            "tokens_rms": float(np.sqrt((m32.astype(np.float64) ** 2).mean())),
+            "note": f"value_f32_encoder: {n - 1} steps x {p.batch} frames, f32 encoder (PyTorch-ROCm f32 GEMMs, no bf16 anywhere) + "
+                    "f32 tokens + bsc_ingest, one stream; tokens_bf16_*: per-voxel feature means of one batch, bf16 encoder + bf16 "
+                    "tokens (the configuration `value` times) against f32 encoder + f32 tokens.  The north star's 1e-3 "
+                    "feature bound is met by the memory path for the tokens it is given (f32 accumulate; tests), not by "
+                    "a bf16 encoder against an f32 one"}
+
+
+def localize_store_leg(B, a, local_rank, D=1024, V=1 << 20, gL=512):
+    """BASELINE configs[3] in the REFERENCE'S store shape: V voxels with M ~ U{1..10} raw tokens each
+    (sum M ~ 5.8 M rows x 1024-D = 23.6 GB) loaded through bsc_import_store; voxel_localized takes the max over a voxel's
+    tokens (memory_2.py:642-663).  Q = 1 and 8, plain and with the region + floor filters; cosine scan priced against HBM."""
+    try:
+        free_kb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1])
+    except Exception:
+        free_kb = 0
+    if free_kb * 1024 < 3 * V * 5.5 * D * 4:
+        V = 1 << 18                                  # small host: the store is staged through host memory like a loaded memory
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    codes = torch.randperm(gL ** 3, device="cuda", generator=gen)[:V]
+    keys = torch.stack([codes // (gL * gL), (codes // gL) % gL, codes % gL], dim=1).to(torch.int32).contiguous()
+    cnt = torch.randint(1, 11, (V,), device="cuda", generator=gen, dtype=torch.int32)
+    T = int(cnt.sum().item())
+    rows = torch.empty((T, D), dtype=torch.float32, device="cuda")
+    for lo in range(0, T, 1 << 20):
+        rows[lo:lo + (1 << 20)] = torch.randn((min(1 << 20, T - lo), D), device="cuda", generator=gen)
+    eng = B.VoxelEngine(a.height, a.width, gL, 0.1, -gL * 0.05, gL * 0.05, 16, D, mode="exact", iter_size=256,
+                        voxel_capacity=V + 8, token_capacity=T, max_points=1024, device=local_rank)
+    kk = keys.cpu().numpy()
+    t0 = time.perf_counter()
+    eng.import_rgb(kk, np.zeros((V, 3), np.uint8), np.ones(V, np.float32))
+    eng.import_store(kk, cnt.cpu().numpy(), rows.cpu().numpy(), np.zeros(T, np.float32))
+    load_s = time.perf_counter() - t0
+    out = {"voxels": V, "token_rows": T, "dim": D, "K": 100, "grid": gL, "tokens_per_voxel": "U{1..10}",
+           "store_bytes": T * D * 4, "load_seconds_through_host": load_s}
+    seg = torch.repeat_interleave(torch.arange(V, device="cuda"), cnt.to(torch.int64))
+    for Q in (1, 8):
+        q = torch.randn(Q, D, device="cuda", generator=gen)
+        pos, sim, n = eng.localize(q, K=100)
+        if Q == 1:      # correctness at this size: top-1 of an independent fp64 scan with the per-voxel max
+            qn = q[0].double() / q[0].double().norm()
+            best = torch.full((V,), -2.0, dtype=torch.float64, device="cuda")
+            for lo in range(0, T, 1 << 19):
+                r = rows[lo:lo + (1 << 19)].double()
+                best.scatter_reduce_(0, seg[lo:lo + (1 << 19)], (r @ qn) / r.norm(dim=1), reduce="amax")
+            assert pos[0, 0].tolist() == keys[best.argmax()].tolist(), "store-shape localize top-1 differs from the fp64 scan"
+            del best
+        for name, kw in (("", {}), ("_region_floor", dict(radius=150.0, curr=[gL // 2] * 3, floor=(gL // 6, gL - gL // 6)))):
+            eng.kernel_stats(1, reset=True)
+            lats = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                eng.localize(q, K=100, **kw)
+                torch.cuda.synchronize()
+                lats.append(time.perf_counter() - t)
+            ls = eng.kernel_stats(1)
+            ms = ls["ms"] / max(1, ls["launches"])
+            gbs = T * D * 4 / (ms * 1e-3) / 1e9
+            out[f"q{Q}{name}"] = {"latency_ms": statistics.median(lats) * 1e3, "cosine_ms": ms, "cosine_GBs": gbs,
+                                  "cosine_frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    eng.close()
+    del rows
+    torch.cuda.empty_cache()
+    return out
+
+
 def localize_leg(B, a, local_rank, D, V=1 << 20, gL=512):
     g = 16
     engL = B.VoxelEngine(a.height, a.width, gL, 0.1, -gL * 0.05, gL * 0.05, g, D, mode="mean", voxel_capacity=V + 8,
@@ -382,14 +502,38 @@ def cpu_baseline(a, p, seconds):
     return one, allc
 
 
+def launch_ranks(a, backend):
+    """`python bench.py --gpus N` outside torchrun: run the N ranks of this script under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and return their exit status.  Fewer than N visible GPUs is an error, not a
+    silently smaller run."""
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and n_dev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} GPU(s) visible on this node — one rank per GPU is required "
+                         f"(RCCL); nothing was measured")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     a = parse()
+    backend = os.environ.get("BSC_BENCH_BACKEND", "nccl")      # "gloo" only to exercise the N>1 path on a 1-GPU box
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a, backend))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU")
-    backend = os.environ.get("BSC_BENCH_BACKEND", "nccl")      # "gloo" only to exercise the N>1 path on a 1-GPU box
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -496,6 +640,9 @@ def main():
                          "chain_ms_per_step_side_stream": iso["stages"]["k_chain"],
                          "encoder_tflops": enc_tf, "encoder_frac_of_bf16_mfma_peak": enc_tf / MFMA_BF16_PEAK_TF,
                          "voxels": c1["max_id"]}
+        out["memory_path_frames_per_s"] = a.batch / (iso["ingest_wall_ms"] * 1e-3)     # bsc_ingest + its rgb chain alone, f32 tokens or bf16 as timed
+        if not a.no_f32:
+            out.update(reference_precision_leg(a, p, local_rank))
         # ---- CPU baseline on the same frames (before they are freed) ----
         if not a.no_cpu_baseline:
             one, allc = cpu_baseline(a, p, a.cpu_seconds)
@@ -508,44 +655,54 @@ def main():
             out["workloads"] = {"room": {"frames_per_s": out["value"], "voxels": out["stages"]["voxels"], "U_over_P": out["roofline"]["U_over_P"],
                                          "ingest_ms_per_step": out["roofline"]["ms_per_call"], "frac_of_hbm_bound": out["roofline"]["frac"]}}
             # as many steps as the headline where the map keeps growing over the run (a short run is mostly start-up: every
-            # voxel new), half of them for the one-voxel-per-point stress case
-            for kind, steps in (("hall", a.steps), ("iid", max(4, a.steps // 2)), ("room_off", a.steps)):
-                q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
-                q.run(0, 2)
+            # voxel new), half of them for the one-voxel-per-point stress case.  "cold": the timed steps follow two warm-up
+            # steps on an empty map (new voxels all along the run); "warm": the same frames again over the map the cold pass
+            # built (the steady state of a scene that is revisited) — separate keys, medians of `reps` passes each.
+            def timed_pass(q, lo, hi):
                 torch.cuda.synchronize()
                 k0 = q.eng.counters()
                 q.reset_stats()
                 t0 = time.perf_counter()
-                q.run(2, steps + 2)
+                q.run(lo, hi)
                 q.eng.sync()
                 torch.cuda.synchronize()
-                dtk = time.perf_counter() - t0
-                k1, st = q.eng.counters(), q.stage_ms()
+                return time.perf_counter() - t0, k0, q.eng.counters(), q.stage_ms()
+
+            def workload(q, steps, reps=3):
+                cold, warm, last = [], [], None
+                for r in range(reps):
+                    if r:
+                        q.eng.reset()
+                    q.run(0, 2)
+                    last = timed_pass(q, 2, steps + 2)
+                    cold.append(last[0])
+                    warm.append(timed_pass(q, 2, steps + 2)[0])
+                dtk, k0, k1, st = last
                 Uk = (k1["voxel_rmw"] - k0["voxel_rmw"]) / steps
-                algk = ingest_alg_bytes(a.batch, N, g, D, tok_bytes, Uk)
-                out["workloads"][kind] = {
-                    "frames_per_s": steps * a.batch / dtk, "steps": steps, "voxels": k1["max_id"], "U_over_P": Uk / (a.batch * N),
-                    "pairs_per_call": (k1["pairs"] - k0["pairs"]) / steps, "ingest_ms_per_step": st["bsc_ingest"],
-                    "bytes_per_call": algk, "frac_of_hbm_bound": algk / st["bsc_ingest"] / 1e6 / HBM_PEAK_GBS, "stage_ms": st}
+                algk = ingest_alg_bytes(q.batch, q.N, q.g, q.D, tok_bytes, Uk)
+                return {"frames_per_s": steps * q.batch / statistics.median(cold), "frames_per_s_cold": steps * q.batch / statistics.median(cold),
+                        "frames_per_s_warm": steps * q.batch / statistics.median(warm), "steps": steps, "repeats": reps,
+                        "voxels": k1["max_id"], "U_over_P": Uk / (q.batch * q.N), "pairs_per_call": (k1["pairs"] - k0["pairs"]) / steps,
+                        "ingest_ms_per_step": st["bsc_ingest"], "bytes_per_call": algk,
+                        "frac_of_hbm_bound": algk / st["bsc_ingest"] / 1e6 / HBM_PEAK_GBS, "stage_ms": st}
+
+            for kind, steps in (("hall", a.steps), ("iid", max(4, a.steps // 2)), ("room_off", a.steps)):
+                q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
+                out["workloads"][kind] = workload(q, steps, reps=3 if kind != "iid" else 2)
                 q.close()
-            # configs[2] (C3) per GPU: ViT-L/14 tokens (16x16x1024) into a 512^3 grid
+            # configs[2] (C3) per GPU: ViT-L/14 tokens (16x16x1024) into a 512^3 grid, as many steps as the headline
             a3 = argparse.Namespace(**vars(a))
-            b3, s3 = 128, 4
+            b3, s3 = 128, max(a.steps, 8)
             q = Pipeline(a3, "hall", "vit_l14", 512, b3, s3 + 2, rank, local_rank, vcap=3_000_000)
-            q.run(0, 2)
-            torch.cuda.synchronize()
-            q.reset_stats()
-            t0 = time.perf_counter()
-            q.run(2, s3 + 2)
-            q.eng.sync()
-            torch.cuda.synchronize()
-            dtk = time.perf_counter() - t0
-            iso3 = q.isolated(2, s3 + 2)
+            w3 = workload(q, s3)
+            iso3 = q.isolated(2, min(s3 + 2, 10))
             tf3 = q.vit.flops_per_frame() * b3 / (iso3["encoder_ms"] * 1e-3) / 1e12
             out["configs"] = {"C3_vit_l14_1024d_grid512_per_gpu": {
-                "frames_per_s": s3 * b3 / dtk, "frames_per_step": b3, "steps": s3, "encoder_ms_per_step": iso3["encoder_ms"],
-                "ingest_ms_per_step": iso3["stages"]["bsc_ingest"], "encoder_tflops": tf3,
-                "encoder_frac_of_bf16_mfma_peak": tf3 / MFMA_BF16_PEAK_TF, "voxels": q.eng.counters()["max_id"], "depth": "hall"}}
+                "frames_per_s": w3["frames_per_s_warm"], "frames_per_s_cold": w3["frames_per_s_cold"],
+                "frames_per_s_warm": w3["frames_per_s_warm"], "frames_per_step": b3, "steps": s3, "repeats": w3["repeats"],
+                "encoder_ms_per_step": iso3["encoder_ms"], "ingest_ms_per_step": iso3["stages"]["bsc_ingest"],
+                "memory_path_frames_per_s": b3 / (iso3["ingest_wall_ms"] * 1e-3), "encoder_tflops": tf3,
+                "encoder_frac_of_bf16_mfma_peak": tf3 / MFMA_BF16_PEAK_TF, "voxels": w3["voxels"], "depth": "hall"}}
             q.close()
         del vit
         torch.cuda.empty_cache()
@@ -554,6 +711,7 @@ def main():
             out["localize"] = localize_leg(B, a, local_rank, D)
             if D != 1024:
                 out.setdefault("configs", {})["C4_C5_localize_2pow20_x_1024_grid512"] = localize_leg(B, a, local_rank, 1024)
+            out.setdefault("configs", {})["C4_store_shape_2pow20_voxels_M_1to10_x_1024"] = localize_store_leg(B, a, local_rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -218,6 +218,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                         const void *tokens, int token_dtype, const int32_t *idx, const int64_t *offsets_host,
                         const double *alpha, bsc_draw_fn draw, void *user);
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user);
+bsc_status grow_token_pool(bsc_ctx *x, int64_t need_rows);   // exact mode: the token store is unbounded like the reference's
 bsc_status launch_pending_chain(bsc_ctx *x);
 bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixels, const uint32_t *p_patf);
 bsc_status frontier_mask_impl(bsc_ctx *x, const uint8_t *navigable_host, uint8_t *mask_host);

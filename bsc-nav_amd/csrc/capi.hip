@@ -688,8 +688,8 @@ extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const
                                        const float *feats, const float *dists)
 {
     if (!x || x->c.mode != BSC_MODE_EXACT) { bsc_set_error("bsc_import_store: exact mode only"); return BSC_E_STATE; }
-    if (nt > x->c.token_capacity) { bsc_set_error("bsc_import_store: %lld tokens > token_capacity", (long long)nt); return BSC_E_CAPACITY; }
     BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(grow_token_pool(x, nt));
     const int64_t vcap = x->c.voxel_capacity, cs = x->c.cache_size, D = x->c.token_dim;
     // voxel ids come from the occupied map imported before (bsc_import_rgb)
     int32_t *occ = (int32_t *)malloc(sizeof(int32_t) * x->ncell);

@@ -131,19 +131,45 @@ __global__ __launch_bounds__(TPB) void k_flush_winners(int n_rows, const int32_t
     if (win[(int64_t)rowseg[r] * cache_size + k] == r) rowdst[r] = store_rows[(int64_t)rowe[r] * cache_size + k];
 }
 
+// token pool of at least `need` rows: new allocation of max(2 x capacity, need), rows in use copied, old pool freed
+bsc_status grow_token_pool(bsc_ctx *x, int64_t need)
+{
+    if (need <= x->c.token_capacity) return BSC_OK;
+    const int64_t D = x->c.token_dim;
+    int64_t cap = 2 * x->c.token_capacity;
+    if (cap < need) cap = need;
+    float *pool = nullptr, *pool_d = nullptr;
+    hipError_t e = hipMalloc((void **)&pool, sizeof(float) * (size_t)cap * D);
+    if (e == hipSuccess) e = hipMalloc((void **)&pool_d, sizeof(float) * (size_t)cap);
+    if (e != hipSuccess) {
+        if (pool) (void)hipFree(pool);
+        bsc_set_error("token store: cannot grow the pool from %lld to %lld rows of %lld floats (%s)", (long long)x->c.token_capacity,
+                      (long long)cap, (long long)D, hipGetErrorString(e));
+        return BSC_E_CAPACITY;
+    }
+    BSC_TRY(sync_all(x));                        // nothing in flight reads the old pool
+    if (x->pool_n_host > 0) {
+        BSC_HIP(hipMemcpy(pool, x->pool, sizeof(float) * (size_t)x->pool_n_host * D, hipMemcpyDeviceToDevice));
+        BSC_HIP(hipMemcpy(pool_d, x->pool_d, sizeof(float) * (size_t)x->pool_n_host, hipMemcpyDeviceToDevice));
+    }
+    (void)hipFree(x->pool);
+    (void)hipFree(x->pool_d);
+    x->pool = pool;
+    x->pool_d = pool_d;
+    x->c.token_capacity = cap;
+    return BSC_OK;
+}
+
 bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user)
 {
     const int n = x->c.iter_size, D = x->c.token_dim, cs = x->c.cache_size;
     hipStream_t s = x->stream;
     const dim3 block(TPB), grid((n + TPB - 1) / TPB), wgrid((unsigned)(((int64_t)n * 64 + TPB - 1) / TPB));
     const int ebits = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
-    // A flush appends at most one pool row per cache row.  Refuse BEFORE anything is changed when the pool could overflow:
-    // the store stays consistent and the caller can grow token_capacity (the reference's HDF5 store is unbounded).
-    if (x->pool_n_host + n > x->c.token_capacity) {
-        bsc_set_error("token store: %lld rows used, a flush may add %d, token_capacity=%lld — create the context with a larger "
-                      "token_capacity", (long long)x->pool_n_host, n, (long long)x->c.token_capacity);
-        return BSC_E_CAPACITY;
-    }
+    // A flush appends at most one pool row per cache row.  The reference's HDF5 store is unbounded (memory_2.py:330-354), so
+    // the pool GROWS here when this flush could overflow it — before anything is changed: a flush triggered from the middle
+    // of an ingest call (memory_2.py:880-881) must never fail half way through the frame.
+    BSC_TRY(grow_token_pool(x, x->pool_n_host + n));
     hipLaunchKernelGGL(k_flush_keys, grid, block, 0, s, n, x->cache_pos, x->occ, x->c.grid_size, x->nh,
                        x->c.voxel_capacity, x->f_keys_a);
     BSC_TRY(prim_sort_keys(x, x->f_keys_a, x->f_keys_b, (size_t)n, 0, 20 + ebits));

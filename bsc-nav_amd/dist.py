@@ -50,9 +50,16 @@ def name_key_np(pos):
 
 
 def _world(group):
-    if not dist.is_available() or not dist.is_initialized():
+    if not _active():
         return 0, 1
     return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _active():
+    """True when a process group exists.  Every exchange below is skipped only when there is NO group: a group of one
+    rank still goes through the collectives (identity results), so a single-GPU box exercises the RCCL code path
+    (tests/test_gpu_dist.py::test_rccl_world1_*)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def _all_gather(t, group=None):
@@ -72,7 +79,7 @@ def _all_gather(t, group=None):
 def all_gather_ragged(t, group=None):
     """All-gather of 1-D tensors of different lengths -> list of tensors (one per rank)."""
     rank, world = _world(group)
-    if world == 1:
+    if not _active():
         return [t]
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [int(s.item()) for s in _all_gather(n, group)]
@@ -111,7 +118,7 @@ def global_id_order(local_codes, group=None):
 def reduce_scatter_rows(rows, op, per, group=None):
     """rows (world*per, ...) -> this rank's (per, ...) slice of the element-wise reduction."""
     rank, world = _world(group)
-    if world == 1:
+    if not _active():
         return rows
     out = torch.empty((per,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     backend = dist.get_backend(group)
@@ -164,7 +171,7 @@ def merge_heightmaps(heights, colours):
 def _all_gather_np(a, device, group=None):
     """NumPy array (same shape on every rank) -> (world, ...) NumPy array."""
     rank, world = _world(group)
-    if world == 1:
+    if not _active():
         return a[None]
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dist.get_backend(group) != "gloo":
@@ -199,7 +206,7 @@ def merge_dense_maps(engine, group=None):
     codes = pack_keys(keys) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=keys.device)
     union, n_union, per = global_id_order(codes, group)
     mark("global_id_order")
-    if world == 1:
+    if not _active():
         return dict(n_union=n_union, per_rank=n_union, n_local=n_union)
     ukeys = unpack_keys(union)
     acc, cnt = engine.dense_gather(ukeys)
@@ -247,7 +254,7 @@ def gather_merged_to_root(engine, info, root=0, group=None):
     (ids 0..n_union-1 in global order, features, counts, rgb, weights, top-down map) and can `save_memory` a directory
     that `load_memory` accepts (memory_2.py:1136-1145 / :189-200).  Other ranks keep their slice.  -> True on root."""
     rank, world = _world(group)
-    if world == 1:
+    if not _active():
         return True
     per, n_local, D = info["per_rank"], info["n_local"], engine.cfg.token_dim
     dev = engine.device
@@ -304,7 +311,7 @@ def localize_sharded(engine, q, K=100, radius=None, curr=None, floor=None, group
     """q (Q,D) identical on every rank -> global (Q,<=K,3) positions and (Q,<=K) similarities."""
     rank, world = _world(group)
     pos, sim, cnt = engine.localize(q, K=K, radius=radius, curr=curr, floor=floor)
-    if world == 1:
+    if not _active():
         return [pos[i, :cnt[i]] for i in range(len(cnt))], [sim[i, :cnt[i]] for i in range(len(cnt))]
     dev = q.device
     Q = pos.shape[0]
@@ -328,7 +335,7 @@ def warmup_collectives(device, group=None):
     """Run every collective merge_dense_maps / localize_sharded use once on small buffers, so that RCCL's
     communicator and protocol setup (seconds on first use) is not charged to the first real merge."""
     rank, world = _world(group)
-    if world == 1:
+    if not _active():
         return
     all_gather_ragged(torch.arange(rank + 1, dtype=torch.int64, device=device), group)
     for dt in (torch.float32, torch.int32):

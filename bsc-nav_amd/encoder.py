@@ -50,11 +50,16 @@ class _Block(nn.Module):
         hd = Wd // self.heads
         qkv = self.qkv(y)
         a = torch.empty((B, T, Wd), dtype=torch.bfloat16, device=y.device)
-        if getattr(self, "_att_work", None) is None or self._att_work.device != y.device:
-            self._att_work = torch.zeros(2, dtype=torch.int32, device=y.device)     # ticket / finished counters
+        # ticket / finished counters: one pair per (device, stream) — launches on one stream are ordered and may share
+        # them, two forwards of this module on different streams (a graph replay beside an eager query embedding) may not
+        stream = torch.cuda.current_stream(y.device)
+        key = (y.device, stream.cuda_stream)
+        works = self.__dict__.setdefault("_att_works", {})
+        if key not in works:
+            works[key] = torch.zeros(2, dtype=torch.int32, device=y.device)
         _lib.check(_lib.load().bsc_enc_attention_dyn(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
-                                                     C.c_void_p(a.data_ptr()), C.c_void_p(self._att_work.data_ptr()),
-                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                     C.c_void_p(a.data_ptr()), C.c_void_p(works[key].data_ptr()),
+                                                     C.c_void_p(stream.cuda_stream)))
         return a
 
     def can_fuse_attention(self, y):
@@ -358,7 +363,6 @@ class GraphedEncoder:
         probe = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
         self.from_patches = vit.can_fuse_preprocess(probe) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
         s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
         if self.from_patches:
             self.static_in = vit.preprocess_patches(probe)
             run = lambda: vit._forward_patches(self.static_in, keep_dtype)["x_norm_patchtokens"].reshape(
@@ -366,6 +370,7 @@ class GraphedEncoder:
         else:
             self.static_in = probe
             run = lambda: vit.patch_tokens(self.static_in, keep_dtype)
+        s.wait_stream(torch.cuda.current_stream())          # after the kernel that writes the graph's input buffer
         with torch.cuda.stream(s):
             for _ in range(2):
                 run()

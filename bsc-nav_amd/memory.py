@@ -110,9 +110,15 @@ class VoxelTokenMemory:
         self._export_cache.clear()
 
     def _cached(self, name, fn):
+        """Cached exports are handed out READ-ONLY: the reference's attributes are its own mutable state, here they are
+        snapshots of HBM, and an in-place edit by a caller would silently change every later read (copy to edit)."""
         hit = self._export_cache.get(name)
         if hit is None or hit[0] != self._gen:
-            hit = (self._gen, fn())
+            val = fn()
+            for a in (val if isinstance(val, tuple) else (val,)):
+                if isinstance(a, np.ndarray):
+                    a.setflags(write=False)
+            hit = (self._gen, val)
             self._export_cache[name] = hit
         return hit[1]
 
@@ -138,7 +144,8 @@ class VoxelTokenMemory:
 
     @property
     def occupied_ids(self):
-        return self._cached("occ", self.engine.export_occupied)
+        """(gs,gs,maxh-minh) i32 — a fresh D2H copy per read (800 MB at the reference defaults: not kept pinned in a cache)."""
+        return self.engine.export_occupied()
 
     @property
     def cv_map(self):
@@ -253,13 +260,19 @@ class VoxelTokenMemory:
         if tokens is None:
             tokens = self._batch_patch_tokens(rgb)
         self._touch()
-        if self.depth_sample_rate == 1 and self.feature_mode != "exact":
+        host_alpha = self.alpha_source == "host"
+        if self.depth_sample_rate == 1 and self.feature_mode != "exact" and not host_alpha:
             self.engine.ingest(depth, rgb, tokens, Ts)
             return
         N = depth.shape[1] * depth.shape[2]
         idxs = [sample_indices(N, self.depth_sample_rate) for _ in range(F)]
         off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
-        self.engine.ingest(depth, rgb, tokens, Ts, torch.from_numpy(np.concatenate(idxs)).to(self.device), off)
+        alpha = None
+        if host_alpha:          # same setting as obs2voxeltoken: rgb bytes / weights bit-exact (one D2H copy of the depth)
+            dh = depth.detach().cpu().numpy()
+            with np.errstate(all="ignore"):
+                alpha = torch.from_numpy(np.concatenate([self._host_alpha(dh[f], idxs[f]) for f in range(F)])).to(self.device)
+        self.engine.ingest(depth, rgb, tokens, Ts, torch.from_numpy(np.concatenate(idxs)).to(self.device), off, alpha)
 
     # ------------------------------------------------------------------------------------------
     def imaginary(self, text_prompts, vis=False):
@@ -347,7 +360,7 @@ class VoxelTokenMemory:
             raise RuntimeError("the exact (token-cache) mode is defined by the global point order: replicas only")
         info = bdist.merge_dense_maps(self.engine, group)
         self._touch()
-        if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size(group) == 1:
+        if not (tdist.is_available() and tdist.is_initialized()):
             return True
         is_root = bdist.gather_merged_to_root(self.engine, info, root, group)
         lists = [None] * tdist.get_world_size(group)
@@ -419,7 +432,6 @@ class VoxelTokenMemory:
         return k
 
     # ------------------------------------------------------------------------------------------
-    # simulator-driven loops: thin restatements over an injected NavEnv-like `Env` (env.py:49-296)
     def long_memory(self, obs):
         """memory_2.py:905-945: detector boxes -> depth at the box centre -> voxel location -> {label, loc, confidence}.
 
@@ -475,44 +487,14 @@ class VoxelTokenMemory:
             final.extend(kept)
         self.long_memory_dict = final
 
-    def excute(self, obs, actions):
-        """memory_2.py:1086-1101."""
-        for action in actions:
-            if action != "stop":
-                obs = self.Env.sims.step(action)
-                st = self.Env.agent.get_state()
-                pos, rot = st.position, st.rotation
-                pose = np.array([pos[0], pos[1], pos[2], rot.x, rot.y, rot.z, rot.w])
-                self.obs2voxeltoken(obs, pose)
-                self.long_memory(obs)
-        return obs
+    def create_memory(self):
+        raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop over the simulator "
+                                  "(out of scope, SURVEY.md §2 #9); feed frames through obs2voxeltoken() / ingest_frames() "
+                                  "or use dataset.create_memory_for_dataset()")
 
     def exploring_create_memory(self):
-        """memory_2.py:1104-1145: random navigable goals + 360 degree sweeps, final flush, save."""
-        self.initial_memory()
-        obs = self.Env.sims.get_sensor_observations(0)
-        self.init_height = self.Env.agent.get_state().position[1]
-        pf = self.Env.plnner.pathfinder
-        for _ in range(int(self.cfg.random_move_num)):
-            subgoal = pf.get_random_navigable_point()
-            island_begin = pf.get_island(self.Env.agent.get_state().position)
-            while (not pf.is_navigable(subgoal)) or (pf.get_island(subgoal) != island_begin):
-                subgoal = pf.get_random_navigable_point()
-            try:
-                path, goal = self.Env.move2point(subgoal)
-                obs = self.excute(obs, path)
-                self.base_height.append(self.Env.agent.get_state().position[1])
-                obs = self.excute(obs, ["turn_left"] * int(360 / self.cfg.turn_left))
-            except Exception as e:   # the reference swallows move failures (memory_2.py:1126-1128)
-                self._log(f"move failed: {e}")
-                continue
-        if self.feature_mode == "exact":
-            self.update_memory_dist_base()
-        self.save_memory()
-
-    def create_memory(self):
-        raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop; use "
-                                  "exploring_create_memory() or feed frames through obs2voxeltoken()")
+        raise NotImplementedError("simulator-driven exploration (memory_2.py:1104-1145) is out of scope (SURVEY.md §2 #9); "
+                                  "dataset.create_memory_for_dataset() runs the same call order over a frame source")
 
 
     # ---- FrontierExplorer (memory_2.py:1147-1418) -----------------------------------------------------------------
@@ -622,28 +604,6 @@ class VoxelTokenMemory:
                 xx, yy = np.ogrid[0:self.gs, 0:self.gs]
                 img[(xx - tx) ** 2 + (yy - ty) ** 2 <= 25] = (0, 255, 0)
         self.FrontierMap = img
-
-    def explore_entire_space(self, max_iterations=30):
-        """memory_2.py:1347-1391: sweep, find frontiers, cluster, go to the most informative cluster, repeat."""
-        self.min_cluster_size, self.ig_radius = 10, 5
-        self.initial_memory()
-        obs = self.Env.sims.get_sensor_observations(0)
-        for _ in range(max_iterations):
-            obs = self.excute(obs, ["turn_left"] * int(360 / self.cfg.turn_left))
-            navigable_mask = self.build_navigable_mask()
-            frontiers = self.find_frontiers(navigable_mask)
-            if not frontiers:
-                break
-            clusters = self.cluster_frontiers(frontiers)
-            if not clusters:
-                break
-            target = self.select_best_cluster_center_by_ig(clusters)
-            if target is None:
-                break
-            self.update_frontier_map(frontiers, clusters, target, navigable_mask)
-            subgoal = self.Env.get_random_navigable_point_near(self.grid2loc_2d(target[0], target[1]))
-            path, goal = self.Env.move2point(subgoal)
-            obs = self.excute(obs, path)
 
     # ---- BASELINE.json vocabulary (north_star names the entry points Memory.update_* / Memory.localize) -------------
     def update_from_observation(self, obs, pose):

@@ -211,3 +211,90 @@ def test_c5_voxel_sharded_localize_equals_single_map():
     for i in range(Q):
         p, s = bd.merge_topk([pp[0][i, :pp[2][i]] for pp in parts], [pp[1][i, :pp[2][i]] for pp in parts], K)
         assert np.array_equal(p, p0[i]) and np.array_equal(s, s0[i])
+
+
+def _store_shape_map(torch, V, D, gs, seed, n_dup=48):
+    """C4 in the reference's store shape: V voxels with M ~ U{1..10} raw tokens each (memory_2.py:642-663
+    takes the max over a voxel's tokens).  `n_dup` voxels carry one and the same token among theirs, so a query near that
+    token meets a block of EXACT ties at the head of the ranking (the reference's name-order case, memory_2.py:665)."""
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    codes = torch.randperm(gs ** 3, device="cuda", generator=gen)[:V]
+    keys = torch.stack([codes // (gs * gs), (codes // gs) % gs, codes % gs], dim=1).to(torch.int32).contiguous()
+    cnt = torch.randint(1, 11, (V,), device="cuda", generator=gen, dtype=torch.int32)
+    off = torch.zeros(V + 1, dtype=torch.int64, device="cuda")
+    off[1:] = torch.cumsum(cnt.to(torch.int64), 0)
+    T = int(off[-1].item())
+    rows = torch.empty((T, D), dtype=torch.float32, device="cuda")
+    for a in range(0, T, 1 << 20):
+        rows[a:a + (1 << 20)] = torch.randn((min(1 << 20, T - a), D), device="cuda", generator=gen)
+    dup_vox = torch.randperm(V, device="cuda", generator=gen)[:n_dup]
+    special = torch.randn(D, device="cuda", generator=gen)
+    rows[off[dup_vox] + (cnt[dup_vox].to(torch.int64) - 1)] = special           # the last token of each of these voxels
+    seg = torch.repeat_interleave(torch.arange(V, device="cuda"), cnt.to(torch.int64))
+    return keys, cnt, off, rows, seg, special, gen
+
+
+def _fp64_voxel_ranking(torch, rows, seg, V, q, keys_np, K, mask=None, slack=64, chunk=1 << 18):
+    """Independent scan in the reference's terms: cosine in float64 per token, max per voxel (memory_2.py:655-661), stable
+    descending sort over name-ordered candidates (:665) -> (pos (K,3), sim (K,)) per query."""
+    from bsc_nav_amd import dist as bd
+    qn = q.double() / q.double().norm(dim=1, keepdim=True).clamp_min(1e-8)
+    best = torch.full((q.shape[0], V), -2.0, dtype=torch.float64, device=rows.device)
+    for a in range(0, rows.shape[0], chunk):
+        r = rows[a:a + chunk].double()
+        s = qn @ (r / r.norm(dim=1, keepdim=True).clamp_min(1e-8)).T
+        best.scatter_reduce_(1, seg[a:a + chunk].expand(q.shape[0], -1), s, reduce="amax")
+    if mask is not None:
+        best[:, ~mask] = -3.0
+    top = torch.topk(best, K + slack, dim=1)
+    out = []
+    for i in range(q.shape[0]):
+        idx, sim = top.indices[i].cpu().numpy(), top.values[i].cpu().numpy()
+        k0, k1, k2 = bd.name_keys_np(keys_np[idx])
+        order = np.lexsort((k2, k1, k0, -sim))
+        assert sim[order][K - 1] > sim[order][-1], "tie group runs past the candidate slack"
+        out.append((keys_np[idx[order[:K]]], sim[order[:K]]))
+    return out
+
+
+def test_c4_store_shape_2pow20_voxels_ragged_tokens_matches_fp64_scan():
+    """BASELINE configs[3] / SURVEY.md §8d "C4": localize over V = 2^20 voxels x 1024-D inside a 512^3 grid in the
+    REFERENCE'S store shape — M ~ U{1..10} raw tokens per voxel (sum M ~ 5.8 M rows, ~23.6 GB), loaded through
+    bsc_import_store like a reference-built memory — Q = 1 and 8, with and without the region + floor filters
+    (memory_2.py:624-640): cosine per token, per-voxel max, stable top-K in HDF5 name order, against the fp64 scan.
+    Scores within 2e-6 (north star: 1e-3); the block of exact ties at the head keeps name order."""
+    import torch
+    import bsc_nav_amd as B
+    import golden_util as gu
+    V, D, gs, K = 1 << 20, 1024, 512, 100
+    keys, cnt, off, rows, seg, special, gen = _store_shape_map(torch, V, D, gs, 11)
+    T = rows.shape[0]
+    assert 5_000_000 < T < 6_500_000
+    eng = B.VoxelEngine(48, 64, gs, 0.1, -25.6, 25.6, 16, D, mode="exact", iter_size=256, voxel_capacity=V + 8,
+                        token_capacity=T, max_points=4096)
+    kk = keys.cpu().numpy()
+    eng.import_rgb(kk, np.zeros((V, 3), np.uint8), np.ones(V, np.float32))
+    eng.import_store(kk, cnt.cpu().numpy(), rows.cpu().numpy(), np.zeros(T, np.float32))
+    c = eng.counters()
+    assert c["store_voxels"] == V and c["store_tokens"] == T
+    q = torch.randn((8, D), device="cuda", generator=gen)
+    q[0] = special + 0.02 * q[0]                                   # heads the ranking with the 48 tied voxels
+    for Q in (1, 8):
+        pos, sim, n = eng.localize(q[:Q], K=K)
+        ref = _fp64_voxel_ranking(torch, rows, seg, V, q[:Q], kk, K)
+        for i in range(Q):
+            assert n[i] == K
+            gu.assert_topk_matches(pos[i], sim[i], ref[i][0], ref[i][1], tol=2e-6)
+        # the block of exact ties heads query 0's ranking, in HDF5 link-name order ('grid_19_..' < 'grid_1_..', memory_2.py:665)
+        assert len(set(sim[0][:48].tolist())) == 1 and sim[0][48] < sim[0][47]
+        names = ["grid_%d_%d_%d" % tuple(r) for r in pos[0][:48].tolist()]
+        assert names == sorted(names)
+    curr, radius, floor = [256, 256, 256], 150.0, (80, 420)
+    k64 = keys.to(torch.int64)
+    mask = (((k64 - torch.tensor(curr, device="cuda")) ** 2).sum(1) <= radius * radius) & (k64[:, 2] >= floor[0]) & (k64[:, 2] <= floor[1])
+    pos, sim, n = eng.localize(q, K=K, radius=radius, curr=curr, floor=floor)
+    ref = _fp64_voxel_ranking(torch, rows, seg, V, q, kk, K, mask)
+    for i in range(8):
+        assert n[i] == K
+        gu.assert_topk_matches(pos[i], sim[i], ref[i][0], ref[i][1], tol=2e-6)
+    eng.close()

@@ -123,3 +123,50 @@ def test_two_process_sharded_build_equals_single_process(tmp_path, mode):
         gu.assert_topk_near(p2[qi], s2[qi], p1[qi], s1[qi], tol=5e-6)
         for r in ranks:                                             # both ranks hold the same merged answer
             gu.assert_topk_near(r[f"sp{qi}"], r[f"ss{qi}"], p1[qi], s1[qi], tol=5e-6)
+
+
+@pytest.mark.parametrize("mode", ["mean", "max"])
+def test_rccl_world1_merge_gather_localize(tmp_path, mode):
+    """The RCCL branches of dist.py on the one GPU of the test box: a `nccl` process group of ONE rank drives
+    merge_dense_maps / gather_merged_to_root / localize_sharded through `reduce_scatter_tensor` (f32 SUM or MAX, int32 SUM),
+    device `all_gather`, `dist.gather` and the ragged key all-gather — no gloo fallback is taken (asserted on the backend).
+    With one rank every exchange is the identity, so the merged memory must equal the memory before the merge bit for bit
+    (ids, positions, feature rows, counts, rgb, weights, top-down map) and the sharded top-K the plain top-K."""
+    import torch
+    import torch.distributed as dist
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dist as bd
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl" and bd._active()
+        rgb, depth, poses, tokens = _inputs()
+        mem = B.VoxelTokenMemory(_args(tmp_path, "w1"), need_diffusion=False, feature_mode=mode, max_frames_per_call=F,
+                                 voxel_capacity=100_000)
+        mem.set_map_origin(poses[0])
+        mem.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+        bd.warmup_collectives(torch.device("cuda", 0))
+        before = (mem.engine.export_rgb(), mem.engine.export_dense(), mem.engine.export_heightmap(), mem.engine.export_occupied())
+        q = torch.from_numpy(np.random.RandomState(5).standard_normal((3, D)).astype(np.float32)).cuda()
+        p0, s0, n0 = mem.engine.localize(q, K=40)
+        info = bd.merge_dense_maps(mem.engine)
+        n = before[0][0].shape[0]
+        assert info == dict(n_union=n, per_rank=n, n_local=n)
+        sp, ss = bd.localize_sharded(mem.engine, q, K=40)
+        assert bd.gather_merged_to_root(mem.engine, info) is True
+        assert mem.merge_shards() is True                 # the public entry: merge + gather + long-memory lists
+        after = (mem.engine.export_rgb(), mem.engine.export_dense(), mem.engine.export_heightmap(), mem.engine.export_occupied())
+        for a, b in zip(before, after):
+            for x, y in zip(a, b) if isinstance(a, tuple) else ((a, b),):
+                assert np.array_equal(x, y)
+        for qi in range(3):
+            assert np.array_equal(sp[qi], p0[qi, :n0[qi]]) and np.array_equal(ss[qi], s0[qi, :n0[qi]])
+        # the raw collectives on known data
+        rows = torch.arange(24, dtype=torch.float32, device="cuda").reshape(6, 4)
+        assert torch.equal(bd.reduce_scatter_rows(rows, dist.ReduceOp.MAX, 6), rows)
+        assert torch.equal(bd.reduce_scatter_rows(rows.to(torch.int32), dist.ReduceOp.SUM, 6), rows.to(torch.int32))
+        parts = bd.all_gather_ragged(torch.arange(5, dtype=torch.int64, device="cuda"))
+        assert len(parts) == 1 and parts[0].tolist() == [0, 1, 2, 3, 4]
+        mem.engine.close()
+    finally:
+        dist.destroy_process_group()

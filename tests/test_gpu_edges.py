@@ -406,32 +406,50 @@ def test_cold_start_every_voxel_new_and_capacity_boundary():
     small.close()
 
 
-def test_token_capacity_refusal_leaves_the_store_consistent():
-    """A flush that could overflow the token pool is refused before anything is changed: the error is loud, the store
-    exported afterwards is the store from before, and the same context keeps answering queries."""
+def test_token_store_grows_like_the_unbounded_reference_store():
+    """The reference's HDF5 store is unbounded (memory_2.py:330-354).  A flush — also one triggered from the middle of an
+    ingest call, memory_2.py:880-881 — that would overflow the token pool grows it in place: the store equals the one of
+    a context created with ample capacity, frame by frame; the same holds after a store was imported into a context
+    that was sized for exactly the imported rows (load_memory followed by more exploration)."""
     import random
     import torch
     import bsc_nav_amd as B
     import synth
-    H, W, g, D, F = 48, 64, 16, 16, 3
+    H, W, g, D, F = 48, 64, 16, 16, 4
     rgb, depth, poses = synth.make_frames(4, F, H, W, "room")
     tokens = synth.make_tokens(4, F, g, D)
     chain = B.PoseChain()
     Ts = np.stack([chain.pc_transform(p) for p in poses])
-    eng = B.VoxelEngine(H, W, 128, 0.1, -6.4, 6.4, g, D, mode="exact", iter_size=2000, voxel_capacity=20_000,
-                        token_capacity=7000, max_points=H * W)
-    random.seed(0)
     d, c, t = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
-    eng.ingest(d[:1], c[:1], t[:1], Ts[:1])                  # ~3000 points: one in-call flush of 2000 rows, ~1000 rows cached
-    assert eng.counters()["flushes"] == 1
-    eng.ingest(d[1:2], c[1:2], t[1:2], Ts[1:2])              # two more flushes: up to 6000 rows, still within 7000
-    mid = eng.export_store()
-    assert eng.counters()["flushes"] == 3 and len(mid[2]) > 5000
-    with pytest.raises(B._lib.BscError, match="token_capacity"):
-        eng.ingest(d[2:3], c[2:3], t[2:3], Ts[2:3])          # the fourth could need 8000 > 7000: refused
-    after = eng.export_store()
-    for a, b in zip(mid, after):
+
+    def build(cap, frames, seed_state=None, start=None):
+        eng = B.VoxelEngine(H, W, 128, 0.1, -6.4, 6.4, g, D, mode="exact", iter_size=2000, voxel_capacity=20_000,
+                            token_capacity=cap, max_points=H * W)
+        if start is not None:
+            eng.import_rgb(*start[0])
+            eng.import_store(*start[1])
+        random.seed(0) if seed_state is None else random.setstate(seed_state)
+        for f in frames:
+            eng.ingest(d[f:f + 1], c[f:f + 1], t[f:f + 1], Ts[f:f + 1])
+        return eng
+
+    big = build(1_000_000, range(F))
+    small = build(2500, range(F))                    # every in-call flush after the first has to grow the pool
+    assert small.counters()["flushes"] == big.counters()["flushes"] >= 4
+    for a, b in zip(big.export_store(), small.export_store()):
         assert np.array_equal(a, b)
-    p, s, n = eng.localize(torch.randn(1, D, device="cuda"), K=5)
+    assert all(np.array_equal(a, b) for a, b in zip(big.export_rgb(), small.export_rgb()))
+    # a loaded store in a context with no spare rows, then more frames
+    half = build(1_000_000, range(2))
+    half.flush()
+    st = random.getstate()
+    state = (half.export_rgb(), half.export_store())
+    n_tok = len(state[1][2])
+    cont_big = build(1_000_000, range(2, F), seed_state=st, start=state)
+    cont_small = build(n_tok, range(2, F), seed_state=st, start=state)
+    for a, b in zip(cont_big.export_store(), cont_small.export_store()):
+        assert np.array_equal(a, b)
+    p, s_, n = cont_small.localize(torch.randn(1, D, device="cuda"), K=5)
     assert n[0] == 5
-    eng.close()
+    for e in (big, small, half, cont_big, cont_small):
+        e.close()
