@@ -80,11 +80,6 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the encoder eagerly instead of a HIP graph")
-    ap.add_argument("--no-overlap", action="store_true", help="do not overlap encoder(s+1) with ingest(s)")
-    ap.add_argument("--serial", action="store_true", help="strict alternation on the GPU: encoder(s+1) starts when the main-"
-                    "stream kernels of ingest(s) are done (the two stages time-slice the chip anyway)")
-    ap.add_argument("--prefetch", type=int, default=1, help="batches the encoder runs ahead of the ingest")
-    ap.add_argument("--priority", action="store_true", help="ingest on a high-priority stream (pair with --prefetch 2)")
     ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurements")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32 encoder) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the hall / iid workloads and the C3 leg")
@@ -114,7 +109,9 @@ def pmc_traffic():
 
 
 class Pipeline:
-    """Encoder (own stream, HIP graph) + bsc_ingest (main stream), tokens double-buffered; frames resident in HBM."""
+    """Encoder (HIP graph) then bsc_ingest, back to back on ONE stream; frames resident in HBM.  The library itself keeps
+    its deferred rgb chain on a side stream.  (An encoder stream running ahead of the ingest bought <= 2 % in round 2 — the
+    stages time-slice the chip — and was dropped.)"""
 
     def __init__(self, a, kind, arch, grid, batch, n_steps, rank, local_rank, vit=None, vcap=None):
         import bsc_nav_amd as B
@@ -139,52 +136,21 @@ class Pipeline:
                                             poses=poses[s * batch:(s + 1) * batch])
             self.rgbs.append(r)
             self.depths.append(d)
-        self.NBUF = a.prefetch + 1
         bf16 = a.tokens == "bf16"
         if a.no_graph:
-            self.encs = [lambda r: self.vit.patch_tokens(r, bf16)] * self.NBUF
+            self.enc = lambda r: self.vit.patch_tokens(r, bf16)
         else:
-            self.encs = [encoder.GraphedEncoder(self.vit, batch, H, W, 4, bf16) for _ in range(self.NBUF)]
-        self.enc_stream = torch.cuda.Stream()
-        self.main_stream = torch.cuda.current_stream()
-        self.tok_ready = [torch.cuda.Event() for _ in range(self.NBUF)]
-        self.tok_free = [torch.cuda.Event() for _ in range(self.NBUF)]
-        self.pending = {}
-        self.ing_done = None              # event after the main-stream kernels of the last ingest (--serial)
-        self.enc_events = []              # (start, end) per encoder run, on the encoder's stream
-        for b in range(self.NBUF):
-            self.tok_free[b].record(self.main_stream)
+            self.enc = encoder.GraphedEncoder(self.vit, batch, H, W, 4, bf16)
+        self.encs = [self.enc]
+        self.enc_events = []              # (start, end) per encoder run
 
-    def _encode_async(self, s):
-        b = s % self.NBUF
-        with torch.cuda.stream(self.enc_stream):
-            self.enc_stream.wait_event(self.tok_free[b])          # ingest of batch s-NBUF no longer reads this token buffer
-            if self.a.serial and self.ing_done is not None:
-                self.enc_stream.wait_event(self.ing_done)
-                self.eng.stream_wait_chain(self.enc_stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(self.enc_stream)
-            tok = self.encs[b](self.rgbs[s])
-            e1.record(self.enc_stream)
-            self.enc_events.append((e0, e1))
-            if self.a.no_graph:
-                tok.record_stream(self.main_stream)               # eager mode: the allocator must not recycle it early
-            self.pending[s] = tok
-            self.tok_ready[b].record(self.enc_stream)
-
-    def step(self, s, stop):
-        for k in range(0 if self.a.no_overlap else self.NBUF):
-            if s + k < stop and s + k not in self.pending:
-                self._encode_async(s + k)
-        if s not in self.pending:
-            self._encode_async(s)
-        b = s % self.NBUF
-        self.main_stream.wait_event(self.tok_ready[b])
-        self.eng.ingest(self.depths[s], self.rgbs[s], self.pending.pop(s), self.Ts[s * self.batch:(s + 1) * self.batch])
-        self.tok_free[b].record(self.main_stream)
-        if self.a.serial:
-            self.ing_done = torch.cuda.Event()
-            self.ing_done.record(self.main_stream)
+    def step(self, s, stop=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tok = self.enc(self.rgbs[s])
+        e1.record()
+        self.enc_events.append((e0, e1))
+        self.eng.ingest(self.depths[s], self.rgbs[s], tok, self.Ts[s * self.batch:(s + 1) * self.batch])
 
     def run(self, lo, hi):
         for s in range(lo, hi):
@@ -547,10 +513,7 @@ def main():
     import bsc_nav_amd as B
     from bsc_nav_amd import dist as bdist
 
-    # the ingest is the latency-critical stage of the pipeline: its stream (and the library's side stream) are
-    # high priority, the MFMA-bound encoder fills the rest of the machine from a normal-priority stream
-    ing_stream = torch.cuda.Stream(priority=-1 if a.priority else 0)
-    torch.cuda.set_stream(ing_stream)
+    torch.cuda.set_stream(torch.cuda.Stream())          # a real stream: the encoder graph cannot be captured on the null stream
     n_steps = a.steps + a.warmup
     p = Pipeline(a, a.kind, a.arch, a.grid, a.batch, n_steps, rank, local_rank)
     g, D, N = p.g, p.D, p.N

@@ -105,9 +105,14 @@ class RandomViT(nn.Module):
         self.norm = nn.LayerNorm(s["width"], eps=1e-6)
         self.head = nn.Linear(s["width"], out_dim, bias=False) if out_dim and out_dim != s["width"] else None
         self.out_dim = out_dim or s["width"]
-        for p in self.parameters() if init_weights else ():
+        # every random value comes from the seeded generator (matrices trunc_normal(0.02), Linear biases U(-0.02, 0.02)), so
+        # two instances with the same seed hold the same weights whatever their dtype and the state of the global RNG
+        for name, p in self.named_parameters() if init_weights else ():
             if p.dim() > 1:
                 nn.init.trunc_normal_(p, std=0.02, generator=g)
+            elif name.endswith(".bias") and isinstance(self.get_submodule(name.rsplit(".", 1)[0]), nn.Linear):
+                with torch.no_grad():
+                    p.uniform_(-0.02, 0.02, generator=g)
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
         self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
         self.eval()
