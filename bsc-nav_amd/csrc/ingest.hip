@@ -1162,12 +1162,14 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (exact) hipLaunchKernelGGL(k_pass_list, fgrid, block, 0, s, P, x->p_cell, x->blk_pass_off, x->pass_list);
     // ids in use are < max_id
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
-    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
-    const int64_t neb = (R + EB - 1) / EB;
-    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
-    BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->gmask, x->run_scan + neb, sj,
-                       x->seg_k0, x->seg_vid, x->bscal_s[set]);
+    if (R > 0) {                                  // R == 0: no point of the batch has a voxel (k_totals left 0 segments)
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+        const int64_t neb = (R + EB - 1) / EB;
+        hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
+        BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->gmask, x->run_scan + neb, sj,
+                           x->seg_k0, x->seg_vid, x->bscal_s[set]);
+    }
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
     if (n_bound > seg_cap) n_bound = seg_cap;
