@@ -66,7 +66,7 @@ __device__ __forceinline__ int frame_of(const int64_t *offsets, int n_frames, in
 // from pixel to pixel (a 16-pixel stretch A B A A B A ... is 8 runs but 2 groups: a quarter of the sort entries).
 // Slots: wave-round w owns slots [64 w, 64 w + 64); it uses the first wr_cnt[w] of them, in order of each group's first
 // lane (any partition of the lanes into same-cell subsets, listed by first lane, keeps the per-voxel order).
-#define GROUP_LOOP_MAX 16       // more run heads than this in a wave-round: the runs themselves are the groups (bounded work)
+#define GROUP_LOOP_MAX 16       // more distinct cells than this in a wave-round: the runs themselves are the groups (bounded work)
 
 // t-th set bit (t < popcount) of a 64-bit mask
 __device__ __forceinline__ int nth_set_bit(u64 m, int t)
@@ -92,29 +92,29 @@ __device__ __forceinline__ int emit_groups(const int32_t cell, const int lane, c
     const bool change = lane == 0 || prev != cell;
     const u64 heads = __ballot(valid && change);
     if (!heads) return 0;
-    const int n_runs = __popcll(heads);
     int32_t myc = 0;
     u64 mym = 0ull;
     int n = 0;
-    if (n_runs <= GROUP_LOOP_MAX) {
-        // the distinct cells of the wave-round, in order of their first lane; lane i keeps group i
-        u64 rem = heads;
-        while (rem) {
-            const int l0 = __ffsll((long long)rem) - 1;
-            const int32_t c = __builtin_amdgcn_readlane(cell, l0);
-            const u64 m = __ballot(cell == c);
-            rem &= ~m;
-            if (lane == n) { myc = c; mym = m; }
-            ++n;
-        }
-    } else {
-        // every run is a group: a head lane owns the lanes up to the next change of cell; lane i fetches the i-th run
-        n = n_runs;
+    // the distinct cells of the wave-round, in order of their first lane; lane i keeps group i.  `rem`: run heads whose cell
+    // has not been taken yet (later runs of a taken cell drop out with it).
+    u64 rem = heads;
+    while (rem && n < GROUP_LOOP_MAX) {
+        const int l0 = __ffsll((long long)rem) - 1;
+        const int32_t c = __builtin_amdgcn_readlane(cell, l0);
+        const u64 m = __ballot(cell == c);
+        rem &= ~m;
+        if (lane == n) { myc = c; mym = m; }
+        ++n;
+    }
+    if (rem) {
+        // more than GROUP_LOOP_MAX distinct cells (far surfaces, noise): every run is a group — a head lane owns the lanes
+        // up to the next change of cell; lane i fetches the i-th run.  Bounded work whatever the input.
+        n = __popcll(heads);
         const u64 ends = __ballot(change);
         const u64 above = lane == 63 ? 0ull : (ends & (~0ull << (lane + 1)));
         const int end = above ? __ffsll((long long)above) - 1 : 64;
         const u64 m = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
-        const int src = lane < n_runs ? nth_set_bit(heads, lane) : 0;
+        const int src = lane < n ? nth_set_bit(heads, lane) : 0;
         myc = __shfl(cell, src);
         mym = ((u64)__shfl((uint32_t)(m >> 32), src) << 32) | (u64)__shfl((uint32_t)m, src);
     }
