@@ -132,11 +132,10 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                                                 int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
                                                 PointRec *__restrict__ p_rec, float *__restrict__ p_r2f,
                                                 int32_t *__restrict__ new_cells, int64_t *dscal,
-                                                int32_t *__restrict__ gcell, u64 *__restrict__ gmask, uint8_t *__restrict__ wr_cnt,
-                                                int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass)
+                                                int32_t *__restrict__ blk_pass)
 {
-    __shared__ int s_heads, s_pass;
-    if (threadIdx.x == 0) { s_heads = 0; s_pass = 0; }
+    __shared__ int s_pass;
+    if (threadIdx.x == 0) s_pass = 0;
     const int lane = threadIdx.x & 63;
     const int32_t N = gc.H * gc.W;
     int32_t cells[PPT];
@@ -238,21 +237,43 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         }
         cells[r] = cell;
     }
-    // groups (-> per-voxel point order) and passing points of the block
-    const int wid = threadIdx.x >> 6;
-    int ng = 0, np = 0;
+    // passing points of the block
+    int np = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) np += __popcll(__ballot(cells[r] >= 0));
+    __syncthreads();                                    // s_pass is initialised
+    if (lane == 0) atomicAdd(&s_pass, np);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_pass[blockIdx.x] = s_pass;
+}
+
+// The groups of the batch (see emit_groups): a memory-bound pass over the cells — 4 bytes per point in, ~12 bytes per group
+// out — so that the loop over a wave-round's distinct cells rides under the loads instead of on top of k_points' fp64 work.
+__global__ __launch_bounds__(TPB) void k_groups(int64_t P, const int32_t *__restrict__ p_cell, int32_t *__restrict__ gcell,
+                                                u64 *__restrict__ gmask, uint8_t *__restrict__ wr_cnt,
+                                                int32_t *__restrict__ blk_groups)
+{
+    __shared__ int s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t cells[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+        cells[r] = j < P ? p_cell[j] : -2;
+    }
+    int ng = 0;
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
         const int wr = r * (TPB / 64) + wid;            // points [64 wr, 64 wr + 64) of the block
         const int n = emit_groups(cells[r], lane, (int64_t)blockIdx.x * FB + 64 * wr, gcell, gmask);
         if (lane == 0) wr_cnt[(int64_t)blockIdx.x * (FB / 64) + wr] = (uint8_t)n;      // n <= 64
         ng += n;
-        np += __popcll(__ballot(cells[r] >= 0));
     }
-    __syncthreads();                                    // s_heads / s_pass are initialised
-    if (lane == 0) { atomicAdd(&s_heads, ng); atomicAdd(&s_pass, np); }
     __syncthreads();
-    if (threadIdx.x == 0) { blk_runs[blockIdx.x] = s_heads; blk_pass[blockIdx.x] = s_pass; }
+    if (lane == 0) atomicAdd(&s_tot, ng);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_groups[blockIdx.x] = s_tot;
 }
 
 // scalars of the batch, on the device: run / passing-point totals from the block scans, the new voxels' id range
@@ -309,33 +330,34 @@ __global__ __launch_bounds__(TPB) void k_new_assign(int64_t n, int64_t n_ok, con
 }
 
 // ---- groups -> sort entries ------------------------------------------------------------------------------------------
-// One workgroup per 1024-point block: the groups k_points left in the block's slots, compacted in slot order:
-// key = voxel id | (points - 1) << vb, value = slot (names the wave-round, hence j0, and the mask).  A few bytes per GROUP
-// are read here, not the cells of every point.
+// One workgroup per 1024-point block: the block's groups compacted in slot order: key = voxel id | (points - 1) << vb,
+// value = slot (names the wave-round, hence j0, and the mask).  Thread t of the block takes its t-th group.
 __global__ __launch_bounds__(TPB) void k_group_keys(int vb, const uint8_t *__restrict__ wr_cnt, const int32_t *__restrict__ gcell,
                                                     const u64 *__restrict__ gmask, const int32_t *__restrict__ occ,
                                                     const int32_t *__restrict__ blk_run_off, uint32_t *__restrict__ rkey,
                                                     uint32_t *__restrict__ rval)
 {
-    __shared__ int s_cnt[FB / 64], s_pre[FB / 64];
-    if (threadIdx.x < FB / 64) s_cnt[threadIdx.x] = wr_cnt[(int64_t)blockIdx.x * (FB / 64) + threadIdx.x];
-    __syncthreads();
+    __shared__ int s_pre[FB / 64 + 1];
     if (threadIdx.x == 0) {
+        const uint4 raw = *(const uint4 *)(wr_cnt + (int64_t)blockIdx.x * (FB / 64));     // the 16 counts of the block
+        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
         int run = 0;
-        for (int w = 0; w < FB / 64; ++w) { s_pre[w] = run; run += s_cnt[w]; }
+#pragma unroll
+        for (int w = 0; w < FB / 64; ++w) { s_pre[w] = run; run += (int)((w4[w >> 2] >> (8 * (w & 3))) & 0xffu); }
+        s_pre[FB / 64] = run;
     }
     __syncthreads();
+    const int total = s_pre[FB / 64];
     const int32_t base = blk_run_off[blockIdx.x];
+    for (int t = threadIdx.x; t < total; t += TPB) {
+        int w = 0;
 #pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        const int sl = r * TPB + (int)threadIdx.x, w = sl >> 6, i = sl & 63;
-        if (i < s_cnt[w]) {
-            const int64_t slot = (int64_t)blockIdx.x * FB + sl;
-            const int32_t v = occ[gcell[slot]];
-            const int len = __popcll(gmask[slot]);
-            rkey[base + s_pre[w] + i] = (uint32_t)v | ((uint32_t)(len - 1) << vb);
-            rval[base + s_pre[w] + i] = (uint32_t)slot;
-        }
+        for (int k = 1; k < FB / 64; ++k) w += t >= s_pre[k] ? 1 : 0;
+        const int64_t slot = (int64_t)blockIdx.x * FB + 64 * w + (t - s_pre[w]);
+        const int32_t v = occ[gcell[slot]];
+        const int len = __popcll(gmask[slot]);
+        rkey[base + t] = (uint32_t)v | ((uint32_t)(len - 1) << vb);
+        rval[base + t] = (uint32_t)slot;
     }
 }
 
@@ -1117,12 +1139,13 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (gc.fast)
         hipLaunchKernelGGL(k_points<true>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
                            x->d_transforms, alpha, P, inv_w, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->gcell, x->gmask, x->wr_cnt, x->blk_cnt, x->blk_pass);
+                           x->dscal, x->blk_pass);
     else
         hipLaunchKernelGGL(k_points<false>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
                            x->d_transforms, alpha, P, inv_w, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->gcell, x->gmask, x->wr_cnt, x->blk_cnt, x->blk_pass);
+                           x->dscal, x->blk_pass);
     stat_end(x, BSC_STAT_POINTS, 0.0);
+    hipLaunchKernelGGL(k_groups, fgrid, block, 0, s, P, x->p_cell, x->gcell, x->gmask, x->wr_cnt, x->blk_cnt);
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
