@@ -96,9 +96,6 @@ struct bsc_ctx {
     // Points are ordered per voxel through their RUNS (maximal stretches of consecutive points in one cell; a 10 cm
     // voxel a few metres away covers ~16 pixels of an image row): the runs are sorted by voxel id (stable radix sort
     // keeps the order j inside a voxel) and expanded back into the per-voxel point order the rgb chain walks.
-    int32_t *gcell;                     // groups of the batch (ingest.hip): cell of the group in slot s (64 slots per wave-round)
-    u64 *gmask;                         //   lanes of the wave-round that belong to it
-    uint8_t *wr_cnt;                    //   groups of every wave-round (<= 64)
     int32_t *new_cells;                 // cells claimed for the first time in this batch (one entry per new voxel)
     int32_t *blk_cnt, *blk_off;         // per 1024-point block: runs (count / exclusive prefix); also head compaction
     int32_t *blk_pass, *blk_pass_off;   // per block: passing points

@@ -133,10 +133,10 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     const int64_t ncell = (int64_t)c.grid_size * c.grid_size * nh;
     if (c.height <= 0 || c.width <= 0 || c.grid_size <= 0 || nh <= 0 || c.patch_grid <= 0 || c.patch_grid > 255 ||
         c.token_dim <= 0 || (c.token_dim & 3) || c.token_dim > 2048 || c.cache_size <= 0 || c.cache_size > 64 ||
-        c.iter_size <= 0 || c.iter_size > (1 << 20) || c.voxel_capacity <= 0 || c.voxel_capacity > (1 << 26) - 2 ||
-        c.max_points <= 0 || c.mode < 0 || c.mode > 2 || ncell >= (1ll << 31) || !(c.cell_size > 0)) {
+        c.iter_size <= 0 || c.iter_size > (1 << 20) || c.voxel_capacity <= 0 || c.max_points <= 0 ||
+        c.mode < 0 || c.mode > 2 || ncell >= (1ll << 31) || !(c.cell_size > 0)) {
         bsc_set_error("bsc_create: invalid configuration (need token_dim %% 4 == 0 <= 2048, patch_grid <= 255, "
-                      "iter_size <= 2^20, voxel_capacity <= 2^26 - 2, gs*gs*(max_h-min_h) < 2^31)");
+                      "iter_size <= 2^20, gs*gs*(max_h-min_h) < 2^31)");
         return BSC_E_INVALID;
     }
     BSC_HIP(hipSetDevice(device));
@@ -228,7 +228,6 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
-    ALLOC(x->gcell, np + 1024); ALLOC(x->gmask, np + 1024); ALLOC(x->wr_cnt, np / 64 + 32);
     ALLOC(x->new_cells, np); ALLOC(x->run_val_b, np); ALLOC(x->run_scan, np); ALLOC(x->seg_k0, np); ALLOC(x->seg_vid, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
@@ -288,7 +287,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     if (x->side) hipStreamSynchronize(x->side);
     hipStreamSynchronize(x->stream);
     void *ptrs[] = {x->pat_x, x->pat_y, x->pt_rect, x->pt_off, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
-                    x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf, x->gcell, x->gmask, x->wr_cnt,
+                    x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
                     x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->new_cells, x->run_scan, x->seg_k0, x->seg_vid, x->blk_pass, x->blk_pass_off, x->hb_cnt, x->hb_off,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,
                     x->pstage_key, x->pstage_cnt, x->tile_cnt, x->tile_off, x->pass_list, x->seg_info_s[0], x->seg_info_s[1], x->run_val_b,

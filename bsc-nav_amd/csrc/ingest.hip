@@ -6,12 +6,12 @@
 //
 //   k_points    1024 consecutive points per workgroup: geometry (fp64, bit-exact) -> cell / rgb / alpha; atomicMin
 //               claims the first toucher of every still-empty cell, the first claimer (in time) lists the cell as new;
-//               the GROUPS of every wave-round (the lanes of one cell: cell + 64-bit lane mask), per-block counts
+//               per-block counts of passing points and of RUNS (stretches of consecutive points in one cell)
 //   k_keys_pairs (dense.hip) LDS aggregation of (cell, frame, patch) pairs — independent of the ids
 //   k_new_keys + sort + k_new_assign   the new cells ranked by their winning point: id = max_id + rank, as the
 //               sequential max_id++ hands them out (a few thousand cells, not a pass over the points)
-//   k_group_keys  the groups compacted in order j: key = voxel id | (size - 1) << id bits, value = slot
-//   radix sort  of the groups (stable, on the id bits only), one scan of (size, segment head) pairs, k_expand: every
+//   k_runs      one pass over the cells: every run as key = voxel id | (length - 1) << id bits, value = first point
+//   radix sort  of the runs (stable, on the id bits only), one scan of (length, segment head) pairs, k_expand: every
 //               voxel's points in order j, at a fraction of the traffic of sorting the points themselves
 //   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
 //               (h, order of the voxel's latest point)                        (1 quad of lanes / voxel)
@@ -59,67 +59,27 @@ __device__ __forceinline__ int frame_of(const int64_t *offsets, int n_frames, in
 #define FB 1024                 // consecutive points per workgroup
 #define PPT (FB / TPB)          // points per thread, strided by TPB (coalesced rounds)
 
-// GROUPS: the unit of the per-voxel point order.  A group is a set of points of ONE wave-round (64 consecutive points
-// j0 .. j0+63, j0 = 64 * (slot >> 6)) that fall into one cell, named by the 64-bit mask of its lanes; a voxel's points in
-// order j are its groups in slot order, bits ascending.  Runs of consecutive same-cell points are the special case of
-// contiguous masks; merging ALL lanes of a cell into one group matters when depth noise flips a surface between two cells
-// from pixel to pixel (a 16-pixel stretch A B A A B A ... is 8 runs but 2 groups: a quarter of the sort entries).
-// Slots: wave-round w owns slots [64 w, 64 w + 64); it uses the first wr_cnt[w] of them, in order of each group's first
-// lane (any partition of the lanes into same-cell subsets, listed by first lane, keeps the per-voxel order).
-#define GROUP_LOOP_MAX 16       // more distinct cells than this in a wave-round: the runs themselves are the groups (bounded work)
-
-// t-th set bit (t < popcount) of a 64-bit mask
-__device__ __forceinline__ int nth_set_bit(u64 m, int t)
+// Head flags of a block's points: point p (0 <= p < FB, order round-major: p = r * TPB + tid) starts a run when its
+// cell differs from the cell of point p - 1, at the block's first point, and at every multiple of `cap` (a run's
+// length has to fit the bits left beside the voxel id in the sort key).  cells[r] = cell of point r * TPB + tid
+// (-1: no voxel; points beyond P carry -2 so that the last real run ends at P).
+__device__ __forceinline__ void block_heads(const int32_t (&cell)[PPT], int cap_mask, int32_t (*s_edge)[TPB / 64], bool (&head)[PPT])
 {
-    uint32_t x = (uint32_t)m;
-    int base = 0;
-    const int c32 = __popc(x);
-    if (t >= c32) { t -= c32; x = (uint32_t)(m >> 32); base = 32; }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int sh = 16; sh > 0; sh >>= 1) {
-        const int cl = __popc(x & ((1u << sh) - 1u));
-        if (t >= cl) { t -= cl; x >>= sh; base += sh; }
+    for (int r = 0; r < PPT; ++r)
+        if (lane == 63) s_edge[r][wid] = cell[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        int32_t prev = __shfl_up(cell[r], 1);
+        if (lane == 0) {
+            if (wid > 0) prev = s_edge[r][wid - 1];
+            else prev = r > 0 ? s_edge[r - 1][TPB / 64 - 1] : cell[r] - 1;      // block start: forced head
+        }
+        const int p = r * TPB + (int)threadIdx.x;
+        head[r] = prev != cell[r] || (p & cap_mask) == 0;
     }
-    return base;
-}
-
-// groups of one wave-round (cell < 0: the lane has no voxel) -> gcell / gmask at slot0 ..; returns their number (wave-uniform)
-__device__ __forceinline__ int emit_groups(const int32_t cell, const int lane, const int64_t slot0, int32_t *__restrict__ gcell,
-                                           u64 *__restrict__ gmask)
-{
-    const int32_t prev = __shfl_up(cell, 1);
-    const bool valid = cell >= 0;
-    const bool change = lane == 0 || prev != cell;
-    const u64 heads = __ballot(valid && change);
-    if (!heads) return 0;
-    int32_t myc = 0;
-    u64 mym = 0ull;
-    int n = 0;
-    // the distinct cells of the wave-round, in order of their first lane; lane i keeps group i.  `rem`: run heads whose cell
-    // has not been taken yet (later runs of a taken cell drop out with it).
-    u64 rem = heads;
-    while (rem && n < GROUP_LOOP_MAX) {
-        const int l0 = __ffsll((long long)rem) - 1;
-        const int32_t c = __builtin_amdgcn_readlane(cell, l0);
-        const u64 m = __ballot(cell == c);
-        rem &= ~m;
-        if (lane == n) { myc = c; mym = m; }
-        ++n;
-    }
-    if (rem) {
-        // more than GROUP_LOOP_MAX distinct cells (far surfaces, noise): every run is a group — a head lane owns the lanes
-        // up to the next change of cell; lane i fetches the i-th run.  Bounded work whatever the input.
-        n = __popcll(heads);
-        const u64 ends = __ballot(change);
-        const u64 above = lane == 63 ? 0ull : (ends & (~0ull << (lane + 1)));
-        const int end = above ? __ffsll((long long)above) - 1 : 64;
-        const u64 m = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
-        const int src = lane < n ? nth_set_bit(heads, lane) : 0;
-        myc = __shfl(cell, src);
-        mym = ((u64)__shfl((uint32_t)(m >> 32), src) << 32) | (u64)__shfl((uint32_t)m, src);
-    }
-    if (lane < n) { gcell[slot0 + lane] = myc; gmask[slot0 + lane] = mym; }
-    return n;
 }
 
 // FAST: geom_point_fast (pinhole intrinsics, patch tables; GeomConst.fast) — otherwise the generic fma chains.
@@ -128,14 +88,15 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
                                                 const int32_t *__restrict__ idx, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
-                                                const double *__restrict__ alpha_in, int64_t P, float inv_w,
+                                                const double *__restrict__ alpha_in, int64_t P, float inv_w, int cap_mask,
                                                 int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
                                                 PointRec *__restrict__ p_rec, float *__restrict__ p_r2f,
                                                 int32_t *__restrict__ new_cells, int64_t *dscal,
-                                                int32_t *__restrict__ blk_pass)
+                                                int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass)
 {
-    __shared__ int s_pass;
-    if (threadIdx.x == 0) s_pass = 0;
+    __shared__ int32_t s_edge[PPT][TPB / 64];
+    __shared__ int s_heads, s_pass;
+    if (threadIdx.x == 0) { s_heads = 0; s_pass = 0; }
     const int lane = threadIdx.x & 63;
     const int32_t N = gc.H * gc.W;
     int32_t cells[PPT];
@@ -237,43 +198,19 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         }
         cells[r] = cell;
     }
-    // passing points of the block
-    int np = 0;
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) np += __popcll(__ballot(cells[r] >= 0));
-    __syncthreads();                                    // s_pass is initialised
-    if (lane == 0) atomicAdd(&s_pass, np);
-    __syncthreads();
-    if (threadIdx.x == 0) blk_pass[blockIdx.x] = s_pass;
-}
-
-// The groups of the batch (see emit_groups): a memory-bound pass over the cells — 4 bytes per point in, ~12 bytes per group
-// out — so that the loop over a wave-round's distinct cells rides under the loads instead of on top of k_points' fp64 work.
-__global__ __launch_bounds__(TPB) void k_groups(int64_t P, const int32_t *__restrict__ p_cell, int32_t *__restrict__ gcell,
-                                                u64 *__restrict__ gmask, uint8_t *__restrict__ wr_cnt,
-                                                int32_t *__restrict__ blk_groups)
-{
-    __shared__ int s_tot;
-    if (threadIdx.x == 0) s_tot = 0;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int32_t cells[PPT];
+    // runs and passing points of the block
+    bool head[PPT];
+    block_heads(cells, cap_mask, s_edge, head);
+    int nh = 0, np = 0;
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
-        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        cells[r] = j < P ? p_cell[j] : -2;
+        nh += (head[r] && cells[r] != -2) ? 1 : 0;
+        np += cells[r] >= 0 ? 1 : 0;
     }
-    int ng = 0;
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        const int wr = r * (TPB / 64) + wid;            // points [64 wr, 64 wr + 64) of the block
-        const int n = emit_groups(cells[r], lane, (int64_t)blockIdx.x * FB + 64 * wr, gcell, gmask);
-        if (lane == 0) wr_cnt[(int64_t)blockIdx.x * (FB / 64) + wr] = (uint8_t)n;      // n <= 64
-        ng += n;
-    }
+    for (int o = 32; o > 0; o >>= 1) { nh += __shfl_xor(nh, o); np += __shfl_xor(np, o); }
+    if (lane == 0) { atomicAdd(&s_heads, nh); atomicAdd(&s_pass, np); }
     __syncthreads();
-    if (lane == 0) atomicAdd(&s_tot, ng);
-    __syncthreads();
-    if (threadIdx.x == 0) blk_groups[blockIdx.x] = s_tot;
+    if (threadIdx.x == 0) { blk_runs[blockIdx.x] = s_heads; blk_pass[blockIdx.x] = s_pass; }
 }
 
 // scalars of the batch, on the device: run / passing-point totals from the block scans, the new voxels' id range
@@ -329,61 +266,65 @@ __global__ __launch_bounds__(TPB) void k_new_assign(int64_t n, int64_t n_ok, con
     rgb_pos[3 * id + 2] = h;
 }
 
-// ---- groups -> sort entries ------------------------------------------------------------------------------------------
-// One workgroup per 1024-point block: the block's groups compacted in slot order: key = voxel id | (points - 1) << vb,
-// value = slot (names the wave-round, hence j0, and the mask).  Thread t of the block takes its t-th group.
-__global__ __launch_bounds__(TPB) void k_group_keys(int vb, const uint8_t *__restrict__ wr_cnt, const int32_t *__restrict__ gcell,
-                                                    const u64 *__restrict__ gmask, const int32_t *__restrict__ occ,
-                                                    const int32_t *__restrict__ blk_run_off, uint32_t *__restrict__ rkey,
-                                                    uint32_t *__restrict__ rval)
+// ---- runs -----------------------------------------------------------------------------------------------------------
+// One pass over the cells of a block: every run r (in order j) -> sort key = voxel id | (length - 1) << vb (id field all
+// ones: no voxel — invalid depth / outside the grid / over capacity), value = first point.  Runs end inside their block
+// (forced head at every block start), so the length comes from the block's own head bits.  Exact mode: the passing
+// points are listed in order as well.
+__global__ __launch_bounds__(TPB) void k_runs(int64_t P, int vb, int cap_mask, const int32_t *__restrict__ p_cell,
+                                              const int32_t *__restrict__ occ, const int32_t *__restrict__ blk_run_off,
+                                              const int32_t *__restrict__ blk_pass_off, uint32_t *__restrict__ rkey,
+                                              uint32_t *__restrict__ rval, int32_t *__restrict__ pass_list)
 {
-    __shared__ int s_pre[FB / 64 + 1];
-    if (threadIdx.x == 0) {
-        const uint4 raw = *(const uint4 *)(wr_cnt + (int64_t)blockIdx.x * (FB / 64));     // the 16 counts of the block
-        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
-        int run = 0;
-#pragma unroll
-        for (int w = 0; w < FB / 64; ++w) { s_pre[w] = run; run += (int)((w4[w >> 2] >> (8 * (w & 3))) & 0xffu); }
-        s_pre[FB / 64] = run;
-    }
-    __syncthreads();
-    const int total = s_pre[FB / 64];
-    const int32_t base = blk_run_off[blockIdx.x];
-    for (int t = threadIdx.x; t < total; t += TPB) {
-        int w = 0;
-#pragma unroll
-        for (int k = 1; k < FB / 64; ++k) w += t >= s_pre[k] ? 1 : 0;
-        const int64_t slot = (int64_t)blockIdx.x * FB + 64 * w + (t - s_pre[w]);
-        const int32_t v = occ[gcell[slot]];
-        const int len = __popcll(gmask[slot]);
-        rkey[base + t] = (uint32_t)v | ((uint32_t)(len - 1) << vb);
-        rval[base + t] = (uint32_t)slot;
-    }
-}
-
-// exact mode: the passing points of the batch, listed in order j (rows of the token cache, memory_2.py:878-886)
-__global__ __launch_bounds__(TPB) void k_pass_list(int64_t P, const int32_t *__restrict__ p_cell,
-                                                   const int32_t *__restrict__ blk_pass_off, int32_t *__restrict__ pass_list)
-{
-    __shared__ u64 s_pbits[FB / 64];
+    __shared__ int32_t s_edge[PPT][TPB / 64];
+    __shared__ u64 s_hbits[FB / 64], s_pbits[FB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    bool pass[PPT];
+    int32_t cells[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
         const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        pass[r] = j < P && p_cell[j] >= 0;
-        const u64 pb = __ballot(pass[r]);
-        if (lane == 0) s_pbits[r * (TPB / 64) + wid] = pb;
+        cells[r] = j < P ? p_cell[j] : -2;
     }
-    __syncthreads();
-    const int32_t pass_base = blk_pass_off[blockIdx.x];
+    int32_t vid[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) vid[r] = occ[cells[r] > 0 ? cells[r] : 0];       // all loads in flight before use
+    bool head[PPT];
+    block_heads(cells, cap_mask, s_edge, head);
+    // word w = r * 4 + wave covers the points [64 w, 64 w + 64) of the block; points beyond P count as heads (run ends)
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
-        if (!pass[r]) continue;
+        const u64 hb = __ballot(head[r]), pb = __ballot(cells[r] >= 0);
+        if (lane == 0) { s_hbits[r * (TPB / 64) + wid] = hb; s_pbits[r * (TPB / 64) + wid] = pb; }
+    }
+    __syncthreads();
+    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+    const int32_t run_base = blk_run_off[blockIdx.x];
+    const int32_t pass_base = pass_list ? blk_pass_off[blockIdx.x] : 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
         const int w = r * (TPB / 64) + wid;
-        int rank = __popcll(s_pbits[w] & ((1ull << lane) - 1ull));
-        for (int k = 0; k < w; ++k) rank += __popcll(s_pbits[k]);
-        pass_list[pass_base + rank] = (int32_t)((int64_t)blockIdx.x * FB + r * TPB + threadIdx.x);
+        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+        if (cells[r] == -2) continue;
+        const u64 below = (1ull << lane) - 1ull;
+        if (pass_list && cells[r] >= 0) {
+            int rank = __popcll(s_pbits[w] & below);
+            for (int k = 0; k < w; ++k) rank += __popcll(s_pbits[k]);
+            pass_list[pass_base + rank] = (int32_t)j;
+        }
+        if (!head[r]) continue;
+        int rank = __popcll(s_hbits[w] & below);
+        for (int k = 0; k < w; ++k) rank += __popcll(s_hbits[k]);
+        // next head after this point (the block's end otherwise)
+        int nxt = FB;
+        const u64 above = lane == 63 ? 0ull : (s_hbits[w] & (~0ull << (lane + 1)));
+        if (above) nxt = w * 64 + __ffsll((long long)above) - 1;
+        else
+            for (int k = w + 1; k < FB / 64; ++k)
+                if (s_hbits[k]) { nxt = k * 64 + __ffsll((long long)s_hbits[k]) - 1; break; }
+        const int len = nxt - (w * 64 + lane);
+        const int32_t v = cells[r] >= 0 ? vid[r] : -1;
+        rkey[run_base + rank] = v >= 0 ? ((uint32_t)v | ((uint32_t)(len - 1) << vb)) : vmask;
+        rval[run_base + rank] = (uint32_t)j;
     }
 }
 
@@ -871,17 +812,15 @@ __global__ __launch_bounds__(TPB) void k_run_blocksum(int64_t R, int vb, const u
     if (threadIdx.x == 0) blk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// point order: sj[off(i) + t] = j0(i) + (t-th set bit of mask(i)).  One wavefront per 64 sorted entries (16 sets of 64 per
-// block); the outputs of the 64 entries are contiguous, so the lanes walk them with coalesced stores and find their entry by
-// bisection in LDS.  The first entry of a voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
+// point order: sj[off(i) + t] = j0(i) + t.  One wavefront per 64 sorted runs (16 groups of 64 per block); the outputs
+// of the 64 runs are contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.
+// The first run of a voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
 __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_t *__restrict__ rkey_sorted,
-                                                const uint32_t *__restrict__ rval_sorted, const u64 *__restrict__ gmask,
-                                                const int64_t *__restrict__ blk_base,
+                                                const uint32_t *__restrict__ rval_sorted, const int64_t *__restrict__ blk_base,
                                                 uint32_t *__restrict__ sj, int32_t *__restrict__ seg_k0,
                                                 int32_t *__restrict__ seg_vid, int64_t *bscal)
 {
     __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
-    __shared__ u64 s_mask[TPB / 64][64];
     __shared__ int64_t s_grp[EB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
@@ -910,13 +849,10 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
         const int64_t sc = pre + incl[r] - item[r];                 // exclusive prefix of this run
         const int64_t i = (int64_t)blockIdx.x * EB + g * 64 + lane;
         int32_t off = INT_MAX, len = 0, j0 = 0;
-        u64 mask = 0ull;
         if (i < R) {
             const uint32_t key = rkey_sorted[i];
             const uint32_t v = key & vmask;
-            const uint32_t slot = rval_sorted[i];
-            mask = gmask[slot];
-            j0 = (int32_t)(slot & ~63u);                // first point of the group's wave-round
+            j0 = (int32_t)rval_sorted[i];
             off = (int32_t)(sc & 0xffffffffll);
             if (v != vmask) {
                 len = (int32_t)(key >> vb) + 1;
@@ -930,7 +866,6 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
         __builtin_amdgcn_wave_barrier();
         s_off[wid][lane] = len > 0 ? off : INT_MAX;
         s_j0[wid][lane] = j0;
-        s_mask[wid][lane] = mask;
         int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0;
         for (int o = 32; o > 0; o >>= 1) { begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); }
         __builtin_amdgcn_wave_barrier();
@@ -940,7 +875,7 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
 #pragma unroll
             for (int stp = 32; stp > 0; stp >>= 1)
                 if (s_off[wid][lo + stp] <= pnt) lo += stp;
-            sj[pnt] = (uint32_t)(s_j0[wid][lo] + nth_set_bit(s_mask[wid][lo], pnt - s_off[wid][lo]));
+            sj[pnt] = (uint32_t)(s_j0[wid][lo] + (pnt - s_off[wid][lo]));
         }
     }
 }
@@ -1125,9 +1060,11 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         BSC_HIP(hipMemcpyAsync(x->d_offsets, offsets_host, sizeof(int64_t) * (n_frames + 1), hipMemcpyHostToDevice, s));
     BSC_HIP(hipMemsetAsync(x->dscal + DS_B_NNEW, 0, sizeof(int64_t), s));
     GeomConst gc = make_geom_const(x);
-    // a group's size (1..64 points) travels in the key bits beside the voxel id: the id field is sized for the voxel
-    // capacity, 6 bits hold size - 1 (bsc_create refuses capacities beyond 2^26 - 2)
+    // a run's length travels in the key bits beside the voxel id: the id field is sized for the voxel capacity, the
+    // rest (at most 10 bits: runs end with their 1024-point block) holds length - 1
     const int vb = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
+    const int lb = 32 - vb < 10 ? 32 - vb : 10;
+    const int cap_mask = (1 << lb) - 1;
     const int64_t nblk = (P + FB - 1) / FB;
     const dim3 fgrid((unsigned)nblk);
     const bool all_px_dense = !exact && idx == nullptr && x->geom_fast;     // the patch comes from the pixel: no p_patf
@@ -1138,14 +1075,13 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     stat_begin(x, BSC_STAT_POINTS);
     if (gc.fast)
         hipLaunchKernelGGL(k_points<true>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
-                           x->d_transforms, alpha, P, inv_w, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->blk_pass);
+                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
+                           x->dscal, x->blk_cnt, x->blk_pass);
     else
         hipLaunchKernelGGL(k_points<false>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
-                           x->d_transforms, alpha, P, inv_w, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->blk_pass);
+                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
+                           x->dscal, x->blk_cnt, x->blk_pass);
     stat_end(x, BSC_STAT_POINTS, 0.0);
-    hipLaunchKernelGGL(k_groups, fgrid, block, 0, s, P, x->p_cell, x->gcell, x->gmask, x->wr_cnt, x->blk_cnt);
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
@@ -1175,24 +1111,20 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // this call's pair sort and reduce (measured: the first pair-sort pass 0.05 -> 0.84 ms beside a starting chain).
     if (!exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
     stat_begin(x, BSC_STAT_ORDER);
-    // stable radix sort of the GROUPS on the voxel id alone: groups enter in slot order (order j), so each voxel's groups
-    // stay in order; their expansion is the per-voxel point order
+    // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
+    // their expansion is the per-voxel point order
     const int64_t R = x->hscal[DS_B_NRUN];
     uint32_t *sj = x->sval_b_s[set];
-    if (R > 0)
-        hipLaunchKernelGGL(k_group_keys, fgrid, block, 0, s, vb, x->wr_cnt, x->gcell, x->gmask, x->occ, x->blk_off, x->skey_a,
-                           x->sval_a);
-    if (exact) hipLaunchKernelGGL(k_pass_list, fgrid, block, 0, s, P, x->p_cell, x->blk_pass_off, x->pass_list);
-    // ids in use are < max_id
+    hipLaunchKernelGGL(k_runs, fgrid, block, 0, s, P, vb, cap_mask, x->p_cell, x->occ, x->blk_off, x->blk_pass_off, x->skey_a,
+                       x->sval_a, exact ? x->pass_list : (int32_t *)nullptr);
+    // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
-    if (R > 0) {                                  // R == 0: no point of the batch has a voxel (k_totals left 0 segments)
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
-        const int64_t neb = (R + EB - 1) / EB;
-        hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
-        BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->gmask, x->run_scan + neb, sj,
-                           x->seg_k0, x->seg_vid, x->bscal_s[set]);
-    }
+    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+    const int64_t neb = (R + EB - 1) / EB;
+    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
+    BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
+                       x->seg_k0, x->seg_vid, x->bscal_s[set]);
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
     if (n_bound > seg_cap) n_bound = seg_cap;
