@@ -88,6 +88,10 @@ struct bsc_ctx {
     // dense modes
     float *acc;   // (vcap,D)
     int32_t *acnt; // (vcap)
+    // point log for the exact colour merge across ranks (bsc_point_log_*): cells + records of every ingested point
+    int32_t *log_cell;
+    PointRec *log_rec;
+    int64_t log_cap, log_n;
     // ---- per-batch scratch (max_points) ----
     int32_t *p_cell;
     uint32_t *p_patf;

@@ -93,6 +93,7 @@ static bsc_status reset_state(bsc_ctx *x)
     x->pool_n_host = 0;
     x->order_base = 0;
     x->names_dirty = true;
+    x->log_n = 0;
     return BSC_OK;
 }
 
@@ -297,7 +298,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
                     x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
-                    x->fr_centers, x->fr_gains};
+                    x->fr_centers, x->fr_gains, x->log_cell, x->log_rec};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
@@ -738,6 +739,79 @@ extern "C" bsc_status bsc_import_dense(bsc_ctx *x, int64_t max_id, const float *
     BSC_HIP(hipMemcpy(x->acc, acc, sizeof(float) * max_id * x->c.token_dim, hipMemcpyHostToDevice));
     BSC_HIP(hipMemcpy(x->acnt, cnt, sizeof(int32_t) * max_id, hipMemcpyHostToDevice));
     x->names_dirty = true;
+    return BSC_OK;
+}
+
+
+// ---- point log + colour replay (exact rgb / weights across ranks) ------------------------------------------------------
+extern "C" bsc_status bsc_point_log_enable(bsc_ctx *x, int64_t capacity)
+{
+    if (!x || capacity < 0) return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_TRY(sync_all(x));
+    if (x->log_cell) { (void)hipFree(x->log_cell); x->log_cell = nullptr; }
+    if (x->log_rec) { (void)hipFree(x->log_rec); x->log_rec = nullptr; }
+    x->log_cap = 0;
+    x->log_n = 0;
+    if (capacity == 0) return BSC_OK;
+    BSC_HIP(hipMalloc((void **)&x->log_cell, sizeof(int32_t) * (size_t)capacity));
+    BSC_HIP(hipMalloc((void **)&x->log_rec, sizeof(PointRec) * (size_t)capacity));
+    x->log_cap = capacity;
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_point_log_dev(bsc_ctx *x, const int32_t **cells_dev, const uint32_t **records_dev, int64_t *n_points)
+{
+    if (!x || !cells_dev || !records_dev || !n_points) return BSC_E_INVALID;
+    if (!x->log_cap) { bsc_set_error("bsc_point_log_dev: the log is not enabled"); return BSC_E_STATE; }
+    BSC_HIP(hipSetDevice(x->device));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    *cells_dev = x->log_cell;
+    *records_dev = (const uint32_t *)x->log_rec;
+    *n_points = x->log_n;
+    return BSC_OK;
+}
+
+// one thread per voxel: its records [lower_bound(v), lower_bound(v + 1)) replayed from the empty state (memory_2.py:888-899)
+__global__ __launch_bounds__(256) void k_replay_colour(int64_t n, const int32_t *__restrict__ vox, const PointRec *__restrict__ rec,
+                                                       int64_t n_vox, uint8_t *__restrict__ rgb, float *__restrict__ weight)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_vox) return;
+    int64_t lo = 0, hi = n;                       // first record with vox >= v
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (vox[mid] < (int32_t)v) lo = mid + 1; else hi = mid; }
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    float w = 0.f;
+    bool first = true;
+    for (int64_t i = lo; i < n && vox[i] == (int32_t)v; ++i) {
+        const PointRec r = rec[i];
+        const double a = __hiloint2double((int)r.ahi, (int)r.alo);
+        const uint32_t r0 = r.rgbv & 0xffu, r1 = (r.rgbv >> 8) & 0xffu, r2 = (r.rgbv >> 16) & 0xffu;
+        if (first) {                              // :890-894 a new id takes the colour of its first point, weight f32(0 + alpha)
+            c0 = r0; c1 = r1; c2 = r2;
+            w = (float)((double)0.f + a);
+            first = false;
+            continue;
+        }
+        const double den = (double)w + a;         // :896 (f32 + f64); the product u8 * f32 is rounded in f32, the rest f64
+        c0 = (uint32_t)(((double)((float)c0 * w) + (double)r0 * a) / den);
+        c1 = (uint32_t)(((double)((float)c1 * w) + (double)r1 * a) / den);
+        c2 = (uint32_t)(((double)((float)c2 * w) + (double)r2 * a) / den);
+        w = (float)den;                           // :899
+    }
+    rgb[3 * v] = (uint8_t)c0; rgb[3 * v + 1] = (uint8_t)c1; rgb[3 * v + 2] = (uint8_t)c2;
+    weight[v] = w;
+}
+
+extern "C" bsc_status bsc_replay_colour(int64_t n_records, const int32_t *vox_sorted_dev, const uint32_t *records_dev, int64_t n_vox,
+                                        uint8_t *rgb_dev, float *weight_dev, void *hip_stream)
+{
+    if (n_records < 0 || n_vox < 0 || (n_records && (!vox_sorted_dev || !records_dev)) || (n_vox && (!rgb_dev || !weight_dev)))
+        return BSC_E_INVALID;
+    if (n_vox == 0) return BSC_OK;
+    hipLaunchKernelGGL(k_replay_colour, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n_records,
+                       vox_sorted_dev, (const PointRec *)records_dev, n_vox, rgb_dev, weight_dev);
+    BSC_HIP(hipGetLastError());
     return BSC_OK;
 }
 

@@ -1046,6 +1046,10 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         return BSC_E_CAPACITY;
     }
     if (P == 0) return BSC_OK;
+    if (x->log_cap && x->log_n + P > x->log_cap) {
+        bsc_set_error("bsc_ingest: point log full (%lld + %lld > %lld points)", (long long)x->log_n, (long long)P, (long long)x->log_cap);
+        return BSC_E_CAPACITY;
+    }
     const dim3 block(TPB);
     hipStream_t s = x->stream;
     const bool exact = x->c.mode == BSC_MODE_EXACT;
@@ -1082,6 +1086,11 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                            x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
                            x->dscal, x->blk_cnt, x->blk_pass);
     stat_end(x, BSC_STAT_POINTS, 0.0);
+    if (x->log_cap) {           // bsc_point_log_*: the call's cells and records, in order j
+        BSC_HIP(hipMemcpyAsync(x->log_cell + x->log_n, x->p_cell, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
+        BSC_HIP(hipMemcpyAsync(x->log_rec + x->log_n, p_rec, sizeof(PointRec) * (size_t)P, hipMemcpyDeviceToDevice, s));
+        x->log_n += P;
+    }
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,

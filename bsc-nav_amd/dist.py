@@ -156,6 +156,60 @@ def merge_colour_states(rgbs, weights, present):
     return c.to(torch.uint8), w
 
 
+def _all_to_all_rows(rows, dest, group=None):
+    """rows (n, k) int64 with a destination rank per row -> the rows sent to this rank, concatenated in SOURCE-RANK order,
+    each source's rows in their original order.  RCCL: one all_to_all_single with split sizes; gloo (tests): all-gather of
+    everything, then selection."""
+    rank, world = _world(group)
+    order = torch.argsort(dest, stable=True)
+    rows, dest = rows[order].contiguous(), dest[order]
+    if dist.get_backend(group) == "gloo":
+        n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+        sizes = [int(v.item()) for v in _all_gather(n, group)]
+        m = max(sizes + [1])
+        pad_r = torch.zeros((m, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        pad_d = torch.full((m,), -1, dtype=torch.int64, device=rows.device)
+        pad_r[:rows.shape[0]], pad_d[:rows.shape[0]] = rows, dest
+        all_r, all_d = _all_gather(pad_r, group), _all_gather(pad_d, group)
+        return torch.cat([r[d == rank] for r, d in zip(all_r, all_d)])
+    send = torch.bincount(dest, minlength=world).to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    send_l, recv_l = send.tolist(), recv.tolist()
+    out = torch.empty((int(sum(recv_l)), rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(out, rows, output_split_sizes=recv_l, input_split_sizes=send_l, group=group)
+    return out
+
+
+def merge_colour_replay(engine, union, per, group=None):
+    """EXACT colour state of this rank's slice of the merged map ("rgb/weights exact via replay").
+
+    Every rank logged (cell, alpha, rgb) of each point it ingested (engine.point_log_enable before the build).  Frames are
+    sharded in contiguous blocks, so the global point order is (rank, local order).  Each record goes to the rank that owns
+    its voxel (one all-to-all of 24-byte rows); the owner lines the records up voxel by voxel — arrival is in source-rank
+    order and a stable sort by voxel keeps it — and replays the truncating running mean of memory_2.py:888-899 from the
+    empty state (bsc_replay_colour): bit for bit what one process leaves.  -> (rgb (per,3) u8, weight (per,) f32)."""
+    rank, world = _world(group)
+    cells, recs = engine.point_log()
+    gs, nh = engine.cfg.grid_size, engine.nh
+    ok = cells >= 0
+    cells, recs = cells[ok].to(torch.int64), recs[ok]
+    rc, h = cells // nh, cells % nh
+    codes = ((rc // gs) << 42) | ((rc % gs) << 21) | h
+    su, order = torch.sort(union)                                   # union is in first-touch order: sorted view for the lookup
+    upos = order[torch.searchsorted(su, codes)] if codes.numel() else codes
+    dest = upos // max(per, 1)
+    rows = torch.stack([upos, (recs[:, 0].to(torch.int64) & 0xffffffff) | (recs[:, 1].to(torch.int64) << 32),
+                        recs[:, 2].to(torch.int64)], dim=1) if codes.numel() else torch.zeros((0, 3), dtype=torch.int64, device=union.device)
+    got = _all_to_all_rows(rows, dest, group) if _active() else rows
+    local = got[:, 0] - rank * per
+    o = torch.argsort(local, stable=True)
+    got, local = got[o], local[o]
+    rec = torch.stack([(got[:, 1] & 0xffffffff), (got[:, 1] >> 32) & 0xffffffff, got[:, 2]], dim=1)
+    rec = torch.where(rec >= (1 << 31), rec - (1 << 32), rec).to(torch.int32)          # 32-bit words back into int32
+    return engine.replay_colour(local.to(torch.int32), rec, per)
+
+
 def merge_heightmaps(heights, colours):
     """Per-rank top-down maps -> the sequential result.  `h >= max_height` in point order (memory_2.py:901-903) keeps,
     per cell, the LATEST point among those at the greatest height; points of a higher rank come later, so the winner
@@ -216,12 +270,18 @@ def merge_dense_maps(engine, group=None):
     my_acc = reduce_scatter_rows(acc, op, per, group)
     my_cnt = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, per, group)
     mark("reduce_scatter")
-    # colour state: 7 bytes per voxel and rank; every rank gathers the union and merges its own slice
     lo, hi = rank * per, (rank + 1) * per
-    all_rgb = torch.stack(_all_gather(rgb, group))[:, lo:hi]
-    all_w = torch.stack(_all_gather(wgt, group))[:, lo:hi]
-    all_present = torch.stack(_all_gather(cnt, group))[:, lo:hi] > 0
-    my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
+    if getattr(engine, "log_capacity", 0):
+        # the ranks kept their points (sub-sampled modes): exact colour state by replay on the voxel's owner
+        my_rgb, my_w = merge_colour_replay(engine, union, per, group)
+        colour_rule = "replay (exact)"
+    else:
+        # colour state: 7 bytes per voxel and rank; every rank gathers the union and merges its own slice
+        all_rgb = torch.stack(_all_gather(rgb, group))[:, lo:hi]
+        all_w = torch.stack(_all_gather(wgt, group))[:, lo:hi]
+        all_present = torch.stack(_all_gather(cnt, group))[:, lo:hi] > 0
+        my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
+        colour_rule = "per-rank states as observations (approximate)"
     mark("colour")
     # top-down map: gs^2 cells, replicated
     mh, cv = engine.export_heightmap()
@@ -234,7 +294,7 @@ def merge_dense_maps(engine, group=None):
     mark("replace")
     if timing and rank == 0:
         print("[merge] " + " ".join(f"{n}={1e3 * (t - marks[i][1]):.1f}ms" for i, (n, t) in enumerate(marks[1:])), flush=True)
-    return dict(n_union=n_union, per_rank=per, n_local=n_local)
+    return dict(n_union=n_union, per_rank=per, n_local=n_local, colour=colour_rule)
 
 
 def _gather_to_root(t, root, group=None):

@@ -53,6 +53,7 @@ class VoxelEngine:
         h = C.c_void_p()
         _lib.check(self.lib.bsc_create(C.byref(c), device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.h = h
+        self.log_capacity = 0
         self._draw = _lib.DRAW_FN(self._draw_cb)
 
     # memory_2.py:352 — Python's global RNG, one draw per row that meets a full voxel
@@ -322,6 +323,38 @@ class VoxelEngine:
             assert rgb.dtype == torch.uint8 and weight.dtype == torch.float32 and rgb.shape[0] == keys.shape[0]
         self._enter(keys, acc, cnt, rgb, weight)
         _lib.check(self.lib.bsc_dense_replace_full(self.h, keys.shape[0], _dp(keys), _dp(acc), _dp(cnt), _dp(rgb), _dp(weight)))
+
+    # ---- exact colour across ranks: point log + replay (include/bscnav.h bsc_point_log_*, bsc_replay_colour) ----------
+    def point_log_enable(self, capacity):
+        """Keep (cell, alpha, rgb) of every ingested point — 16 B / point, for the sub-sampled modes; 0 disables."""
+        _lib.check(self.lib.bsc_point_log_enable(self.h, int(capacity)))
+        self.log_capacity = int(capacity)
+
+    def point_log(self):
+        """-> (cells (n,) int32, records (n,3) int32 [alpha lo, alpha hi, rgb]) CUDA copies of the log, order of ingestion."""
+        pc, pr, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.bsc_point_log_dev(self.h, C.byref(pc), C.byref(pr), C.byref(n)))
+        cells = torch.empty(n.value, dtype=torch.int32, device=self.device)
+        recs = torch.empty((n.value, 3), dtype=torch.int32, device=self.device)
+        if n.value:
+            hip = torch.cuda.cudart()
+            for dst, src in ((cells, pc), (recs, pr)):
+                err = hip.cudaMemcpy(dst.data_ptr(), src.value, dst.numel() * 4, 3)        # device to device
+                if int(err) != 0:
+                    raise RuntimeError(f"point_log: hipMemcpy failed ({err})")
+        return cells, recs
+
+    def replay_colour(self, vox_sorted, records, n_vox):
+        """Records (n,3) int32 grouped by voxel (vox_sorted (n,) int32 ascending in [0, n_vox)), every voxel's in global point
+        order -> (rgb (n_vox,3) u8, weight (n_vox,) f32): the sequential chain of memory_2.py:888-899 from the empty state."""
+        vox_sorted, records = vox_sorted.contiguous(), records.contiguous()
+        assert vox_sorted.dtype == torch.int32 and records.dtype == torch.int32 and records.shape == (vox_sorted.numel(), 3)
+        rgb = torch.zeros((n_vox, 3), dtype=torch.uint8, device=self.device)
+        w = torch.zeros(n_vox, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.bsc_replay_colour(vox_sorted.numel(), _dp(vox_sorted), _dp(records), int(n_vox), _dp(rgb), _dp(w),
+                                              C.c_void_p(st.cuda_stream)))
+        return rgb, w
 
     def import_heightmap(self, max_height, cv_map):
         gs = self.cfg.grid_size

@@ -349,10 +349,16 @@ class VoxelTokenMemory:
         """Anchor the map frame at `pose` (the scene's first pose) on every rank of a frame-sharded build."""
         self.chain.anchor(pose)
 
+    def enable_point_log(self, capacity_points):
+        """Frame-sharded builds in the sub-sampled modes: keep 16 bytes per ingested point so that merge_shards reproduces
+        rgb / weights bit for bit (dist.merge_colour_replay).  Call on every rank before the first frame."""
+        self.engine.point_log_enable(capacity_points)
+
     def merge_shards(self, group=None, root=0):
         """Dense modes: merge the per-rank maps (one reduce-scatter over RCCL, dist.merge_dense_maps) and collect the
         result on `root`, whose object then holds the whole memory — ids in the single-process first-touch order,
-        features / counts reduced, rgb / weights by the documented merge rule, top-down map exact — ready for
+        features / counts reduced, rgb / weights exact when the ranks kept their points (enable_point_log), otherwise by the
+        documented approximate rule, top-down map exact — ready for
         save_memory().  base_height and long_memory entries are concatenated in rank order.  -> True on root."""
         import torch.distributed as tdist
         from . import dist as bdist

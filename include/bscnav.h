@@ -185,6 +185,24 @@ bsc_status bsc_dense_replace(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, c
 bsc_status bsc_dense_replace_full(bsc_ctx *ctx, int64_t n, const int32_t *keys_dev, const float *acc_dev,
                                   const int32_t *cnt_dev, const uint8_t *rgb_dev, const float *weight_dev);
 bsc_status bsc_import_heightmap(bsc_ctx *ctx, const double *max_height_host, const uint8_t *cv_map_host);
+/* Exact colour across ranks (SURVEY.md §8e "rgb/weights exact via replay"; memory_2.py:888-899 defines the state).
+ * The running colour mean truncates at every step, so per-rank results cannot be combined; what can be exchanged is the
+ * points themselves.  With the log enabled every bsc_ingest call appends, for each point of the call in order j, its cell
+ * ((row*gs + col)*(max_h-min_h) + h, or < 0: no voxel) and its 12-byte record {alpha f64 as lo/hi words, rgb packed
+ * r | g<<8 | b<<16} — 16 bytes per point, meant for the sub-sampled modes (depth_sample_rate >= 50: a few thousand points per
+ * frame).  The host sends each record to the rank that owns its voxel (torch.distributed all-to-all), the owner lists the
+ * records voxel by voxel in global order (rank, then local order) and replays the chain:
+ *   bsc_point_log_enable  allocate room for `capacity` points (0 disables and frees); cleared by bsc_reset
+ *   bsc_point_log_dev     device views of the log: cells (n) i32, records (n,3) u32, n points so far; an ingest call that
+ *                         would overflow the log fails with BSC_E_CAPACITY before anything is changed
+ *   bsc_replay_colour     stateless: n records sorted by voxel (vox_sorted ascending, values in [0, n_vox)), each voxel's
+ *                         records in global point order -> rgb (n_vox,3) u8, weight (n_vox) f32 exactly as the sequential
+ *                         loop leaves them (first point: colour copied, weight f32(0 + alpha); then
+ *                         c = u8(trunc((f32(c*w) + r*alpha) / (w + alpha))), w = f32(w + alpha)); voxels without records: 0 */
+bsc_status bsc_point_log_enable(bsc_ctx *ctx, int64_t capacity);
+bsc_status bsc_point_log_dev(bsc_ctx *ctx, const int32_t **cells_dev, const uint32_t **records_dev, int64_t *n_points);
+bsc_status bsc_replay_colour(int64_t n_records, const int32_t *vox_sorted_dev, const uint32_t *records_dev, int64_t n_vox,
+                             uint8_t *rgb_dev, float *weight_dev, void *hip_stream);
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
 bsc_status bsc_keys_dev(bsc_ctx *ctx, const int32_t **keys_dev, int64_t *max_id);
 

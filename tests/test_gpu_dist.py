@@ -151,7 +151,7 @@ def test_rccl_world1_merge_gather_localize(tmp_path, mode):
         p0, s0, n0 = mem.engine.localize(q, K=40)
         info = bd.merge_dense_maps(mem.engine)
         n = before[0][0].shape[0]
-        assert info == dict(n_union=n, per_rank=n, n_local=n)
+        assert {k: info[k] for k in ("n_union", "per_rank", "n_local")} == dict(n_union=n, per_rank=n, n_local=n)
         sp, ss = bd.localize_sharded(mem.engine, q, K=40)
         assert bd.gather_merged_to_root(mem.engine, info) is True
         assert mem.merge_shards() is True                 # the public entry: merge + gather + long-memory lists
@@ -167,6 +167,99 @@ def test_rccl_world1_merge_gather_localize(tmp_path, mode):
         assert torch.equal(bd.reduce_scatter_rows(rows.to(torch.int32), dist.ReduceOp.SUM, 6), rows.to(torch.int32))
         parts = bd.all_gather_ragged(torch.arange(5, dtype=torch.int64, device="cuda"))
         assert len(parts) == 1 and parts[0].tolist() == [0, 1, 2, 3, 4]
+        mem.engine.close()
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- exact colour across ranks: sub-sampled build, point log, owner-side replay ---------------------------
+RATE = 50
+
+
+def _sampled_args(tmp, name):
+    a = _args(tmp, name)
+    a.depth_sample_rate = RATE
+    return a
+
+
+def _replay_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bsc_nav_amd as B
+    from bsc_nav_amd import dist as bd
+    from bsc_nav_amd.geometry import sample_indices_fast
+    rgb, depth, poses, tokens = _inputs()
+    mem = B.VoxelTokenMemory(_sampled_args(out_dir, "merged"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+                             voxel_capacity=100_000)
+    mem.enable_point_log(F * H * W)
+    mem.set_map_origin(poses[0])
+    a, b = bd.shard_frames(F)
+    np.random.seed(3)
+    for _ in range(a):                                              # the shuffles the earlier ranks' frames consume
+        sample_indices_fast(H * W, RATE)
+    dev = lambda x: torch.from_numpy(x[a:b]).cuda().contiguous()   # noqa: E731
+    mem.ingest_frames(dev(rgb), dev(depth), poses[a:b], tokens=dev(tokens))
+    if mem.merge_shards(root=0):
+        pos, c, w = mem.engine.export_rgb()
+        acc, cnt = mem.engine.export_dense()
+        np.savez(f"{out_dir}/replay_root.npz", pos=pos, rgb=c, w=w, cnt=cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_colour_replay_is_bit_exact(tmp_path):
+    """depth_sample_rate = 50, two ranks, point log on: ids, counts AND rgb bytes / weights of the merged memory equal the
+    single-process build bit for bit (the owner of every voxel replays its points in global order)."""
+    import torch
+    import torch.multiprocessing as mp
+    import bsc_nav_amd as B
+    mp.spawn(_replay_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(f"{tmp_path}/replay_root.npz")
+    rgb, depth, poses, tokens = _inputs()
+    one = B.VoxelTokenMemory(_sampled_args(tmp_path, "single"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+                             voxel_capacity=100_000)
+    np.random.seed(3)
+    one.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+    pos, c, w = one.engine.export_rgb()
+    assert len(pos) > 1000 and np.array_equal(got["pos"], pos)
+    assert np.array_equal(got["rgb"], c) and np.array_equal(got["w"], w)           # exact, not "close"
+    assert np.array_equal(got["cnt"], one.engine.export_dense()[1])
+    # the replay kernel alone against the engine's own chain: all points of the single-process build, grouped by voxel
+    one2 = B.VoxelTokenMemory(_sampled_args(tmp_path, "single2"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+                              voxel_capacity=100_000)
+    one2.enable_point_log(F * H * W)
+    np.random.seed(3)
+    one2.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+    from bsc_nav_amd import dist as bd
+    keys = one2.engine.keys_tensor()
+    r2, w2 = bd.merge_colour_replay(one2.engine, bd.pack_keys(keys), len(pos))
+    assert np.array_equal(r2.cpu().numpy(), c) and np.array_equal(w2.cpu().numpy(), w)
+
+
+def test_rccl_world1_colour_replay(tmp_path):
+    """The all-to-all of the colour replay through RCCL (`all_to_all_single` with split sizes) on a one-rank group: the
+    merged rgb / weights equal the chain's own result bit for bit."""
+    import torch
+    import torch.distributed as dist
+    import bsc_nav_amd as B
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        rgb, depth, poses, tokens = _inputs()
+        mem = B.VoxelTokenMemory(_sampled_args(tmp_path, "w1r"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+                                 voxel_capacity=100_000)
+        mem.enable_point_log(F * H * W)
+        np.random.seed(3)
+        mem.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+        before = mem.engine.export_rgb()
+        from bsc_nav_amd import dist as bd
+        info = bd.merge_dense_maps(mem.engine)
+        assert info["colour"].startswith("replay")
+        after = mem.engine.export_rgb()
+        assert len(before[0]) > 1000 and all(np.array_equal(a, b) for a, b in zip(before, after))
         mem.engine.close()
     finally:
         dist.destroy_process_group()
