@@ -61,7 +61,7 @@ SIGNATURES = {
     "bsc_import_heightmap": (_I32, [_VP, _VP, _VP]),
     "bsc_keys_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "bsc_point_log_enable": (_I32, [_VP, _I64]),
-    "bsc_point_log_dev": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_I64)]),
+    "bsc_point_log_read": (_I32, [_VP, _VP, _VP, _I64, C.POINTER(_I64)]),
     "bsc_replay_colour": (_I32, [_I64, _VP, _VP, _I64, _VP, _VP, _VP]),
     "bsc_kernel_stats": (_I32, [_VP, _I32, _I32, _VP]),
     "bsc_sync": (_I32, [_VP]),

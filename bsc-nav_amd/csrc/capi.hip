@@ -760,15 +760,19 @@ extern "C" bsc_status bsc_point_log_enable(bsc_ctx *x, int64_t capacity)
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_point_log_dev(bsc_ctx *x, const int32_t **cells_dev, const uint32_t **records_dev, int64_t *n_points)
+extern "C" bsc_status bsc_point_log_read(bsc_ctx *x, int32_t *cells_out_dev, uint32_t *records_out_dev, int64_t capacity,
+                                         int64_t *n_points)
 {
-    if (!x || !cells_dev || !records_dev || !n_points) return BSC_E_INVALID;
-    if (!x->log_cap) { bsc_set_error("bsc_point_log_dev: the log is not enabled"); return BSC_E_STATE; }
+    if (!x || !n_points || capacity < 0) return BSC_E_INVALID;
+    if (!x->log_cap) { bsc_set_error("bsc_point_log_read: the log is not enabled"); return BSC_E_STATE; }
     BSC_HIP(hipSetDevice(x->device));
-    BSC_HIP(hipStreamSynchronize(x->stream));
-    *cells_dev = x->log_cell;
-    *records_dev = (const uint32_t *)x->log_rec;
     *n_points = x->log_n;
+    const int64_t n = x->log_n < capacity ? x->log_n : capacity;
+    if (n > 0 && cells_out_dev)
+        BSC_HIP(hipMemcpyAsync(cells_out_dev, x->log_cell, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, x->stream));
+    if (n > 0 && records_out_dev)
+        BSC_HIP(hipMemcpyAsync(records_out_dev, x->log_rec, sizeof(PointRec) * (size_t)n, hipMemcpyDeviceToDevice, x->stream));
+    BSC_HIP(hipStreamSynchronize(x->stream));
     return BSC_OK;
 }
 

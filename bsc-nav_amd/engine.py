@@ -332,16 +332,13 @@ class VoxelEngine:
 
     def point_log(self):
         """-> (cells (n,) int32, records (n,3) int32 [alpha lo, alpha hi, rgb]) CUDA copies of the log, order of ingestion."""
-        pc, pr, n = C.c_void_p(), C.c_void_p(), C.c_int64()
-        _lib.check(self.lib.bsc_point_log_dev(self.h, C.byref(pc), C.byref(pr), C.byref(n)))
+        n = C.c_int64()
+        _lib.check(self.lib.bsc_point_log_read(self.h, None, None, 0, C.byref(n)))
         cells = torch.empty(n.value, dtype=torch.int32, device=self.device)
         recs = torch.empty((n.value, 3), dtype=torch.int32, device=self.device)
-        if n.value:
-            hip = torch.cuda.cudart()
-            for dst, src in ((cells, pc), (recs, pr)):
-                err = hip.cudaMemcpy(dst.data_ptr(), src.value, dst.numel() * 4, 3)        # device to device
-                if int(err) != 0:
-                    raise RuntimeError(f"point_log: hipMemcpy failed ({err})")
+        self._enter(cells, recs)
+        _lib.check(self.lib.bsc_point_log_read(self.h, _dp(cells), _dp(recs), n.value, C.byref(n)))
+        self._leave()
         return cells, recs
 
     def replay_colour(self, vox_sorted, records, n_vox):

@@ -193,14 +193,16 @@ bsc_status bsc_import_heightmap(bsc_ctx *ctx, const double *max_height_host, con
  * frame).  The host sends each record to the rank that owns its voxel (torch.distributed all-to-all), the owner lists the
  * records voxel by voxel in global order (rank, then local order) and replays the chain:
  *   bsc_point_log_enable  allocate room for `capacity` points (0 disables and frees); cleared by bsc_reset
- *   bsc_point_log_dev     device views of the log: cells (n) i32, records (n,3) u32, n points so far; an ingest call that
- *                         would overflow the log fails with BSC_E_CAPACITY before anything is changed
+ *   bsc_point_log_read    *n_points = points logged so far; when the output pointers are given, the first min(n, capacity)
+ *                         entries are copied to the caller's device buffers: cells (n) i32, records (n,3) u32.  An ingest
+ *                         call that would overflow the log fails with BSC_E_CAPACITY before anything is changed
  *   bsc_replay_colour     stateless: n records sorted by voxel (vox_sorted ascending, values in [0, n_vox)), each voxel's
  *                         records in global point order -> rgb (n_vox,3) u8, weight (n_vox) f32 exactly as the sequential
  *                         loop leaves them (first point: colour copied, weight f32(0 + alpha); then
  *                         c = u8(trunc((f32(c*w) + r*alpha) / (w + alpha))), w = f32(w + alpha)); voxels without records: 0 */
 bsc_status bsc_point_log_enable(bsc_ctx *ctx, int64_t capacity);
-bsc_status bsc_point_log_dev(bsc_ctx *ctx, const int32_t **cells_dev, const uint32_t **records_dev, int64_t *n_points);
+bsc_status bsc_point_log_read(bsc_ctx *ctx, int32_t *cells_out_dev, uint32_t *records_out_dev, int64_t capacity,
+                              int64_t *n_points);
 bsc_status bsc_replay_colour(int64_t n_records, const int32_t *vox_sorted_dev, const uint32_t *records_dev, int64_t n_vox,
                              uint8_t *rgb_dev, float *weight_dev, void *hip_stream);
 /* device views for the host-side collective: voxel keys (max_id,3) i32 */
