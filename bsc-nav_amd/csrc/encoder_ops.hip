@@ -4,7 +4,6 @@
 //     s = x + delta (bf16) ; y = LayerNorm(s) * gamma + beta            one wavefront per token row
 // Stateless entry point, launched on the caller's stream (captured into the encoder's HIP graph).
 #include "bsc_internal.h"
-#include <type_traits>
 
 #define TPB 256
 
@@ -765,213 +764,6 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
     }
 }
 
-// ---- k_attention2: the same product, organised around the LDS pipe -----------------------------------------------------------
-// PMC of k_attention (round 3, scripts/attention_only.py): waves wait 50 % of their cycles (s_waitcnt / barriers), stall
-// on issue 25 %, issue 25 %; per (image, head) item the LDS pipe is busy ~8 k of 28 k CU-cycles (every 16-query strip re-reads
-// all of K and V^T, 22 % of the LDS cycles are bank conflicts), VALU 6 k, MFMA 3 k — one workgroup of 7 wavefronts per CU has
-// nothing to run while it waits.  This kernel:
-//   * 4 wavefronts per workgroup, TWO workgroups per CU (K + V^T of one item = 62 KB of LDS): one loads while the other computes;
-//   * every wavefront takes up to NG query strips AT ONCE: a K or V^T fragment read from LDS feeds NG MFMAs (LDS reads / NG),
-//     and the NG independent strips are the instruction-level parallelism that covers MFMA and LDS latency;
-//   * two passes over the keys instead of NT score tiles in registers: pass 1 computes S = K Q^T tile by tile for the row
-//     maxima only, pass 2 computes it again, exponentiates against the final maximum and feeds P V — the score registers drop
-//     from 4 NT to 8 per strip (the matrix cores were 10 % busy: the second QK^T is free), the arithmetic is the same;
-//   * Q fragments come straight from global memory in MFMA layout (two 16-byte loads per strip and lane): no Q tile in LDS.
-template <int NT, int NG>
-__global__ __launch_bounds__(256, 2) void k_attention2(const uint16_t *__restrict__ qkv, int T, int H, int items,
-                                                       uint16_t *__restrict__ out, int *work)
-{
-    __shared__ int s_ticket;
-    constexpr int NTHR = 256, NW = 4;
-    constexpr int TP = NT * 16;
-    constexpr int KP = 64 + 8;                              // K row pitch (bf16 elements)
-    constexpr int VP = 4 * (((TP / 4 - 1) | 7) + 1) + 8;    // V^T row pitch: granules of 4 keys (xor-swizzled) + pad
-    constexpr int NLD = (TP * 8 + NTHR - 1) / NTHR;         // 16-byte pieces of K (and of V) per thread
-    __shared__ __attribute__((aligned(16))) uint16_t sK[TP * KP];
-    __shared__ __attribute__((aligned(16))) uint16_t sVt[64 * VP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const int64_t tok_stride = (int64_t)3 * H * 64;                 // elements between consecutive tokens
-    const float c = 0.125f * 1.44269504088896340736f;               // 1/sqrt(64) * log2(e)
-    // strips beyond the sequence (13 of 16 are real at T = 197) are computed on clamped rows and dropped at the store:
-    // straight-line code, no per-strip branches between the MFMAs
-
-    int item = blockIdx.x;
-    if (work) {
-        if (tid == 0) s_ticket = atomicAdd(&work[0], 1);
-        __syncthreads();
-        item = s_ticket;
-    }
-    int nxt = item;
-    for (; item < items; item = nxt) {
-        const int b = item / H, h = item % H;
-        const uint16_t *Qp = qkv + (int64_t)b * T * tok_stride + (int64_t)h * 64;
-        const uint16_t *Kp = Qp + (int64_t)H * 64, *Vp = Qp + (int64_t)2 * H * 64;
-        // ---- K, V of the item: global -> registers (all loads in flight together) -> LDS ----------------------------------
-        uint4 kr[NLD], vr[NLD];
-#pragma unroll
-        for (int r = 0; r < NLD; ++r) {
-            const int idx = tid + NTHR * r;
-            const int t = idx >> 3, ch = idx & 7;
-            const int tc = t < T ? t : T - 1;
-            kr[r] = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + ch * 8);
-            vr[r] = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + ch * 8);
-        }
-        // the strips of this wavefront: wave, wave + 4, ...; their Q fragments (B operand: query n, features kk*32 + g*8 ..)
-        bf16x8_t bq[NG][2];
-#pragma unroll
-        for (int s = 0; s < NG; ++s) {
-            const int q = (wave + NW * s) * 16 + n;
-            const int qc = q < T ? q : T - 1;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bq[s][kk] = *(const bf16x8_t *)(Qp + (int64_t)qc * tok_stride + kk * 32 + g * 8);
-        }
-        __syncthreads();                                            // the previous item's strips are done with LDS
-#pragma unroll
-        for (int r = 0; r < NLD; ++r) {
-            const int idx = tid + NTHR * r;
-            const int t = idx >> 3, ch = idx & 7;
-            if (idx < TP * 8) {
-                const bool in = t < T;
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                *(uint4 *)&sK[t * KP + ch * 8] = in ? kr[r] : z;
-                const uint4 v = in ? vr[r] : z;
-                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-                // V^T[d][t] lives at granule (t >> 2) ^ (d >> 3) of row d (see k_attention)
-                const int col = 4 * ((t >> 2) ^ ch) + (t & 3);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sVt[(ch * 8 + 2 * e) * VP + col] = (uint16_t)(vv[e] & 0xffffu);
-                    sVt[(ch * 8 + 2 * e + 1) * VP + col] = (uint16_t)(vv[e] >> 16);
-                }
-            }
-        }
-        if (work && tid == 0) s_ticket = atomicAdd(&work[0], 1);    // everyone has read the previous ticket (barrier above)
-        __syncthreads();
-        nxt = work ? s_ticket : item + (int)gridDim.x;
-        // ---- pass 1: row maxima -------------------------------------------------------------------------------------------
-        // padded keys (>= T) sit in the last two tiles only (T > 16 (NT - 2)): the loops over the unpadded tiles carry no masking
-        float mx[NG];
-#pragma unroll
-        for (int s = 0; s < NG; ++s) mx[s] = -INFINITY;
-        auto max_tile = [&](const int t, auto masked) {
-            const bf16x8_t a0 = *(const bf16x8_t *)&sK[(t * 16 + n) * KP + g * 8];
-            const bf16x8_t a1 = *(const bf16x8_t *)&sK[(t * 16 + n) * KP + 32 + g * 8];
-#pragma unroll
-            for (int s = 0; s < NG; ++s) {
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[s][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[s][1], acc, 0, 0, 0);
-                if (decltype(masked)::value) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (t * 16 + g * 4 + i >= T) acc[i] = -INFINITY;
-                }
-                mx[s] = fmaxf(mx[s], fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-            }
-        };
-#pragma unroll 1
-        for (int t = 0; t < NT - 2; ++t) max_tile(t, std::false_type{});     // rolled: the NG strips are the parallelism
-        max_tile(NT - 2, std::true_type{});
-        max_tile(NT - 1, std::true_type{});
-        float nmc[NG], sum[NG];
-        f32x4_t o[NG][4];
-#pragma unroll
-        for (int s = 0; s < NG; ++s) {
-            float m = mx[s];
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            nmc[s] = -m * c;
-            sum[s] = 0.f;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[s][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- pass 2: P = exp2((S - m) c), O += P V, 32 keys per step ------------------------------------------------------------
-        int v0o[4], v1o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d = dt * 16 + n;
-            v0o[dt] = d * VP + 4 * (g ^ (d >> 3));
-            v1o[dt] = d * VP + 4 * ((4 + g) ^ (d >> 3));
-        }
-        auto pv_step = [&](const int ks, auto masked) {
-            bf16x8_t ka[2][2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                ka[u][0] = *(const bf16x8_t *)&sK[((2 * ks + u) * 16 + n) * KP + g * 8];
-                ka[u][1] = *(const bf16x8_t *)&sK[((2 * ks + u) * 16 + n) * KP + 32 + g * 8];
-            }
-            bf16x8_t vb[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint2 v0 = *(const uint2 *)&sVt[v0o[dt] + 32 * ks], v1 = *(const uint2 *)&sVt[v1o[dt] + 32 * ks];
-                uint4 vq = make_uint4(v0.x, v0.y, v1.x, v1.y);
-                vb[dt] = *(bf16x8_t *)&vq;
-            }
-#pragma unroll
-            for (int s = 0; s < NG; ++s) {
-                f32x4_t e[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[u][0], bq[s][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[u][1], bq[s][1], acc, 0, 0, 0);
-                    if (decltype(masked)::value) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if ((2 * ks + u) * 16 + g * 4 + i >= T) acc[i] = -INFINITY;
-                    }
-                    const f32x4_t cv = {c, c, c, c}, nm = {nmc[s], nmc[s], nmc[s], nmc[s]};
-                    f32x4_t x = __builtin_elementwise_fma(acc, cv, nm);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]);
-                    e[u] = x;
-                    sum[s] += (x[0] + x[1]) + (x[2] + x[3]);
-                }
-                uint4 pa;
-                pa.x = pack_bf16(e[0][0], e[0][1]);
-                pa.y = pack_bf16(e[0][2], e[0][3]);
-                pa.z = pack_bf16(e[1][0], e[1][1]);
-                pa.w = pack_bf16(e[1][2], e[1][3]);
-                const bf16x8_t a = *(bf16x8_t *)&pa;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vb[dt], o[s][dt], 0, 0, 0);
-            }
-        };
-#pragma unroll 1
-        for (int ks = 0; ks < NT / 2 - 1; ++ks) pv_step(ks, std::false_type{});
-        pv_step(NT / 2 - 1, std::true_type{});
-        // ---- o[s][dt][i] = O[query q0 + 4g + i][d = 16 dt + n]; the row sums sit with the lanes whose n is that query ----------
-#pragma unroll
-        for (int s = 0; s < NG; ++s) {
-            float l = sum[s];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            const float inv = 1.f / l;
-            const int q0 = (wave + NW * s) * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = __shfl(inv, g * 4 + i);
-                const int q = q0 + g * 4 + i;
-                if (q < T) {
-                    uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + n;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (uint16_t)(pack_bf16(o[s][dt][i] * r, 0.f) & 0xffffu);
-                }
-            }
-        }
-    }
-    // the last workgroup to leave re-arms the counters for the next launch on this stream
-    if (work && tid == 0) {
-        __threadfence();
-        if (atomicAdd(&work[1], 1) == (int)gridDim.x - 1) {
-            work[0] = 0;
-            work[1] = 0;
-            __threadfence();
-        }
-    }
-}
-
 extern "C" bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                                             void *out_dev, int32_t *work2_dev, void *hip_stream)
 {
@@ -988,18 +780,6 @@ extern "C" bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int3
         BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int64_t items = (int64_t)B * heads;
-    static const bool v1 = getenv("BSC_ENC_ATTENTION_V1") != nullptr;       // A/B: the round-2 kernel (one workgroup of 7-8 waves per CU)
-    if (!v1) {
-        const dim3 grid2((unsigned)(items < 2 * n_cu ? items : 2 * n_cu));
-        if (T <= 224)
-            hipLaunchKernelGGL((k_attention2<14, 4>), grid2, dim3(256), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
-                               (uint16_t *)out_dev, (int *)work2_dev);
-        else
-            hipLaunchKernelGGL((k_attention2<18, 5>), grid2, dim3(256), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
-                               (uint16_t *)out_dev, (int *)work2_dev);
-        BSC_HIP(hipGetLastError());
-        return BSC_OK;
-    }
     const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
     if (T <= 224)
         hipLaunchKernelGGL((k_attention<14, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
