@@ -70,6 +70,7 @@ static bsc_status reset_state(bsc_ctx *x)
     x->last_chain_set = -1;
     if (x->side) BSC_HIP(hipStreamSynchronize(x->side));
     x->ev_done_valid[0] = x->ev_done_valid[1] = false;
+    x->ev_runs_valid = false;
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
     const int64_t vcap = x->c.voxel_capacity;
     fill<int32_t>(x, x->occ, x->ncell, -1);                                     // memory_2.py:717
@@ -271,6 +272,11 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
     hipError_t e = hipMalloc(&x->prim_tmp, x->prim_tmp_bytes);
     if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
+    e = hipMalloc(&x->prim_tmp_side, x->prim_tmp_bytes);
+    if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
+    x->order_on_side = getenv("BSC_ORDER_MAIN") == nullptr;
+    BSC_HIP(hipEventCreateWithFlags(&x->ev_ids, hipEventDisableTiming));
+    BSC_HIP(hipEventCreateWithFlags(&x->ev_runs, hipEventDisableTiming));
     for (int w = 0; w < BSC_STAT_SLOTS; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i) BSC_HIP(hipEventCreate(&x->ev[w][i]));
     x->timing = true;
@@ -296,13 +302,15 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
-                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
+                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
                     x->fr_centers, x->fr_gains, x->log_cell, x->log_rec};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);
     if (x->side) hipStreamDestroy(x->side);
+    if (x->ev_ids) hipEventDestroy(x->ev_ids);
+    if (x->ev_runs) hipEventDestroy(x->ev_runs);
     for (int k = 0; k < 2; ++k) {
         if (x->ev_ready[k]) hipEventDestroy(x->ev_ready[k]);
         if (x->ev_done[k]) hipEventDestroy(x->ev_done[k]);

@@ -1058,6 +1058,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     const int set = x->cur_set;
     x->cur_set ^= 1;
     if (x->ev_done_valid[set]) BSC_HIP(hipStreamWaitEvent(s, x->ev_done[set], 0));
+    if (x->ev_runs_valid) BSC_HIP(hipStreamWaitEvent(s, x->ev_runs, 0));      // the last call's k_runs (side stream) is done with p_cell / blk_off
     PointRec *p_rec = x->p_rec_s[set];
     uint32_t *skey_b = x->skey_b_s[set];
     if (idx)
@@ -1115,37 +1116,57 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
         return BSC_E_CAPACITY;
     }
-    // dense feature reduce first: it only needs the ids.  The rgb chain is launched at the very end of the call, so that
-    // its bulk phase (thousands of quads stepping) overlaps the head of the NEXT call instead of
-    // this call's pair sort and reduce (measured: the first pair-sort pass 0.05 -> 0.84 ms beside a starting chain).
-    if (!exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
-    stat_begin(x, BSC_STAT_ORDER);
+    // The per-voxel point order (k_runs .. k_seg_order) feeds only the rgb chain, which runs on the side stream anyway: it is
+    // enqueued THERE, as soon as the ids exist, and runs beside the pair sort / dense reduce of this call on the main stream.
+    // Both halves are chains of short memory-bound kernels with launch gaps between them; side by side each fills the other's
+    // gaps (own rocPRIM workspace, disjoint buffers).  BSC_ORDER_MAIN=1: one stream, as in round 2.
+    const bool side_order = x->order_on_side;
+    hipStream_t so = side_order ? x->side : s;
+    if (side_order) {
+        BSC_HIP(hipEventRecord(x->ev_ids, s));
+        BSC_HIP(hipStreamWaitEvent(so, x->ev_ids, 0));
+    } else if (!exact) {
+        BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    }
+    // order-pipeline launches go through the ctx's stream / workspace fields
+    void *const prim_main = x->prim_tmp;
+    if (side_order) { x->stream = so; x->prim_tmp = x->prim_tmp_side; }
+    const bsc_status order_st = [&]() -> bsc_status {
+    stat_begin(x, BSC_STAT_ORDER, so);
     // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
     // their expansion is the per-voxel point order
     const int64_t R = x->hscal[DS_B_NRUN];
     uint32_t *sj = x->sval_b_s[set];
-    hipLaunchKernelGGL(k_runs, fgrid, block, 0, s, P, vb, cap_mask, x->p_cell, x->occ, x->blk_off, x->blk_pass_off, x->skey_a,
+    hipLaunchKernelGGL(k_runs, fgrid, block, 0, so, P, vb, cap_mask, x->p_cell, x->occ, x->blk_off, x->blk_pass_off, x->skey_a,
                        x->sval_a, exact ? x->pass_list : (int32_t *)nullptr);
+    if (side_order) { BSC_HIP(hipEventRecord(x->ev_runs, so)); x->ev_runs_valid = true; }
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
     const int64_t neb = (R + EB - 1) / EB;
-    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_scan);
+    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan);
     BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, s, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
                        x->seg_k0, x->seg_vid, x->bscal_s[set]);
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
     if (n_bound > seg_cap) n_bound = seg_cap;
-    hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, s, x->bscal_s[set], n_bound, x->seg_k0, x->seg_vid,
+    hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, so, x->bscal_s[set], n_bound, x->seg_k0, x->seg_vid,
                        x->seg_info_s[set], x->skey_a, x->sval_a);
     if (n_bound > 0)
         BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
     static const int long_log2 = getenv("BSC_LONG_LOG2") ? atoi(getenv("BSC_LONG_LOG2")) : LONG_MIN_LOG2;
     static const int hot_log2 = getenv("BSC_NO_HOT_SPLIT") ? 0 : (getenv("BSC_HOT_LOG2") ? atoi(getenv("BSC_HOT_LOG2")) : HOT_MIN_LOG2);
-    hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, s, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,
+    hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, so, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,
                        x->seg_info_s[set], x->long_chain ? long_log2 : 0, hot_log2);
-    stat_end(x, BSC_STAT_ORDER, 0.0);
+    stat_end(x, BSC_STAT_ORDER, 0.0, so);
+    return BSC_OK;
+    }();
+    x->stream = s;
+    x->prim_tmp = prim_main;
+    BSC_TRY(order_st);
+    if (side_order && !exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    if (side_order && exact) BSC_HIP(hipStreamWaitEvent(s, x->ev_runs, 0));       // k_append reads the pass list k_runs wrote
     // rgb chain + top-down map: sequential-latency bound, on the library's side stream — and DEFERRED: the
     // call only marks its point order ready; the kernels are launched at the start of the next bsc_ingest (or by whatever
     // needs their result first: exports, merges, resets — sync_all).  The chain's long tail (one voxel seen in every frame
@@ -1153,7 +1174,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // caller's encoder: its few resident wavefronts are harmless beside streaming kernels, but a library GEMM that splits
     // its work statically over all 256 CUs (stream-K) runs up to twice as long while any CU is held by a chain wavefront
     // (measured: 26.4 -> 22.3 ms per 384-frame step without the chain beside the encoder).
-    BSC_HIP(hipEventRecord(x->ev_ready[set], s));
+    BSC_HIP(hipEventRecord(x->ev_ready[set], so));
     x->chain_pending = true;
     x->chain_set = set;
     x->chain_order_base = x->order_base;
