@@ -21,7 +21,7 @@ for rep in range(2):
     y.copy_(x)                                                 # copy: stream read + stream write
     y.fill_(2.0)                                               # fill: stream write
     g4 = x.view(-1)[idx]                                       # index kernel: 4-byte gathers
-    g16 = rows.index_select(0, idx)                            # 16-byte row gathers
+    g16 = rows[idx[:1 << 24]]                                  # 16-byte row gathers
     gt = tok.index_select(0, ridx)                             # 1536-byte row gathers
     torch.cuda.synchronize()
 print("expected bytes per launch:")
@@ -29,5 +29,5 @@ print(f"  reduce_kernel (sum)        read {N * 4}")
 print(f"  copy (elementwise copy)    read {N * 4} write {N * 4}")
 print(f"  fill                       write {N * 4}")
 print(f"  index (4 B gather)         read idx {n_idx * 8} + gather {n_idx * 4} useful / {n_idx * 64} in 64 B sectors; write {n_idx * 4}")
-print(f"  index_select 16 B rows     read idx {n_idx * 8} + gather {n_idx * 16} useful / {n_idx * 64} in 64 B sectors; write {n_idx * 16}")
+print(f"  index (16 B row gather)    read idx {(1 << 24) * 8} + gather {(1 << 24) * 16} useful / {(1 << 24) * 64} in 64 B sectors; write {(1 << 24) * 16}")
 print(f"  index_select 1536 B rows   read idx {ridx.numel() * 8} + gather {ridx.numel() * 1536}; write {ridx.numel() * 1536}")

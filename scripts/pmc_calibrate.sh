@@ -4,11 +4,13 @@ out=${1:-gpurun_out/pmc_calibration.txt}
 export TMPDIR=/tmp
 cd /tmp
 python /root/repo/scripts/pmc_calibrate.py > $OLDPWD/$out 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pcal_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pcal_$c -- python /root/repo/scripts/pmc_calibrate.py > /dev/null 2>&1
-  echo "== $c (KiB per launch, mean)" >> $OLDPWD/$out
-  python /root/repo/scripts/pmc_generic.py $(find /tmp/pcal_$c -name "*counter_collection.csv" | head -1) "" | cut -c1-200 >> $OLDPWD/$out
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_RDREQ_DRAM_32B TCC_EA0_WRREQ_DRAM"; do
+  i=$((i+1))
+  rm -rf /tmp/pcal_$i
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pcal_$i -- python /root/repo/scripts/pmc_calibrate.py > /dev/null 2>&1
+  echo "== $c (FETCH/WRITE_SIZE in KiB, TCC_* in requests; per launch, mean)" >> $OLDPWD/$out
+  python /root/repo/scripts/pmc_generic.py $(find /tmp/pcal_$i -name "*counter_collection.csv" | head -1) "" | cut -c1-260 >> $OLDPWD/$out
 done
 cd $OLDPWD
 cat $out
