@@ -93,17 +93,14 @@ def ingest_alg_bytes(F, N, g, D, tok_bytes, U, P_sampled=0):
 
 
 def pmc_traffic():
-    """HBM bytes per bsc_ingest call from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r02_pmc_ingest_kernels.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the call's kernels —
-    gfx950 FETCH_SIZE counts wide coalesced reads at half, MI355X_MICROARCH.md, HBM).  The file names the commit it was
-    measured at; None when it is absent."""
+    """HBM-side bytes per bsc_ingest call from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r03_pmc_ingest_kernels.json, scripts/pmc_summary.py: read / write requests of the L2's memory side counted by
+    request size — 32 / 64 / 128 B —, two separate --pmc passes, summed over the call's kernels; the counters are checked on
+    known-byte kernels in profiles/r03_pmc_calibration.txt).  The file names the commit it was measured at; None when absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_ingest_kernels.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_ingest_kernels.json")) as f:
             d = json.load(f)
-        tot = sum(2.0 * v.get("FETCH_SIZE_KiB_per_launch", 0.0) * v.get("launches_per_call", 1.0) +
-                  v.get("WRITE_SIZE_KiB_per_launch", 0.0) * v.get("launches_per_call", 1.0)
-                  for k, v in d["kernels"].items() if v.get("ingest"))
-        return tot * 1024.0, d.get("commit")
+        return float(d["ingest_traffic_bytes_per_call"]), d.get("commit")
     except Exception:
         return None, None
 
@@ -586,7 +583,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "bsc_ingest: every kernel of one call, main stream (SURVEY.md 8d bytes of the batch)",
             "achieved": alg / ing_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": None if traffic is None else f"profiles/r02_pmc_ingest_kernels.json @ {traffic_commit}",
+            "traffic": traffic, "traffic_source": None if traffic is None else f"profiles/r03_pmc_ingest_kernels.json @ {traffic_commit}",
             "bytes_per_call": alg, "ms_per_call": ing_ms, "ms_per_call_isolated": iso["stages"]["bsc_ingest"],
             "frac_isolated": alg / iso["stages"]["bsc_ingest"] / 1e6 / HBM_PEAK_GBS,
             "voxel_rows_per_call": U, "points_per_call": (c1["points_passed"] - c0["points_passed"]) / a.steps,

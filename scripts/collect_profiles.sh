@@ -2,13 +2,14 @@
 # Round artifacts for profiles/: PMC traffic (two separate passes) first, so that the bench line that follows quotes the traffic
 # of this very commit; then the bench line, rocprofv3 kernel stats of the same command, MFMA counters of the encoder.
 # usage (on the GPU box, from the repo root): scripts/collect_profiles.sh <tag> <commit>
-tag=${1:-r02}
+tag=${1:-r03}
 commit=${2:-unknown}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in RD WR; do
   rm -rf /tmp/pmc/$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc/$c -- python bench.py --no-cpu-baseline --no-localize --no-workloads --repeats 1 > /dev/null 2>&1
+  if [ $c = RD ]; then ctr="TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B"; else ctr="TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"; fi
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc/$c -- python bench.py --no-cpu-baseline --no-localize --no-workloads --no-f32 --repeats 1 > /dev/null 2>&1
   f=$(find /tmp/pmc/$c -name "*counter_collection.csv" | head -1)
   mkdir -p /tmp/pmc_flat/$c && cp "$f" /tmp/pmc_flat/$c/pmc_counter_collection.csv
 done
