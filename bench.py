@@ -227,6 +227,10 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     the bf16 encoder + bf16 tokens against the f32 encoder + f32 tokens (same frames, same voxels)."""
     B = p.B
     from bsc_nav_amd import encoder
+    try:                                            # library-default f32 GEMM solutions: no TunableOp search for this leg
+        torch.cuda.tunable.tuning_enable(False)
+    except Exception:
+        pass
     vit32 = encoder.RandomViT(a.arch, image_size=224, seed=0, dtype=torch.float32).cuda()
     half = a.grid * 0.05
 
@@ -257,6 +261,10 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     e16.close()
     del vit32
     torch.cuda.empty_cache()
+    try:
+        torch.cuda.tunable.tuning_enable(True)
+    except Exception:
+        pass
     assert np.array_equal(cnt16, cnt32)
     c = np.maximum(cnt32, 1)[:, None].astype(np.float32)
     m16, m32 = acc16 / c if a.mode == "mean" else acc16, acc32 / c if a.mode == "mean" else acc32
