@@ -188,3 +188,96 @@ def test_key_packing_roundtrip_and_frame_sharding():
     assert torch.equal(bd.unpack_keys(bd.pack_keys(k)), k)
     assert bd.shard_frames(10) == (0, 10)
     assert bd.name_key_np([19, 1, 1]) < bd.name_key_np([1, 1, 1])      # "grid_19_" < "grid_1_"
+
+
+# ---- exact colour across ranks: the exchange of dist.merge_colour_replay on CPU (gloo has no all-to-all: all-gather branch) ----
+def _chain_np(recs):
+    """The sequential colour chain of memory_2.py:888-899 over (alpha f64, rgb packed) records, restated for the test."""
+    c, w, first = np.zeros(3, np.uint32), np.float32(0), True
+    for a, rgbv in recs:
+        r = np.array([rgbv & 0xff, (rgbv >> 8) & 0xff, (rgbv >> 16) & 0xff], np.uint32)
+        if first:
+            c, w, first = r.copy(), np.float32(np.float64(np.float32(0)) + a), False
+            continue
+        den = np.float64(w) + a
+        num = (c.astype(np.float32) * w).astype(np.float64) + r.astype(np.float64) * a
+        c = np.trunc(num / den).astype(np.uint32)
+        w = np.float32(den)
+    return c.astype(np.uint8), w
+
+
+class LogEngine(DictEngine):
+    """DictEngine + the point log / replay entry points of the real engine (NumPy stand-ins)."""
+
+    def __init__(self, *a, gs=12, nh=12, log=None, **kw):
+        super().__init__(*a, gs=gs, **kw)
+        import types
+        self.cfg = types.SimpleNamespace(token_dim=self.D, grid_size=gs)
+        self.nh, self.log_capacity, self._log = nh, 1 << 20, log
+
+    def point_log(self):
+        return self._log
+
+    def replay_colour(self, vox_sorted, records, n_vox):
+        rgb, w = torch.zeros((n_vox, 3), dtype=torch.uint8), torch.zeros(n_vox)
+        v, rec = vox_sorted.numpy(), records.numpy().astype(np.int64) & 0xffffffff
+        assert np.all(np.diff(v) >= 0)
+        for vox in np.unique(v):
+            rows = rec[v == vox]
+            alphas = ((rows[:, 1] << 32) | rows[:, 0]).astype(np.uint64).view(np.float64)
+            c, ww = _chain_np(list(zip(alphas, rows[:, 2])))
+            rgb[vox], w[vox] = torch.from_numpy(c.copy()), float(ww)
+        return rgb, w
+
+
+def _rank_points(rank, n=400):
+    rs = np.random.RandomState(50 + rank)
+    vox = rs.randint(0, 5, size=(n, 3))                               # 125 cells, every one hit by both ranks
+    alpha = np.exp(-rs.uniform(0.1, 30, size=n) / 1.2)
+    rgbv = rs.randint(0, 1 << 24, size=n)
+    bad = rs.uniform(size=n) < 0.1                                    # points without a voxel are logged with cell < 0
+    return vox, alpha, rgbv, bad
+
+
+def _replay_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bsc_nav_amd import dist as bd
+    gs = nh = 12
+    vox, alpha, rgbv, bad = _rank_points(rank)
+    cells = np.where(bad, -1, (vox[:, 0] * gs + vox[:, 1]) * nh + vox[:, 2]).astype(np.int32)
+    bits = alpha.view(np.uint64)
+    recs = np.stack([(bits & 0xffffffff).astype(np.uint32).view(np.int32), (bits >> 32).astype(np.uint32).view(np.int32),
+                     rgbv.astype(np.int32)], axis=1)
+    ok = ~bad
+    _, first = np.unique(vox[ok], axis=0, return_index=True)
+    keys = torch.from_numpy(vox[ok][np.sort(first)].astype(np.int32))            # local first-touch order
+    eng = LogEngine("mean", 4, keys, torch.zeros((len(keys), 4)), torch.ones(len(keys), dtype=torch.int32), seed=rank,
+                    log=(torch.from_numpy(cells), torch.from_numpy(recs)))
+    info = bd.merge_dense_maps(eng)
+    assert info["colour"].startswith("replay")
+    torch.save(dict(keys=eng.keys, rgb=eng.rgb, w=eng.w), f"{out_dir}/c{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_colour_replay_equals_sequential_chain(tmp_path):
+    """merge_colour_replay on two CPU ranks: every voxel's colour state after the merge equals the sequential chain over rank
+    0's points, then rank 1's, in their logged order (global point order of a frame-sharded build)."""
+    world = 2
+    mp.spawn(_replay_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seq = {}
+    for r in range(world):
+        vox, alpha, rgbv, bad = _rank_points(r)
+        for v, a, c, b in zip(vox.tolist(), alpha, rgbv, bad):
+            if not b:
+                seq.setdefault(tuple(v), []).append((a, int(c)))
+    n = 0
+    for r in range(world):
+        got = torch.load(f"{tmp_path}/c{r}.pt", weights_only=False)
+        for k, c, w in zip(got["keys"].tolist(), got["rgb"], got["w"]):
+            ec, ew = _chain_np(seq[tuple(k)])
+            assert np.array_equal(c.numpy(), ec) and np.float32(w.item()) == ew
+            n += 1
+    assert n == len(seq)
