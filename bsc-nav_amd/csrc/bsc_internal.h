@@ -169,6 +169,7 @@ struct bsc_ctx {
     bool order_on_side;        // per-voxel point order (k_runs .. k_seg_order) on the side stream (BSC_ORDER_MAIN=1 keeps it on the main stream)
     hipEvent_t ev_ids, ev_runs;   // main: voxel ids assigned; side: k_runs has read the call's cells / block offsets
     bool ev_runs_valid;
+    int last_order_set;        // scratch set of the last order stage enqueued on the side stream (-1: none): its ev_ready marks it complete
     // bookkeeping
     int64_t order_base; // global point counter (top-down map tie order)
     // HIP-event rings around the stages of the path (BSC_STAT_*), recorded on the stream the stage is launched on

@@ -71,6 +71,7 @@ static bsc_status reset_state(bsc_ctx *x)
     if (x->side) BSC_HIP(hipStreamSynchronize(x->side));
     x->ev_done_valid[0] = x->ev_done_valid[1] = false;
     x->ev_runs_valid = false;
+    x->last_order_set = -1;
     const int64_t gs2 = (int64_t)x->c.grid_size * x->c.grid_size;
     const int64_t vcap = x->c.voxel_capacity;
     fill<int32_t>(x, x->occ, x->ncell, -1);                                     // memory_2.py:717

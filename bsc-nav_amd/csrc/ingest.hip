@@ -1103,6 +1103,9 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // Everything enqueued so far is the call's front end; the back end is sized from these numbers.
     BSC_TRY(read_scalars(x));
     const int64_t n_new_listed = x->hscal[DS_B_NNEW], n_new = x->hscal[DS_B_NFIRST];
+    // The buffers the back end shares with the order stage (run keys / values and their sort outputs) may still be in use by
+    // the previous call's order stage on the side stream when calls follow each other without an encoder pass in between
+    if (x->last_order_set >= 0) BSC_HIP(hipStreamWaitEvent(s, x->ev_ready[x->last_order_set], 0));
     // ids of the new voxels: rank of their winning point among the winners (memory_2.py:888-894)
     if (n_new_listed > 0) {
         const dim3 ngrid((unsigned)((n_new_listed + TPB - 1) / TPB));
@@ -1175,6 +1178,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // its work statically over all 256 CUs (stream-K) runs up to twice as long while any CU is held by a chain wavefront
     // (measured: 26.4 -> 22.3 ms per 384-frame step without the chain beside the encoder).
     BSC_HIP(hipEventRecord(x->ev_ready[set], so));
+    x->last_order_set = side_order ? set : -1;
     x->chain_pending = true;
     x->chain_set = set;
     x->chain_order_base = x->order_base;
