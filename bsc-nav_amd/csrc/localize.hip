@@ -363,6 +363,7 @@ __global__ __launch_bounds__(TPB) void k_gather_topk(int K, int n_cand, int max_
 // K smallest rank keys of each 1024-element slice: bitonic sort in LDS (keys are unique: similarity key | name rank).
 // Rounds of this kernel shrink n candidates to K without a device-wide sort: n -> ceil(n/1024)*K -> ... -> K.
 #define TK_N 1024
+#define SEL_CNT_PAD 32          // int32 slots between the survivor counters of consecutive queries (one 128-byte line each)
 __device__ __forceinline__ void bitonic_1024(u64 *sk, uint32_t *sv)
 {
     for (int k = 2; k <= TK_N; k <<= 1) {
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
     __shared__ uint32_t sv[TK_N];
     for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
         const int q = wi / nb, bx = wi - q * nb;
-        const int64_t nn = n_per_q ? min((int64_t)n_per_q[q], n) : n;
+        const int64_t nn = n_per_q ? min((int64_t)n_per_q[q * SEL_CNT_PAD], n) : n;
         const int64_t base = (int64_t)bx * TK_N;
         for (int i = threadIdx.x; i < TK_N; i += TPB) {
             const int64_t g = base + i;
@@ -469,35 +470,43 @@ __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__
             for (int k = 0; k < 4; ++k) sk[g][k] = cand_simkey(a, c0 + k, qs);
         }
     }
-    // phase 2: almost every wave has nothing to keep -> one ballot per wave decides
-    bool any = false;
-#pragma unroll
-    for (int g = 0; g < FILT_G; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) any = any || (sk[g][k] <= thr_hi && sk[g][k] != 0xffffffffu);
-    if (!__ballot(any)) continue;
+    // phase 2: which of the lane's 16 candidates survive (the name rank breaks ties with the threshold's similarity bits)
+    uint32_t keepbits = 0u;
 #pragma unroll
     for (int g = 0; g < FILT_G; ++g) {
         const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
-            u64 key = ~0ull;
-            if (sk[g][k] != 0xffffffffu && sk[g][k] <= thr_hi) key = ((u64)sk[g][k] << 32) | (u64)a.name_rank[c];
-            const bool keep = key != ~0ull && key <= thr;
-            const u64 m = __ballot(keep);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&counts[q], __popcll(m));
-                base = __shfl(base, leader);
-                if (keep) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < cap) {
-                        out_keys[(int64_t)q * cap + pos] = key;
-                        out_vals[(int64_t)q * cap + pos] = (uint32_t)c;
-                    }
+            bool keep = sk[g][k] != 0xffffffffu && sk[g][k] <= thr_hi;
+            if (keep && sk[g][k] == thr_hi) keep = (((u64)sk[g][k] << 32) | (u64)a.name_rank[c0 + k]) <= thr;
+            keepbits |= keep ? (1u << (g * 4 + k)) : 0u;
+        }
+    }
+    // phase 3: ONE atomic per wavefront with survivors (the counters of the queries sit a cache line apart: with one counter
+    // per survivor on 16 shared lines this kernel spent 1.1 ms of its 1.2 ms queueing at the L2 atomic units)
+    const int mine = __popc(keepbits);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counts[q * SEL_CNT_PAD], total);
+    base = __shfl(base, 0) + incl - mine;
+#pragma unroll
+    for (int g = 0; g < FILT_G; ++g) {
+        const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (keepbits & (1u << (g * 4 + k))) {
+                if (base < cap) {
+                    out_keys[(int64_t)q * cap + base] = ((u64)sk[g][k] << 32) | (u64)a.name_rank[c0 + k];
+                    out_vals[(int64_t)q * cap + base] = (uint32_t)(c0 + k);
                 }
+                ++base;
             }
         }
     }
@@ -511,7 +520,7 @@ __global__ void k_sel_thresholds(const u64 *__restrict__ win_keys, int64_t strid
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     thr[q] = win_keys[(int64_t)q * stride + (K - 1)];
-    counts[q] = 0;
+    counts[q * SEL_CNT_PAD] = 0;
 }
 
 // the filter is exact unless a survivor list overflowed or the sample held fewer than K valid candidates
@@ -519,7 +528,7 @@ __global__ void k_sel_check(const u64 *__restrict__ thr, const int32_t *__restri
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    if (counts[q] > cap || thr[q] == ~0ull) *flag = 1;
+    if (counts[q * SEL_CNT_PAD] > cap || thr[q] == ~0ull) *flag = 1;
 }
 
 static bsc_status grow_dev(void **p, int64_t *cap, int64_t need_bytes)
@@ -569,7 +578,7 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
     BSC_TRY(grow_dev((void **)&x->l_sel_val[0], &x->l_sel_cap[2], sizeof(uint32_t) * stride * nq));
     BSC_TRY(grow_dev((void **)&x->l_sel_val[1], &x->l_sel_cap[3], sizeof(uint32_t) * stride * nq));
     BSC_TRY(grow_dev((void **)&x->l_sel_thr, &x->l_sel_cap[4], sizeof(u64) * (int64_t)(nq + 1)));
-    BSC_TRY(grow_dev((void **)&x->l_sel_cnt, &x->l_sel_cap[5], sizeof(int32_t) * nq));
+    BSC_TRY(grow_dev((void **)&x->l_sel_cnt, &x->l_sel_cap[5], sizeof(int32_t) * nq * SEL_CNT_PAD));
     int cur = 0;
     // round 1 over the sample (or over everything), fused with the candidate keys
     hipLaunchKernelGGL(k_cand_topk, dim3((unsigned)(nbs * nq < 4096 ? nbs * nq : 4096)), dim3(TPB), 0, x->stream, ca, x->l_sims,
