@@ -386,7 +386,7 @@ __device__ __forceinline__ void bitonic_1024(u64 *sk, uint32_t *sv)
 // first round, fused with the candidate scan: block (b, q) ranks candidates [1024 b, 1024 b + 1024) of query q
 __global__ __launch_bounds__(TPB) void k_cand_topk(CandArgs a, const float *__restrict__ sims, int64_t sims_stride, int K,
                                                    u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
-                                                   int64_t out_stride, int nb, int nq)
+                                                   int64_t out_stride, int nb, int nq, int bstride)
 {
     __shared__ u64 sk[TK_N];
     __shared__ uint32_t sv[TK_N];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(TPB) void k_cand_topk(CandArgs a, const float *__re
         const int q = wi / nb, bx = wi - q * nb;
         const float *qs = sims + (int64_t)q * sims_stride;
         for (int i = threadIdx.x; i < TK_N; i += TPB) {
-            const int c = bx * TK_N + i;
+            const int c = bx * bstride * TK_N + i;            // bstride > 1: a sample of blocks spread over the whole map
             sk[i] = cand_key(a, c, qs);
             sv[i] = (uint32_t)c;
         }
@@ -544,9 +544,11 @@ static bsc_status grow_dev(void **p, int64_t *cap, int64_t need_bytes)
 
 // K <= 512, all queries at once, no device-wide sort:
 //   small candidate sets: rounds of 1024-key bitonic selections (round 1 fused with the candidate scan);
-//   large sets: selection over a sample of 64 blocks gives a per-query threshold, one streaming filter pass keeps the
-//   few candidates that beat it, rounds over the survivors finish.  *overflow is set when the host must fall back.
-#define SEL_SAMPLE_BLOCKS 64
+//   large sets: selection over a sample of 16 blocks spread over the map gives a per-query threshold, one streaming filter
+//   pass keeps the few candidates that beat it, rounds over the survivors finish.  *overflow is set when the host must fall
+//   back.  Sample size: nbs x nq bitonic selections for the sample + (K n_cand / (1024 nbs)) / 1024 x nq for the survivors —
+//   at 2^20 candidates and K = 100, 16 blocks (~6400 survivors per query) cost a third of 64 blocks (~1600 survivors).
+#define SEL_SAMPLE_BLOCKS 16
 #define SEL_SURVIVOR_CAP 32768
 static bsc_status bitonic_rounds(bsc_ctx *x, int nq, int64_t n, const int32_t *n_per_q, int K, int64_t stride, int *cur)
 {
@@ -582,7 +584,7 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
     int cur = 0;
     // round 1 over the sample (or over everything), fused with the candidate keys
     hipLaunchKernelGGL(k_cand_topk, dim3((unsigned)(nbs * nq < 4096 ? nbs * nq : 4096)), dim3(TPB), 0, x->stream, ca, x->l_sims,
-                       sims_stride, K, x->l_sel_key[0], x->l_sel_val[0], stride, (int)nbs, nq);
+                       sims_stride, K, x->l_sel_key[0], x->l_sel_val[0], stride, (int)nbs, nq, use_filter ? (int)(nb1 / nbs) : 1);
     if (nbs > 1) BSC_TRY(bitonic_rounds(x, nq, nbs * K, nullptr, K, stride, &cur));
     *filtered = false;
     if (use_filter) {
