@@ -703,9 +703,10 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     ca.rgb_pos = x->rgb_pos; ca.cnt = cnt; ca.store_rows = x->store_rows; ca.name_rank = x->l_name_rank;
     bool filtered = false;
     if (K <= TK_N / 2) {
+        static const int sel_min_q = getenv("BSC_SEL_MIN_Q") ? atoi(getenv("BSC_SEL_MIN_Q")) : 5;     // sample + filter from this many queries on (Q = 1: 0.79 vs 0.87 ms without / with; Q = 8: 1.08 vs 0.98; Q = 12: 1.20 vs 1.00)
         for (int attempt = 0; attempt < 2; ++attempt) {
             u64 *wk; uint32_t *wv; int64_t ws;
-            BSC_TRY(select_topk_batched(x, ca, nq, sstride, K, attempt == 0 && nq >= 16, &wk, &wv, &ws, &filtered));
+            BSC_TRY(select_topk_batched(x, ca, nq, sstride, K, attempt == 0 && nq >= sel_min_q, &wk, &wv, &ws, &filtered));
             hipLaunchKernelGGL(k_gather_topk, dim3((K + TPB - 1) / TPB, (unsigned)nq), block, 0, s, K, /*entries*/ K, max_id,
                                vcap, wk, wv, ws, x->rgb_pos, x->l_out_pos, x->l_out_sim);
             if (!filtered) break;
