@@ -190,71 +190,78 @@ __global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int
 #define PP_HS 4096
 #define PP_R 13                 // rounds of TPB pixels: tiles of up to 3328 pixels (640x480 at 14x14 patches: 46 x 46, and 68 x 46 in
                                 // patch column 0, which int() widens to u in (-1, 1))
-__global__ __launch_bounds__(TPB) void k_patch_pairs(int W, int64_t N, int g, const int32_t *__restrict__ pt_rect,
+// Persistent workgroups walk the tiles: the 4096-slot table (sized for one cell per pixel) is cleared ONCE; every insert that
+// claims an empty slot also lists it, so a tile's pairs are emitted — and its slots cleared again — by walking that short list
+// (a few dozen entries for a surface at room distance) instead of scanning and re-initialising 4096 slots per tile.
+__global__ __launch_bounds__(TPB) void k_patch_pairs(int W, int64_t N, int g, int64_t n_tiles, const int32_t *__restrict__ pt_rect,
                                                      const int32_t *__restrict__ pt_off, CellCode cc,
                                                      const int32_t *__restrict__ p_cell, u64 *__restrict__ stage_rec,
                                                      uint32_t *__restrict__ stage_blk, int32_t *__restrict__ tile_cnt)
 {
     __shared__ uint32_t hkey[PP_HS], hcnt[PP_HS];
+    __shared__ uint16_t hlist[PP_R * TPB];          // slots claimed by the tile in flight (<= one per pixel)
     __shared__ int nloc;
     const int tid = threadIdx.x, lane = tid & 63;
     const int g2 = g * g;
-    const int64_t tile = blockIdx.x;
-    const int64_t f = tile / g2;
-    const int p = (int)(tile - f * g2);
-    const int x0 = pt_rect[4 * p], w = pt_rect[4 * p + 1], y0 = pt_rect[4 * p + 2], n = pt_rect[4 * p + 3];    // n = w * h pixels
-    if (n == 0) {
-        if (tid == 0) tile_cnt[tile] = 0;
-        return;
-    }
     for (int s = tid; s < PP_HS; s += TPB) { hkey[s] = 0xffffffffu; hcnt[s] = 0u; }
     if (tid == 0) nloc = 0;
     __syncthreads();
-    const float inv_w = 1.0f / (float)w;
-    int32_t cell[PP_R];
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t f = tile / g2;
+        const int p = (int)(tile - f * g2);
+        const int x0 = pt_rect[4 * p], w = pt_rect[4 * p + 1], y0 = pt_rect[4 * p + 2], n = pt_rect[4 * p + 3];    // n = w * h pixels
+        if (n == 0) {
+            if (tid == 0) tile_cnt[tile] = 0;
+            continue;
+        }
+        const float inv_w = 1.0f / (float)w;
+        int32_t cell[PP_R];
 #pragma unroll
-    for (int r = 0; r < PP_R; ++r) {                // all loads in flight before the first use (clamped addresses)
-        const int l = tid + r * TPB;
-        const int lc = l < n ? l : 0;
-        int y = (int)((float)lc * inv_w);
-        int x = lc - y * w;
-        if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
-        const int32_t c = p_cell[f * N + (int64_t)(y0 + y) * W + x0 + x];
-        cell[r] = l < n ? c : -1;
-    }
+        for (int r = 0; r < PP_R; ++r) {                // all loads in flight before the first use (clamped addresses)
+            const int l = tid + r * TPB;
+            const int lc = l < n ? l : 0;
+            int y = (int)((float)lc * inv_w);
+            int x = lc - y * w;
+            if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
+            const int32_t c = p_cell[f * N + (int64_t)(y0 + y) * W + x0 + x];
+            cell[r] = l < n ? c : -1;
+        }
 #pragma unroll
-    for (int r = 0; r < PP_R; ++r) {
-        if (r * TPB >= n) break;
-        // neighbouring pixels share the cell: only the first lane of a stretch inserts, with the stretch's length
-        const int32_t pc = __shfl_up(cell[r], 1);
-        const bool edge = lane == 0 || cell[r] != pc;
-        const u64 em = __ballot(edge);
-        const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
-        const int end = above ? (__ffsll((long long)above) - 1) : 64;
-        if (edge && cell[r] >= 0) {
-            const uint32_t key = (uint32_t)cell[r];
-            uint32_t h = (key * 2654435761u) >> 20;        // 12 bits
-            for (;;) {
-                const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, key);
-                if (old == 0xffffffffu || old == key) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
-                h = (h + 1) & (PP_HS - 1);
+        for (int r = 0; r < PP_R; ++r) {
+            if (r * TPB >= n) break;
+            // neighbouring pixels share the cell: only the first lane of a stretch inserts, with the stretch's length
+            const int32_t pc = __shfl_up(cell[r], 1);
+            const bool edge = lane == 0 || cell[r] != pc;
+            const u64 em = __ballot(edge);
+            const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
+            const int end = above ? (__ffsll((long long)above) - 1) : 64;
+            if (edge && cell[r] >= 0) {
+                const uint32_t key = (uint32_t)cell[r];
+                uint32_t h = (key * 2654435761u) >> 20;        // 12 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, key);
+                    if (old == 0xffffffffu) hlist[atomicAdd(&nloc, 1)] = (uint16_t)h;      // first claim of the slot: list it
+                    if (old == 0xffffffffu || old == key) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
+                    h = (h + 1) & (PP_HS - 1);
+                }
             }
         }
-    }
-    __syncthreads();
-    const int64_t base = f * N + pt_off[p];              // the tile's staging slice: as many slots as it has pixels
-    const u64 row = (u64)(f * g2 + p) << 32;
-    for (int s = tid; s < PP_HS; s += TPB) {
-        const uint32_t key = hkey[s];
-        if (key != 0xffffffffu) {
-            const int li = atomicAdd(&nloc, 1);
-            const uint32_t code = (uint32_t)cell_to_code(cc, (int32_t)key);
-            stage_rec[base + li] = row | (u64)hcnt[s];
-            stage_blk[base + li] = code;
+        __syncthreads();
+        const int nl = nloc;
+        const int64_t base = f * N + pt_off[p];              // the tile's staging slice: as many slots as it has pixels
+        const u64 row = (u64)(f * g2 + p) << 32;
+        for (int li = tid; li < nl; li += TPB) {
+            const int h = hlist[li];
+            const uint32_t key = hkey[h];
+            stage_rec[base + li] = row | (u64)hcnt[h];
+            stage_blk[base + li] = (uint32_t)cell_to_code(cc, (int32_t)key);
+            hkey[h] = 0xffffffffu;                           // the table is clean again for the workgroup's next tile
+            hcnt[h] = 0u;
         }
+        __syncthreads();
+        if (tid == 0) { tile_cnt[tile] = nl; nloc = 0; }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) tile_cnt[tile] = nloc;
 }
 
 __global__ __launch_bounds__(TPB) void k_patch_compact(int64_t n_tiles, int g2, int64_t N, const int32_t *__restrict__ pt_off,
@@ -730,8 +737,9 @@ bsc_status launch_keys_pairs(bsc_ctx *x, int64_t P, int n_frames, bool all_pixel
         const int64_t tiles = (int64_t)n_frames * g2, N = (int64_t)H * W;
         if (tiles > x->max_tiles) { bsc_set_error("launch_keys_pairs: %lld tiles > %lld", (long long)tiles, (long long)x->max_tiles); return BSC_E_CAPACITY; }
         const dim3 grid((unsigned)tiles), block(TPB);
+        const dim3 pgrid((unsigned)(tiles < 256 * 4 ? tiles : 256 * 4));      // persistent: 4 workgroups per CU (41 KB of LDS each)
         uint32_t *pair_idx = (uint32_t *)x->pair_key_b;
-        hipLaunchKernelGGL(k_patch_pairs, grid, block, 0, x->stream, W, N, x->c.patch_grid, x->pt_rect, x->pt_off,
+        hipLaunchKernelGGL(k_patch_pairs, pgrid, block, 0, x->stream, W, N, x->c.patch_grid, tiles, x->pt_rect, x->pt_off,
                            make_cell_code32(x), x->p_cell, x->pstage_key, x->pstage_cnt, x->tile_cnt);
         BSC_TRY(prim_exclusive_sum_i32(x, x->tile_cnt, x->tile_off, (size_t)tiles));
         hipLaunchKernelGGL(k_patch_compact, grid, block, 0, x->stream, tiles, g2, N, x->pt_off, x->tile_cnt, x->tile_off,
