@@ -10,8 +10,9 @@ single-process; this module is the new frame-sharded design of S
      3. reduce-scatter of the (U,D) accumulators and (U,) counts: rank r ends up owning the r-th
         contiguous slice of the union.  xGMI is point-to-point, so reduce-scatter (all 7 links busy)
         is preferred over a ring all-reduce followed by a broadcast.
-     4. colour state (7 B / voxel / rank) and the top-down map (gs^2 cells) are all-gathered and merged
-        (merge_colour_states: documented rule; merge_heightmaps: exact)
+     4. colour state (7 B / voxel / rank: slices exchanged by one all-to-all) and the top-down map (gs^2 cells: one MAX
+        all-reduce of packed height | rank | colour keys) are merged
+        (merge_colour_states: documented rule, or merge_colour_replay: exact; allreduce_heightmap: exact)
   gather_merged_to_root   slices -> one engine that holds the whole memory and can save a loadable directory
   localize_sharded   every rank scans its slice, all-gather of the (Q,K) local winners, K-way merge
                      with the reference's tie order (HDF5 group-name order).
@@ -210,27 +211,41 @@ def merge_colour_replay(engine, union, per, group=None):
     return engine.replay_colour(local.to(torch.int32), rec, per)
 
 
-def merge_heightmaps(heights, colours):
-    """Per-rank top-down maps -> the sequential result.  `h >= max_height` in point order (memory_2.py:901-903) keeps,
-    per cell, the LATEST point among those at the greatest height; points of a higher rank come later, so the winner
-    is the highest rank that reaches the cell's maximum.  heights (R,gs,gs) f64 (-inf empty), colours (R,gs,gs,3) u8."""
-    R = heights.shape[0]
-    top = heights.max(axis=0)
-    at_top = heights == top[None]                                       # -inf == -inf: empty everywhere -> rank R-1, colour 0
-    winner = (R - 1) - np.argmax(at_top[::-1], axis=0)
-    rr, cc = np.meshgrid(np.arange(top.shape[0]), np.arange(top.shape[1]), indexing="ij")
-    return top, colours[winner, rr, cc]
-
-
-def _all_gather_np(a, device, group=None):
-    """NumPy array (same shape on every rank) -> (world, ...) NumPy array."""
+def _exchange_slices(rgb, wgt, present, per, group=None):
+    """Per-rank colour state laid out in union order (world * per rows) -> what the owner of slice `rank` needs from every
+    rank: (world, per, 3) u8, (world, per) f32, (world, per) bool."""
     rank, world = _world(group)
-    if not _active():
-        return a[None]
-    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dist.get_backend(group) == "gloo":
+        lo, hi = rank * per, (rank + 1) * per
+        return (torch.stack(_all_gather(rgb, group))[:, lo:hi], torch.stack(_all_gather(wgt, group))[:, lo:hi],
+                torch.stack(_all_gather(present, group))[:, lo:hi])
+    packed = torch.zeros((world * per, 8), dtype=torch.uint8, device=rgb.device)          # r g b present | weight as 4 bytes
+    packed[:, :3] = rgb
+    packed[:, 3] = present.to(torch.uint8)
+    packed[:, 4:] = wgt.contiguous().view(torch.uint8).view(-1, 4)
+    out = torch.empty_like(packed)
+    dist.all_to_all_single(out, packed, group=group)                                      # equal splits of `per` rows
+    out = out.view(world, per, 8)
+    return out[..., :3].contiguous(), out[..., 4:].contiguous().view(torch.float32).view(world, per), out[..., 3] > 0
+
+
+def allreduce_heightmap(mh, cv, device, group=None):
+    """max_height (gs,gs) f64 (-inf empty, else an integer height index) and cv_map (gs,gs,3) u8 of this rank -> the merged
+    pair, identical on every rank: per cell the greatest height, among the ranks that reach it the highest one (its points
+    come last in the global order, memory_2.py:901-903 `h >= max_height`), and that rank's colour."""
+    rank, world = _world(group)
+    h = np.where(np.isfinite(mh), mh, -1.0).astype(np.int64) + 1                       # 0: empty
+    rgbp = cv[..., 0].astype(np.int64) | (cv[..., 1].astype(np.int64) << 8) | (cv[..., 2].astype(np.int64) << 16)
+    key = torch.from_numpy((h << 40) | (np.int64(rank) << 24) | rgbp)
     if dist.get_backend(group) != "gloo":
-        t = t.to(device)
-    return torch.stack(_all_gather(t, group)).cpu().numpy()
+        key = key.to(device)
+    dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+    key = key.cpu().numpy()
+    hh = key >> 40
+    top = np.where(hh > 0, (hh - 1).astype(np.float64), -np.inf)
+    colour = np.stack([key & 0xff, (key >> 8) & 0xff, (key >> 16) & 0xff], axis=-1).astype(np.uint8)
+    colour[hh == 0] = cv[hh == 0] if world == 1 else 0                                 # empty everywhere: no colour
+    return top, colour
 
 
 def merge_dense_maps(engine, group=None):
@@ -240,7 +255,7 @@ def merge_dense_maps(engine, group=None):
       ids / positions   global first-touch order (global_id_order) == the single-process numbering
       features, counts  one reduce-scatter of the (U,D) sums (or maxima) and (U,) counts
       rgb, weights      merge_colour_states (documented dense-mode rule)
-      top-down map      merge_heightmaps (exact), replicated on every rank
+      top-down map      allreduce_heightmap (exact), replicated on every rank
 
     `engine` needs: mode, device, keys_tensor(), dense_gather(keys), dense_gather_rgb(keys), export_heightmap(),
     import_heightmap(h, cv), dense_replace(keys, acc, cnt, rgb, weight).  Returns dict(n_union, per_rank, n_local)."""
@@ -276,16 +291,17 @@ def merge_dense_maps(engine, group=None):
         my_rgb, my_w = merge_colour_replay(engine, union, per, group)
         colour_rule = "replay (exact)"
     else:
-        # colour state: 7 bytes per voxel and rank; every rank gathers the union and merges its own slice
-        all_rgb = torch.stack(_all_gather(rgb, group))[:, lo:hi]
-        all_w = torch.stack(_all_gather(wgt, group))[:, lo:hi]
-        all_present = torch.stack(_all_gather(cnt, group))[:, lo:hi] > 0
+        # colour state: 7 bytes per voxel and rank, needed only by the voxel's owner: every rank sends slice s of its
+        # (rgb, weight, present) to rank s — one all-to-all of equal splits (gloo, tests: all-gather and slice)
+        all_rgb, all_w, all_present = _exchange_slices(rgb, wgt, cnt > 0, per, group)
         my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
         colour_rule = "per-rank states as observations (approximate)"
     mark("colour")
-    # top-down map: gs^2 cells, replicated
+    # top-down map: gs^2 cells, replicated.  Per cell the LATEST point among those at the greatest height wins
+    # (memory_2.py:901-903: `h >= max_height` in point order); points of a higher rank come later, so the winner is the
+    # highest rank at the maximum: one MAX all-reduce of (h + 1) << 40 | rank << 24 | rgb carries height, winner and colour.
     mh, cv = engine.export_heightmap()
-    top, colour = merge_heightmaps(_all_gather_np(mh, engine.device, group), _all_gather_np(cv, engine.device, group))
+    top, colour = allreduce_heightmap(mh, cv, engine.device, group)
     mark("heightmap")
     n_local = int((union[lo:hi] < _SENTINEL).sum().item())
     engine.dense_replace(ukeys[lo:lo + n_local].contiguous(), my_acc[:n_local].contiguous(), my_cnt[:n_local].contiguous(),
@@ -404,6 +420,9 @@ def warmup_collectives(device, group=None):
     reduce_scatter_rows(torch.ones((world * 4, 8), dtype=torch.float32, device=device), dist.ReduceOp.MAX, 4, group)
     _all_gather(torch.zeros((2, 4), dtype=torch.float64, device=device), group)
     _all_gather(torch.zeros(2, dtype=torch.int64, device=device), group)
+    _exchange_slices(torch.zeros((world * 2, 3), dtype=torch.uint8, device=device), torch.zeros(world * 2, device=device),
+                     torch.zeros(world * 2, dtype=torch.bool, device=device), 2, group)
+    allreduce_heightmap(np.full((2, 2), -np.inf), np.zeros((2, 2, 3), np.uint8), device, group)
 
 
 def shard_frames(n_frames, group=None):
