@@ -281,3 +281,18 @@ def test_two_rank_colour_replay_equals_sequential_chain(tmp_path):
             assert np.array_equal(c.numpy(), ec) and np.float32(w.item()) == ew
             n += 1
     assert n == len(seq)
+
+
+def test_batched_topk_merge_equals_per_query_merge():
+    """merge_topk_batched (all queries in one lexsort) == merge_topk query by query: exact ties in name order, ragged counts."""
+    from bsc_nav_amd import dist as bd
+    rs = np.random.RandomState(3)
+    W, Q, K = 4, 9, 40
+    pos = rs.randint(0, 25, size=(W, Q, K, 3))
+    sim = -np.sort(-np.round(rs.uniform(size=(W, Q, K)), 1).astype(np.float32), axis=2)        # many exact ties
+    cnt = rs.randint(0, K + 1, size=(W, Q))
+    cnt[:, 0] = 0                                                                               # a query with no candidate anywhere
+    got_p, got_s = bd.merge_topk_batched(pos, sim, cnt, K)
+    for qi in range(Q):
+        p, s = bd.merge_topk([pos[r, qi, :cnt[r, qi]] for r in range(W)], [sim[r, qi, :cnt[r, qi]] for r in range(W)], K)
+        assert np.array_equal(got_p[qi], p) and np.array_equal(got_s[qi], s.astype(np.float32))
