@@ -789,6 +789,7 @@ __global__ __launch_bounds__(LONG_WG) void k_chain_long(const uint32_t *__restri
 // of its voxel" flags: both ride in one 64-bit value (length | head << 32), summed per block of EB runs (k_run_blocksum),
 // scanned over the ~R / 1024 block sums, and finished inside the block by k_expand — no R-sized scan array.
 #define EB 1024
+#define EXPAND_RUN_DRIVEN 16    // k_expand: wave-groups whose longest run has at most this many points are written run by run
 __device__ __forceinline__ int64_t run_item(const uint32_t *__restrict__ rkey, int64_t i, int64_t R, uint32_t vmask, int vb)
 {
     if (i >= R) return 0;
@@ -866,10 +867,20 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
         __builtin_amdgcn_wave_barrier();
         s_off[wid][lane] = len > 0 ? off : INT_MAX;
         s_j0[wid][lane] = j0;
-        int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0;
-        for (int o = 32; o > 0; o >>= 1) { begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); }
+        int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0, longest = len;
+        for (int o = 32; o > 0; o >>= 1) {
+            begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); longest = max(longest, __shfl_xor(longest, o));
+        }
         __builtin_amdgcn_wave_barrier();
         if (begin == INT_MAX) continue;
+        if (longest <= EXPAND_RUN_DRIVEN) {
+            // short runs (the usual case: a voxel a few metres away covers a handful of pixels of an image row): every lane
+            // writes its own run; the runs of neighbouring lanes are neighbours in the output, so each of the `longest` store
+            // instructions covers a few cache lines — no search per output point
+            for (int t = 0; t < longest; ++t)
+                if (t < len) sj[off + t] = (uint32_t)(j0 + t);
+            continue;
+        }
         for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
             int lo = 0;                         // largest lo with s_off[lo] <= pnt (offsets ascend; empty runs sort last)
 #pragma unroll
