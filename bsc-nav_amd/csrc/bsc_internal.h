@@ -147,6 +147,7 @@ struct bsc_ctx {
     uint32_t *l_val_a, *l_val_b;
     uint32_t *l_name_rank;
     float *l_q;          // normalised queries
+    uint16_t *l_qp;      // their three bf16 pieces (3, 1024, D) for the bf16x3 scan
     u64 *l_sel_key[2];   // batched top-K selection rounds (grown on demand)
     uint32_t *l_sel_val[2];
     u64 *l_sel_thr;      // per-query threshold keys of the sample selection

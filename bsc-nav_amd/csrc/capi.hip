@@ -268,6 +268,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->l_val_a, vcap + 1); ALLOC(x->l_val_b, vcap + 1);
     ALLOC(x->l_name_rank, vcap + 1);
     ALLOC(x->l_q, 1024 * D);
+    ALLOC(x->l_qp, 3 * 1024 * D);
     int64_t prim_items = (np > vcap + 1) ? np : vcap + 1;
     if (x->max_tiles > prim_items) prim_items = x->max_tiles;
     x->prim_tmp_bytes = prim_workspace_bytes((size_t)prim_items);
@@ -302,7 +303,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->seg_last_s[0], x->seg_last_s[1], x->bscal_s[0], x->bscal_s[1], x->f_keys_a, x->f_keys_b, x->pair_key_a, x->pair_key_b, x->pair_cnt_a, x->pair_cnt_b, x->pseg_start,
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
-                    x->l_name_rank, x->l_q, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
+                    x->l_name_rank, x->l_q, x->l_qp, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
                     x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
                     x->fr_centers, x->fr_gains, x->log_cell, x->log_rec};

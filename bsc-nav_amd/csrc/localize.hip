@@ -255,6 +255,152 @@ __global__ __launch_bounds__(TPB) void k_cosine_mfma(const float *__restrict__ X
     }
 }
 
+// ---- batched queries on the bf16 matrix cores at f32 accuracy -----------------------------------------------------------
+// gfx950 has no TF32; its f32 MFMA peaks at 157 TFLOP/s, its bf16 MFMA at 2.5 PFLOP/s.  An f32 value is the exact sum of three
+// bf16 pieces (8 significand bits each: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), the differences are exact), so a
+// product x q is the sum of nine piece products; the six of weight >= 2^-16 (hh, hm, mh, hl, mm, lh) leave a truncation of
+// 2^-24 per product — the rounding an f32 multiply has anyway — and accumulate in the matrix core's f32 accumulators like the
+// f32 instruction does.  Six bf16 MFMAs at 16x the rate replace one f32 MFMA: 0.375x the matrix time, and the scan moves from
+// MFMA-bound (4.1 ms for 256 queries over 2^20 x 768) towards its HBM time.
+//   A operand (M axis): 32 queries per tile, NT tiles — the three pieces of the normalised queries come precomputed
+//                       (k_split_q) and are staged per 32-wide K chunk through LDS (80-byte row pitch), double-buffered;
+//   B operand (N axis): the wavefront's 32 rows straight from global memory in fragment layout — lane (n, g) loads the 16
+//                       floats [32 c + 16 g, + 16) of row n (one 128-byte line per row and chunk over the two lane groups),
+//                       splits them in registers; sub-step s of a chunk contracts floats [8 s, 8 s + 8) of every lane;
+//   v_mfma_f32_32x32x16_bf16: 12 per tile and chunk, interleaved over the NT independent accumulators.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#define BX_KC 32                 // K chunk
+#define BX_PITCH 40              // bf16 elements per staged query row (80 bytes: conflict-free 16-byte reads)
+
+__device__ __forceinline__ uint32_t pack_bf16_rne(float lo, float hi)      // v_cvt_pk_bf16_f32
+{
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *(const uint32_t *)&r;
+}
+
+// (a, b) -> packed bf16 pieces h, m, l of both
+__device__ __forceinline__ void split3(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = pack_bf16_rne(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16_rne(ra, rb);
+    l = pack_bf16_rne(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+
+// qn (Q, D) f32 -> qp (3, Q, D) bf16 pieces
+__global__ __launch_bounds__(TPB) void k_split_q(const float *__restrict__ qn, int64_t n, uint16_t *__restrict__ qp)
+{
+    const int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 2;
+    if (i >= n) return;
+    uint32_t h, m, l;
+    split3(qn[i], qn[i + 1], h, m, l);
+    *(uint32_t *)(qp + i) = h;
+    *(uint32_t *)(qp + n + i) = m;
+    *(uint32_t *)(qp + 2 * n + i) = l;
+}
+
+template <int NT>
+__global__ __launch_bounds__(TPB) void k_cosine_bf16x3(const float *__restrict__ X, int64_t n_rows, int D,
+                                                       const uint16_t *__restrict__ qp, int64_t q_plane, int q0, int q_valid,
+                                                       float *__restrict__ sims, int64_t sims_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t Qs[];           // [2][3][NT * 32][BX_PITCH]
+    constexpr int QROWS = NT * 32;
+    constexpr int BUF = 3 * QROWS * BX_PITCH;
+    constexpr int NLD = 3 * QROWS * 4 / TPB;                                 // 16-byte pieces of a query chunk per thread
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int64_t row = row0 + w * 32 + n;
+    const int64_t rowc = row < n_rows ? row : n_rows - 1;                  // clamped: results of padded rows are not stored
+    const float *xrow = X + rowc * D + g * 16;
+    const int nchunks = D / BX_KC;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float nrm = 0.f;
+    float4 xf[4];
+    uint4 qr[NLD];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const float4 *)(xrow + c * BX_KC + 4 * i);
+    };
+    auto load_q = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + TPB * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            qr[j] = *(const uint4 *)(qp + (int64_t)p * q_plane + (int64_t)(q0 + q) * D + c * BX_KC + part * 8);
+        }
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + TPB * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            *(uint4 *)&Qs[buf * BUF + (p * QROWS + q) * BX_PITCH + part * 8] = qr[j];
+        }
+    };
+    load_x(0);
+    load_q(0);
+    store_q(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        // this chunk's rows -> bf16 pieces (two sub-steps of 8 floats), then the next chunk's loads go in flight
+        uint32_t bh[2][4], bm[2][4], bl[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = xf[i];
+            nrm = fmaf(v.x, v.x, nrm); nrm = fmaf(v.y, v.y, nrm); nrm = fmaf(v.z, v.z, nrm); nrm = fmaf(v.w, v.w, nrm);
+            split3(v.x, v.y, bh[i >> 1][2 * (i & 1)], bm[i >> 1][2 * (i & 1)], bl[i >> 1][2 * (i & 1)]);
+            split3(v.z, v.w, bh[i >> 1][2 * (i & 1) + 1], bm[i >> 1][2 * (i & 1) + 1], bl[i >> 1][2 * (i & 1) + 1]);
+        }
+        if (c + 1 < nchunks) { load_x(c + 1); load_q(c + 1); }
+        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16];
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+            const bf16x8_t xh = *(const bf16x8_t *)bh[sstep], xm = *(const bf16x8_t *)bm[sstep], xl = *(const bf16x8_t *)bl[sstep];
+            bf16x8_t ah[NT], am[NT], al[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                ah[t] = *(const bf16x8_t *)(qb + (0 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+                am[t] = *(const bf16x8_t *)(qb + (1 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+                al[t] = *(const bf16x8_t *)(qb + (2 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+            }
+            // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], xm, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xm, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xh, acc[t], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_q(buf ^ 1);
+        __syncthreads();
+    }
+    nrm += __shfl_xor(nrm, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(nrm), 1e-8f);
+    if (row < n_rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (q < q_valid) sims[(int64_t)q * sims_stride + row] = acc[t][r] * inv;
+            }
+    }
+}
+
 __device__ __forceinline__ uint32_t float_desc_key(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -674,8 +820,34 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     const int64_t sstride = sims_row_stride(n_rows);
     int passes = 0;                          // times the row matrix is streamed
     if (nq >= BSC_MFMA_MIN_Q && D % MF_KC == 0 && n_rows > 0) {
-        // batched queries: fp32 MFMA GEMM, 32-query tiles (l_q is zero-padded to a multiple of 32 rows)
+        // batched queries on the matrix cores, 32-query tiles (l_q is zero-padded to a multiple of 256 rows): more than 32
+        // queries -> bf16 pieces at f32 accuracy (k_cosine_bf16x3); up to 32 -> the f32 MFMA, HBM-bound at that size anyway
         const dim3 mgrid((unsigned)((n_rows + 127) / 128));
+        static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;                 // A/B: the round-2 f32 MFMA scan throughout
+        const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
+        const int64_t q_plane = (int64_t)1024 * D;
+        if (!f32_only && nq > 32) {
+            const int64_t nel = (int64_t)padded * D;
+            hipLaunchKernelGGL(k_split_q, dim3((unsigned)((nel / 2 + TPB - 1) / TPB)), block, 0, s, x->l_q, nel, x->l_qp);
+            // k_split_q wrote planes nel apart; the scan indexes them with the same stride
+            while (done < nq) {
+                const int left = nq - done;
+                ++passes;
+#define BX_LAUNCH(NTV, ADV)                                                                                                        \
+    do {                                                                                                                            \
+        const size_t lds = (size_t)2 * 3 * (NTV * 32) * BX_PITCH * sizeof(uint16_t);                                               \
+        (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL((k_cosine_bf16x3<NTV>), mgrid, block, lds, s, rows, n_rows, D, (const uint16_t *)x->l_qp, nel, done, nq,  \
+                           x->l_sims, sstride);                                                                                     \
+        done += ADV;                                                                                                                \
+    } while (0)
+                if (left > 128) BX_LAUNCH(8, 256);
+                else if (left > 64) BX_LAUNCH(4, 128);
+                else BX_LAUNCH(2, 64);
+#undef BX_LAUNCH
+            }
+            (void)q_plane;
+        }
         while (done < nq) {
             const int left = nq - done;
             ++passes;
