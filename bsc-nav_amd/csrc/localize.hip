@@ -352,10 +352,45 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *(uint4 *)&Qs[buf * BUF + (p * QROWS + q) * BX_PITCH + part * 8] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
         }
     };
+    // A fragments of one sub-step (8 k of every query tile, three pieces) as vector values; the fragments of the NEXT sub-step
+    // are read from LDS while the 6 NT MFMAs of the current one run (software pipeline over (chunk, sub-step) phases)
+    typedef uint32_t fr_t __attribute__((ext_vector_type(12 * NT)));
+    auto load_frags = [&](fr_t &f, int buf, int sstep) {
+        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16 + sstep * 8];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint4 v = *(const uint4 *)(qb + (p * QROWS + t * 32) * BX_PITCH);
+                f[4 * (p * NT + t)] = v.x; f[4 * (p * NT + t) + 1] = v.y; f[4 * (p * NT + t) + 2] = v.z; f[4 * (p * NT + t) + 3] = v.w;
+            }
+    };
+    auto frag = [&](const fr_t &f, int p, int t) {
+        uint4 v = make_uint4(f[4 * (p * NT + t)], f[4 * (p * NT + t) + 1], f[4 * (p * NT + t) + 2], f[4 * (p * NT + t) + 3]);
+        return *(bf16x8_t *)&v;
+    };
+    auto mma6 = [&](const fr_t &f, const uint32_t (&bh)[4], const uint32_t (&bm)[4], const uint32_t (&bl)[4]) {
+        const bf16x8_t xh = *(const bf16x8_t *)bh, xm = *(const bf16x8_t *)bm, xl = *(const bf16x8_t *)bl;
+        // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 2, t), xh, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 1, t), xm, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xl, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 1, t), xh, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xm, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xh, acc[t], 0, 0, 0);
+    };
     load_x(0);
     load_q(0);
     store_q(0);
     __syncthreads();
+    fr_t fa, fb;
+    load_frags(fa, 0, 0);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         // this chunk's rows -> bf16 pieces (two sub-steps of 8 floats), then the next chunk's loads go in flight
@@ -368,33 +403,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             split3(v.z, v.w, bh[i >> 1][2 * (i & 1) + 1], bm[i >> 1][2 * (i & 1) + 1], bl[i >> 1][2 * (i & 1) + 1]);
         }
         if (c + 1 < nchunks) { load_x(c + 1); load_q(c + 1); }
-        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16];
-#pragma unroll
-        for (int sstep = 0; sstep < 2; ++sstep) {
-            const bf16x8_t xh = *(const bf16x8_t *)bh[sstep], xm = *(const bf16x8_t *)bm[sstep], xl = *(const bf16x8_t *)bl[sstep];
-            bf16x8_t ah[NT], am[NT], al[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                ah[t] = *(const bf16x8_t *)(qb + (0 * QROWS + t * 32) * BX_PITCH + sstep * 8);
-                am[t] = *(const bf16x8_t *)(qb + (1 * QROWS + t * 32) * BX_PITCH + sstep * 8);
-                al[t] = *(const bf16x8_t *)(qb + (2 * QROWS + t * 32) * BX_PITCH + sstep * 8);
-            }
-            // smallest terms first; consecutive MFMAs go to different accumulators
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], xh, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], xm, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xl, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], xh, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xm, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], xh, acc[t], 0, 0, 0);
-        }
+        load_frags(fb, buf, 1);                             // sub-step 1 of this chunk: in flight under sub-step 0's MFMAs
+        mma6(fa, bh[0], bm[0], bl[0]);
         if (c + 1 < nchunks) store_q(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                    // the other buffer holds chunk c + 1
+        if (c + 1 < nchunks) load_frags(fa, buf ^ 1, 0);    // its sub-step 0: in flight under sub-step 1's MFMAs
+        mma6(fb, bh[1], bm[1], bl[1]);
     }
     nrm += __shfl_xor(nrm, 32);
     const float inv = 1.0f / fmaxf(sqrtf(nrm), 1e-8f);
