@@ -843,12 +843,12 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     int passes = 0;                          // times the row matrix is streamed
     if (nq >= BSC_MFMA_MIN_Q && D % MF_KC == 0 && n_rows > 0) {
         // batched queries on the matrix cores, 32-query tiles (l_q is zero-padded to a multiple of 256 rows): more than 32
-        // queries -> bf16 pieces at f32 accuracy (k_cosine_bf16x3); up to 32 -> the f32 MFMA, HBM-bound at that size anyway
+        // 64 queries -> bf16 pieces at f32 accuracy (k_cosine_bf16x3); up to 64 -> the f32 MFMA, HBM-bound at that size anyway
         const dim3 mgrid((unsigned)((n_rows + 127) / 128));
         static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;                 // A/B: the round-2 f32 MFMA scan throughout
         const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
         const int64_t q_plane = (int64_t)1024 * D;
-        if (!f32_only && nq > 32) {
+        if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
             const int64_t nel = (int64_t)padded * D;
             hipLaunchKernelGGL(k_split_q, dim3((unsigned)((nel / 2 + TPB - 1) / TPB)), block, 0, s, x->l_q, nel, x->l_qp);
             // k_split_q wrote planes nel apart; the scan indexes them with the same stride
@@ -865,7 +865,7 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
     } while (0)
                 if (left > 128) BX_LAUNCH(8, 256);
                 else if (left > 64) BX_LAUNCH(4, 128);
-                else BX_LAUNCH(2, 64);
+                else { --passes; break; }                    // the remainder (<= 64 queries) goes to the f32 MFMA below
 #undef BX_LAUNCH
             }
             (void)q_plane;
