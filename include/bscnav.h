@@ -132,7 +132,10 @@ bsc_status bsc_pool_query(bsc_ctx *ctx, const float *tokens_dev, int32_t B, int3
 /* voxel_localized scan (memory_2.py:623-671) for n_queries pooled queries q_dev (Q,D):
  * cosine vs every stored token, per-voxel max, stable top-K in HDF5 name order.
  * radius<0 disables the sphere filter (:624-629); floor_lo>floor_hi disables the floor filter (:633-640).
- * out_pos_host (Q,K,3) i32, out_sim_host (Q,K) f32, out_count_host (Q) = rows actually written. */
+ * out_pos_host (Q,K,3) i32, out_sim_host (Q,K) f32, out_count_host (Q) = rows actually written.
+ * Arithmetic: f32 dot products and norms (F.cosine_similarity, :655) — on the vector ALUs up to 4 queries, on the f32 matrix
+ * cores up to 64, and beyond that on the bf16 matrix cores with every f32 operand split exactly into three bf16 pieces (the six
+ * piece products of weight >= 2^-16, f32 accumulation: truncation 2^-24 per product, scores within 3e-6 of an fp64 scan). */
 bsc_status bsc_localize(bsc_ctx *ctx, const float *q_dev, int32_t n_queries, int32_t K, double radius,
                         const int32_t *curr_host, int32_t floor_lo, int32_t floor_hi, int32_t *out_pos_host,
                         float *out_sim_host, int32_t *out_count_host);
