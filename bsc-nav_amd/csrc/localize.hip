@@ -302,18 +302,21 @@ __global__ __launch_bounds__(TPB) void k_split_q(const float *__restrict__ qn, i
     *(uint32_t *)(qp + 2 * n + i) = l;
 }
 
-template <int NT>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_cosine_bf16x3(const float *__restrict__ X, int64_t n_rows, int D,
+// WV wavefronts per workgroup, 32 rows each: WV = 8 puts two wavefronts on every SIMD (256 registers each) that share one staged
+// query chunk — one covers the other's LDS / global / barrier waits
+template <int NT, int WV>
+__global__ __launch_bounds__(64 * WV) void k_cosine_bf16x3(const float *__restrict__ X, int64_t n_rows, int D,
                                                        const uint16_t *__restrict__ qp, int64_t q_plane, int q0, int q_valid,
                                                        float *__restrict__ sims, int64_t sims_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t Qs[];           // [2][3][NT * 32][BX_PITCH]
     constexpr int QROWS = NT * 32;
     constexpr int BUF = 3 * QROWS * BX_PITCH;
-    constexpr int NLD = 3 * QROWS * 4 / TPB;                                 // 16-byte pieces of a query chunk per thread
+    constexpr int NTHR = 64 * WV;
+    constexpr int NLD = 3 * QROWS * 4 / NTHR;                                 // 16-byte pieces of a query chunk per thread
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int64_t row0 = (int64_t)blockIdx.x * (32 * WV);
     const int64_t row = row0 + w * 32 + n;
     const int64_t rowc = row < n_rows ? row : n_rows - 1;                  // clamped: results of padded rows are not stored
     const float *xrow = X + rowc * D + g * 16;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load_q = [&](int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = tid + TPB * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            const int i = tid + NTHR * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
             const uint4 v = *(const uint4 *)(qp + (int64_t)p * q_plane + (int64_t)(q0 + q) * D + c * BX_KC + part * 8);
             qr[4 * j] = v.x; qr[4 * j + 1] = v.y; qr[4 * j + 2] = v.z; qr[4 * j + 3] = v.w;
         }
@@ -348,49 +351,14 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto store_q = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = tid + TPB * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            const int i = tid + NTHR * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
             *(uint4 *)&Qs[buf * BUF + (p * QROWS + q) * BX_PITCH + part * 8] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
         }
-    };
-    // A fragments of one sub-step (8 k of every query tile, three pieces) as vector values; the fragments of the NEXT sub-step
-    // are read from LDS while the 6 NT MFMAs of the current one run (software pipeline over (chunk, sub-step) phases)
-    typedef uint32_t fr_t __attribute__((ext_vector_type(12 * NT)));
-    auto load_frags = [&](fr_t &f, int buf, int sstep) {
-        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16 + sstep * 8];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4 v = *(const uint4 *)(qb + (p * QROWS + t * 32) * BX_PITCH);
-                f[4 * (p * NT + t)] = v.x; f[4 * (p * NT + t) + 1] = v.y; f[4 * (p * NT + t) + 2] = v.z; f[4 * (p * NT + t) + 3] = v.w;
-            }
-    };
-    auto frag = [&](const fr_t &f, int p, int t) {
-        uint4 v = make_uint4(f[4 * (p * NT + t)], f[4 * (p * NT + t) + 1], f[4 * (p * NT + t) + 2], f[4 * (p * NT + t) + 3]);
-        return *(bf16x8_t *)&v;
-    };
-    auto mma6 = [&](const fr_t &f, const uint32_t (&bh)[4], const uint32_t (&bm)[4], const uint32_t (&bl)[4]) {
-        const bf16x8_t xh = *(const bf16x8_t *)bh, xm = *(const bf16x8_t *)bm, xl = *(const bf16x8_t *)bl;
-        // smallest terms first; consecutive MFMAs go to different accumulators
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 2, t), xh, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 1, t), xm, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xl, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 1, t), xh, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xm, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(f, 0, t), xh, acc[t], 0, 0, 0);
     };
     load_x(0);
     load_q(0);
     store_q(0);
     __syncthreads();
-    fr_t fa, fb;
-    load_frags(fa, 0, 0);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         // this chunk's rows -> bf16 pieces (two sub-steps of 8 floats), then the next chunk's loads go in flight
@@ -403,12 +371,34 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             split3(v.z, v.w, bh[i >> 1][2 * (i & 1) + 1], bm[i >> 1][2 * (i & 1) + 1], bl[i >> 1][2 * (i & 1) + 1]);
         }
         if (c + 1 < nchunks) { load_x(c + 1); load_q(c + 1); }
-        load_frags(fb, buf, 1);                             // sub-step 1 of this chunk: in flight under sub-step 0's MFMAs
-        mma6(fa, bh[0], bm[0], bl[0]);
+        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16];
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+            const bf16x8_t xh = *(const bf16x8_t *)bh[sstep], xm = *(const bf16x8_t *)bm[sstep], xl = *(const bf16x8_t *)bl[sstep];
+            // one piece of the queries at a time (NT fragments live instead of 3 NT): l is used once, m twice, h three times;
+            // smallest terms first; consecutive MFMAs go to different accumulators
+            bf16x8_t af[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (2 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (1 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xm, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (0 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xm, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
+        }
         if (c + 1 < nchunks) store_q(buf ^ 1);
-        __syncthreads();                                    // the other buffer holds chunk c + 1
-        if (c + 1 < nchunks) load_frags(fa, buf ^ 1, 0);    // its sub-step 0: in flight under sub-step 1's MFMAs
-        mma6(fb, bh[1], bm[1], bl[1]);
+        __syncthreads();
     }
     nrm += __shfl_xor(nrm, 32);
     const float inv = 1.0f / fmaxf(sqrtf(nrm), 1e-8f);
@@ -845,7 +835,8 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         // batched queries on the matrix cores, 32-query tiles (l_q is zero-padded to a multiple of 256 rows): more than 32
         // 64 queries -> bf16 pieces at f32 accuracy (k_cosine_bf16x3); up to 64 -> the f32 MFMA, HBM-bound at that size anyway
         const dim3 mgrid((unsigned)((n_rows + 127) / 128));
-        static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;                 // A/B: the round-2 f32 MFMA scan throughout
+        static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;
+        static const bool wv8 = getenv("BSC_COSINE_WV4") == nullptr;                     // A/B: 8 (default) or 4 wavefronts per workgroup                 // A/B: the round-2 f32 MFMA scan throughout
         const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
         const int64_t q_plane = (int64_t)1024 * D;
         if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
@@ -858,9 +849,15 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
 #define BX_LAUNCH(NTV, ADV)                                                                                                        \
     do {                                                                                                                            \
         const size_t lds = (size_t)2 * 3 * (NTV * 32) * BX_PITCH * sizeof(uint16_t);                                               \
-        (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL((k_cosine_bf16x3<NTV>), mgrid, block, lds, s, rows, n_rows, D, (const uint16_t *)x->l_qp, nel, done, nq,  \
-                           x->l_sims, sstride);                                                                                     \
+        if (wv8) {                                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_cosine_bf16x3<NTV, 8>), dim3((unsigned)((n_rows + 255) / 256)), dim3(512), lds, s, rows, n_rows, D, \
+                               (const uint16_t *)x->l_qp, nel, done, nq, x->l_sims, sstride);                                       \
+        } else {                                                                                                                    \
+            (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_cosine_bf16x3<NTV, 4>), mgrid, block, lds, s, rows, n_rows, D, (const uint16_t *)x->l_qp, nel,    \
+                               done, nq, x->l_sims, sstride);                                                                       \
+        }                                                                                                                           \
         done += ADV;                                                                                                                \
     } while (0)
                 if (left > 128) BX_LAUNCH(8, 256);
