@@ -368,7 +368,11 @@ def localize_leg(B, a, local_rank, D, V=1 << 20, gL=512):
         ls = engL.kernel_stats(1)
         ms = ls["ms"] / max(1, ls["launches"])
         e = {"latency_ms": statistics.median(lats) * 1e3, "cosine_ms": ms}
-        if Q >= 16:     # fp32-MFMA GEMM path: priced against the 157.3 TFLOP/s fp32 matrix peak
+        if Q > 64:      # bf16 matrix cores at f32 accuracy (k_cosine_bf16x3): six bf16 MFMAs per f32 product
+            tf = 2.0 * V * D * Q / (ms * 1e-3) / 1e12
+            e.update({"cosine_f32_equivalent_TFLOPs": tf, "cosine_bf16_mfma_TFLOPs": 6.0 * tf,
+                      "cosine_frac_of_bf16_mfma_peak": 6.0 * tf / MFMA_BF16_PEAK_TF})
+        elif Q >= 16:   # fp32-MFMA GEMM path: priced against the 157.3 TFLOP/s fp32 matrix peak
             tf = 2.0 * V * D * Q / (ms * 1e-3) / 1e12
             e.update({"cosine_TFLOPs": tf, "cosine_frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TF})
         else:
