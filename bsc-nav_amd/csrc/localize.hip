@@ -838,7 +838,6 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;
         static const bool wv8 = getenv("BSC_COSINE_WV4") == nullptr;                     // A/B: 8 (default) or 4 wavefronts per workgroup                 // A/B: the round-2 f32 MFMA scan throughout
         const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
-        const int64_t q_plane = (int64_t)1024 * D;
         if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
             const int64_t nel = (int64_t)padded * D;
             hipLaunchKernelGGL(k_split_q, dim3((unsigned)((nel / 2 + TPB - 1) / TPB)), block, 0, s, x->l_q, nel, x->l_qp);
@@ -865,7 +864,6 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
                 else { --passes; break; }                    // the remainder (<= 64 queries) goes to the f32 MFMA below
 #undef BX_LAUNCH
             }
-            (void)q_plane;
         }
         while (done < nq) {
             const int left = nq - done;
