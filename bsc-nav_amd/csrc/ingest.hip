@@ -822,21 +822,26 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
                                                 int32_t *__restrict__ seg_vid, int64_t *bscal)
 {
     __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
-    __shared__ int64_t s_grp[EB / 64];
+    __shared__ uint32_t s_grp[EB / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    // exclusive prefix of (length | head << 32) inside the block: per 64-run group totals, then lanes
-    int64_t item[EB / TPB], incl[EB / TPB];
+    // exclusive prefix of (length, head) inside the block, both in ONE 32-bit word — a block's 1024 runs hold at most 2^20
+    // points (bits 0..20) and 1024 heads (bits 21..31) — scanned with DPP row shifts instead of 64-bit shuffles
+    uint32_t item[EB / TPB], incl[EB / TPB];
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
         const int64_t i = (int64_t)blockIdx.x * EB + (r * (TPB / 64) + wid) * 64 + lane;      // group g = r * 4 + wid
-        item[r] = run_item(rkey_sorted, i, R, vmask, vb);
-        int64_t v = item[r];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int64_t t = __shfl_up(v, o);
-            if (lane >= o) v += t;
-        }
+        const int64_t it = run_item(rkey_sorted, i, R, vmask, vb);
+        item[r] = (uint32_t)(it & 0x1fffff) | ((uint32_t)(it >> 32) << 21);
+        uint32_t v = item[r];
+#define BSC_ISCAN_STEP(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false);
+        BSC_ISCAN_STEP(0x111, 0xf)                   // row_shr:1
+        BSC_ISCAN_STEP(0x112, 0xf)                   // row_shr:2
+        BSC_ISCAN_STEP(0x114, 0xf)                   // row_shr:4
+        BSC_ISCAN_STEP(0x118, 0xf)                   // row_shr:8
+        BSC_ISCAN_STEP(0x142, 0xa)                   // row_bcast:15 into rows 1 and 3
+        BSC_ISCAN_STEP(0x143, 0xc)                   // row_bcast:31 into rows 2 and 3
+#undef BSC_ISCAN_STEP
         incl[r] = v;
         if (lane == 63) s_grp[r * (TPB / 64) + wid] = v;
     }
@@ -845,9 +850,10 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
         const int g = r * (TPB / 64) + wid;
-        int64_t pre = base;
-        for (int k = 0; k < g; ++k) pre += s_grp[k];
-        const int64_t sc = pre + incl[r] - item[r];                 // exclusive prefix of this run
+        uint32_t pre32 = 0;
+        for (int k = 0; k < g; ++k) pre32 += s_grp[k];
+        pre32 += incl[r] - item[r];                                 // exclusive prefix of this run inside the block
+        const int64_t sc = base + (int64_t)(pre32 & 0x1fffffu) + ((int64_t)(pre32 >> 21) << 32);
         const int64_t i = (int64_t)blockIdx.x * EB + g * 64 + lane;
         int32_t off = INT_MAX, len = 0, j0 = 0;
         if (i < R) {
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
             off = (int32_t)(sc & 0xffffffffll);
             if (v != vmask) {
                 len = (int32_t)(key >> vb) + 1;
-                const bool head = (item[r] >> 32) != 0;
+                const bool head = (item[r] >> 21) != 0;
                 if (head) { seg_k0[sc >> 32] = off; seg_vid[sc >> 32] = (int32_t)v; }
                 if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = (int64_t)off + len; }
             } else if (i == R - 1) {
