@@ -680,19 +680,23 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[kk], acc[t], 0, 0, 0);
                 }
             }
-            // padded keys leave the softmax with -inf; for the usual lengths only the last two tiles have any
+            // padded keys leave the softmax with -inf; for the usual lengths only the last two tiles have any.  The lane's key
+            // limit is made opaque per strip: left loop-invariant, the compiler evaluates all 4 NT comparisons once per kernel
+            // into scalar mask pairs, runs out of SGPRs and spills them into VGPR lanes (72 v_readlane per strip)
+            int lim = T - g * 4;
+            asm volatile("" : "+v"(lim));
             if (T > 16 * (NT - 2)) {
 #pragma unroll
                 for (int t = NT - 2; t < NT; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (t * 16 + g * 4 + i >= T) acc[t][i] = -INFINITY;
+                        if (t * 16 + i >= lim) acc[t][i] = -INFINITY;
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (t * 16 + g * 4 + i >= T) acc[t][i] = -INFINITY;
+                        if (t * 16 + i >= lim) acc[t][i] = -INFINITY;
             }
             f32x4_t mv = acc[0];
 #pragma unroll
