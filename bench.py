@@ -227,7 +227,9 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     the bf16 encoder + bf16 tokens against the f32 encoder + f32 tokens (same frames, same voxels)."""
     B = p.B
     from bsc_nav_amd import encoder
+    tuning_was_on = None
     try:                                            # library-default f32 GEMM solutions: no TunableOp search for this leg
+        tuning_was_on = torch.cuda.tunable.tuning_is_enabled()
         torch.cuda.tunable.tuning_enable(False)
     except Exception:
         pass
@@ -262,7 +264,8 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     del vit32
     torch.cuda.empty_cache()
     try:
-        torch.cuda.tunable.tuning_enable(True)
+        if tuning_was_on:
+            torch.cuda.tunable.tuning_enable(True)
     except Exception:
         pass
     assert np.array_equal(cnt16, cnt32)
