@@ -1031,7 +1031,8 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     // soonest (hall: 128 / 256 / 512 waves = 6.7 / 4.6 / 2.6 ms); a tail-bound call is indifferent to it.  Two wavefronts
     // per SIMD (workgroups of 8) slow the tail itself: 6 -> 9 ms.
     stat_begin(x, BSC_STAT_CHAIN, x->side);
-    hipLaunchKernelGGL(k_chain, dim3(CHAIN_WAVES * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
+    static const int chain_waves = getenv("BSC_CHAIN_WAVES") ? atoi(getenv("BSC_CHAIN_WAVES")) : CHAIN_WAVES;
+    hipLaunchKernelGGL(k_chain, dim3(chain_waves * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
                        x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
                        x->chain_order_base);
     static const int long_waves = getenv("BSC_LONG_WAVES") ? atoi(getenv("BSC_LONG_WAVES")) : LONG_WAVES;
