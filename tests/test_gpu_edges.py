@@ -453,3 +453,71 @@ def test_token_store_grows_like_the_unbounded_reference_store():
     assert n[0] == 5
     for e in (big, small, half, cont_big, cont_small):
         e.close()
+
+
+def test_selection_filter_overflow_falls_back_to_the_exact_rounds():
+    """The batched top-K takes its per-query threshold from a sample of 16 blocks spread over the map and keeps the candidates that
+    beat it.  When the sample is unrepresentative — here every sampled block holds rows orthogonal to the queries while all other
+    rows score high, so ~7/8 of 2^17 candidates beat the threshold and the survivor list (32768) overflows — the call must notice
+    and fall back to the direct rounds: same answer as an fp64 scan."""
+    import torch
+    import bsc_nav_amd as B
+    import golden_util as gu
+    V, D, gs, K, Q = 1 << 17, 64, 64, 100, 8
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    codes = torch.randperm(gs ** 3, device="cuda", generator=gen)[:V]
+    keys = torch.stack([codes // (gs * gs), (codes // gs) % gs, codes % gs], dim=1).to(torch.int32).contiguous()
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    q[:, D // 2:] = 0                                                    # queries live in the first half of the dimensions
+    rows = torch.randn((V, D), device="cuda", generator=gen)
+    blk = torch.arange(V, device="cuda") // 1024                         # the sample takes blocks 0, 8, 16, ... of the 128
+    sampled = (blk % 8) == 0
+    rows[sampled, :D // 2] = 0                                           # sampled rows: orthogonal to every query (similarity 0)
+    rows[~sampled, :D // 2] = rows[~sampled, :D // 2].abs() * torch.sign(q[0, :D // 2])    # the others: aligned with query 0
+    eng = B.VoxelEngine(48, 64, gs, 0.1, -3.2, 3.2, 16, D, mode="mean", voxel_capacity=V + 8, max_points=4096)
+    eng.dense_replace(keys, rows.contiguous(), torch.ones(V, dtype=torch.int32, device="cuda"))
+    pos, sim, n = eng.localize(q, K=K)
+    rn = rows.double() / rows.double().norm(dim=1, keepdim=True).clamp_min(1e-8)
+    ref = (q.double() / q.double().norm(dim=1, keepdim=True)) @ rn.T
+    top = torch.topk(ref, K, dim=1)
+    kk = keys.cpu().numpy()
+    for i in range(Q):
+        assert n[i] == K
+        gu.assert_topk_near(pos[i], sim[i], kk[top.indices[i].cpu().numpy()], top.values[i].cpu().numpy(), tol=2e-6)
+    assert sim[0, K - 1] > 0.5                                           # query 0's answers come from the unsampled rows
+    eng.close()
+
+
+def test_point_log_capacity_and_empty_replay():
+    """The point log refuses a call that would overflow it before anything is changed; bsc_replay_colour leaves voxels without
+    records at zero."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    H, W, g, D, F = 48, 64, 16, 16, 2
+    rgb, depth, poses = synth.make_frames(9, F, H, W, "room")
+    tokens = synth.make_tokens(9, F, g, D)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    eng = B.VoxelEngine(H, W, 128, 0.1, -6.4, 6.4, g, D, mode="mean", voxel_capacity=50_000, max_points=H * W)
+    eng.point_log_enable(H * W + 10)
+    d, c, t = (torch.from_numpy(a).cuda() for a in (depth, rgb, tokens))
+    eng.ingest(d[:1], c[:1], t[:1], Ts[:1])
+    before = (eng.export_rgb(), eng.export_dense())
+    with pytest.raises(B._lib.BscError, match="point log full"):
+        eng.ingest(d[1:2], c[1:2], t[1:2], Ts[1:2])
+    after = (eng.export_rgb(), eng.export_dense())
+    for a, b in zip(before, after):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    cells, recs = eng.point_log()
+    assert cells.numel() == H * W and recs.shape == (H * W, 3)
+    vox = torch.tensor([1, 1, 3], dtype=torch.int32, device="cuda")      # voxels 0, 2, 4 have no record
+    r = torch.tensor([[0, 0x3ff00000, 0x0a0b0c], [0, 0x3fe00000, 0x010203], [0, 0x3fd00000, 0x040506]], dtype=torch.int32, device="cuda")
+    out_rgb, out_w = eng.replay_colour(vox, r, 5)
+    assert out_rgb.cpu().tolist()[0] == [0, 0, 0] and out_rgb.cpu().tolist()[2] == [0, 0, 0] and out_rgb.cpu().tolist()[4] == [0, 0, 0]
+    assert out_rgb.cpu().tolist()[3] == [6, 5, 4] and float(out_w[3]) == 0.25 and float(out_w[0]) == 0.0
+    # voxel 1: first point (alpha 1: colour 0x0a0b0c, weight 1), then alpha 0.5 with colour 0x010203
+    c0 = [0x0c, 0x0b, 0x0a]
+    exp = [int((np.float64(np.float32(c0[k]) * np.float32(1.0)) + [3, 2, 1][k] * 0.5) / 1.5) for k in range(3)]
+    assert out_rgb.cpu().tolist()[1] == exp and float(out_w[1]) == 1.5
+    eng.close()
