@@ -105,6 +105,8 @@ struct bsc_ctx {
     int32_t *blk_pass, *blk_pass_off;   // per block: passing points
     int32_t *hb_cnt, *hb_off;           // segment-head compaction (dense.hip compact_heads): per-block counts / offsets
     int64_t nblk_cap;
+    uint32_t *stage_cell, *stage_pos;   // k_points: the runs of every block of points (cell, first position), slice b * GB
+    int group_rpw;                      // rounds of 64 points per wavefront in k_points: 4 (1024-point blocks) or 8 (2048; BSC_GROUP_RPW)
     uint32_t *skey_a, *sval_a;          // run sort input: key = voxel id | (length - 1) << id bits, value = first point
     uint32_t *skey_b_s[2];              // sorted run keys
     uint32_t *run_val_b;                // sorted run values

@@ -231,6 +231,8 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
+    ALLOC(x->stage_cell, np + 2048); ALLOC(x->stage_pos, np + 2048);
+    x->group_rpw = getenv("BSC_GROUP_RPW") && atoi(getenv("BSC_GROUP_RPW")) == 8 ? 8 : 4;
     ALLOC(x->new_cells, np); ALLOC(x->run_val_b, np); ALLOC(x->run_scan, np); ALLOC(x->seg_k0, np); ALLOC(x->seg_vid, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);
@@ -306,7 +308,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->l_name_rank, x->l_q, x->l_qp, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
                     x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
-                    x->fr_centers, x->fr_gains, x->log_cell, x->log_rec};
+                    x->fr_centers, x->fr_gains, x->log_cell, x->log_rec, x->stage_cell, x->stage_pos};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);

@@ -56,54 +56,93 @@ __device__ __forceinline__ int frame_of(const int64_t *offsets, int n_frames, in
 }
 
 // ------------------------------------------------------------------------------------------------
-#define FB 1024                 // consecutive points per workgroup
-#define PPT (FB / TPB)          // points per thread, strided by TPB (coalesced rounds)
+// k_points: geometry of GB consecutive points per workgroup + BLOCK-LOCAL STABLE GROUPING of their records by cell.
+//
+// The rgb chain needs every voxel's points in order j.  Sorting the points is out of the question (1.2e8 per call), and a
+// "run" of consecutive same-cell points is short where a surface lies on a voxel boundary (1.9 points in the bench scene).
+// So the block groups its own points: the records of a cell are written next to each other (in order j) inside the block's
+// slice of p_rec, and the block emits ONE run per distinct cell — 4.5x (GB = 1024) to 8x (GB = 2048) fewer runs to sort,
+// expand and gather, and the chain reads its records as contiguous stretches instead of one 128-byte line per 12-byte record.
+// Order inside a voxel stays j: blocks are consecutive in j, the grouping is stable, the run sort is stable.
+//
+// Stable rank of a point inside its group without sorting: wavefront wv owns the points [wv * RPW * 64, (wv + 1) * RPW * 64) of
+// the block and walks them in rounds of 64 (in order).  A cell gets a slot e of a workgroup-wide LDS hash table; in a round
+// every lane ORs its bit into the wavefront's 64-bit word of that slot — the word is the ballot of the cell — so
+//     rank inside the wavefront = points of the cell in the wavefront's earlier rounds (s_cnt[wv][e]) + popc(word & lanes below),
+// and after the barrier the exclusive prefix over slots (group base) and over wavefronts finishes the position.  OR is
+// order-free, so the layout does not depend on how the LDS serialises the lanes.  A cell that finds no slot within
+// GROUP_PROBES probes (more distinct cells than the table holds: one voxel per point) keeps its points as runs of one,
+// placed after the groups in order j.  Which slot a cell gets depends on the race for it; the RESULT does not.
+#define GW (TPB / 64)           // wavefronts per workgroup
+#define GROUP_HS 512            // hash slots per workgroup
+#define GROUP_HS_LOG2 9
+#define GROUP_PROBES 8
+#define GROUP_OVF 0xffffu
 
-// Head flags of a block's points: point p (0 <= p < FB, order round-major: p = r * TPB + tid) starts a run when its
-// cell differs from the cell of point p - 1, at the block's first point, and at every multiple of `cap` (a run's
-// length has to fit the bits left beside the voxel id in the sort key).  cells[r] = cell of point r * TPB + tid
-// (-1: no voxel; points beyond P carry -2 so that the last real run ends at P).
-__device__ __forceinline__ void block_heads(const int32_t (&cell)[PPT], int cap_mask, int32_t (*s_edge)[TPB / 64], bool (&head)[PPT])
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
 {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < PPT; ++r)
-        if (lane == 63) s_edge[r][wid] = cell[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        int32_t prev = __shfl_up(cell[r], 1);
-        if (lane == 0) {
-            if (wid > 0) prev = s_edge[r][wid - 1];
-            else prev = r > 0 ? s_edge[r - 1][TPB / 64 - 1] : cell[r] - 1;      // block start: forced head
-        }
-        const int p = r * TPB + (int)threadIdx.x;
-        head[r] = prev != cell[r] || (p & cap_mask) == 0;
-    }
+#define BSC_USCAN_STEP(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false);
+    BSC_USCAN_STEP(0x111, 0xf)                   // row_shr:1
+    BSC_USCAN_STEP(0x112, 0xf)                   // row_shr:2
+    BSC_USCAN_STEP(0x114, 0xf)                   // row_shr:4
+    BSC_USCAN_STEP(0x118, 0xf)                   // row_shr:8
+    BSC_USCAN_STEP(0x142, 0xa)                   // row_bcast:15 into rows 1 and 3
+    BSC_USCAN_STEP(0x143, 0xc)                   // row_bcast:31 into rows 2 and 3
+#undef BSC_USCAN_STEP
+    return v;
+}
+
+// LDS accesses of ONE wavefront execute in program order; this keeps the compiler from reordering them
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // FAST: geom_point_fast (pinhole intrinsics, patch tables; GeomConst.fast) — otherwise the generic fma chains.
-template <bool FAST>
+// RPW: rounds of 64 points per wavefront; GB = GW * RPW * 64 points per workgroup.
+template <bool FAST, int RPW>
 __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__restrict__ depth,
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
                                                 const int32_t *__restrict__ idx, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
-                                                const double *__restrict__ alpha_in, int64_t P, float inv_w, int cap_mask,
+                                                const double *__restrict__ alpha_in, int64_t P, float inv_w, int cap_log2,
                                                 int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
                                                 PointRec *__restrict__ p_rec, float *__restrict__ p_r2f,
                                                 int32_t *__restrict__ new_cells, int64_t *dscal,
-                                                int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass)
+                                                int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass,
+                                                uint32_t *__restrict__ stage_cell, uint32_t *__restrict__ stage_pos,
+                                                int32_t *__restrict__ g_cell)
 {
-    __shared__ int32_t s_edge[PPT][TPB / 64];
-    __shared__ int s_heads, s_pass;
-    if (threadIdx.x == 0) { s_heads = 0; s_pass = 0; }
-    const int lane = threadIdx.x & 63;
+    constexpr int GB = GW * RPW * 64;
+    constexpr int EPT = GROUP_HS / TPB;         // slots per thread in the prefix pass
+    __shared__ uint32_t s_key[GROUP_HS];
+    __shared__ u64 s_word[GW][GROUP_HS + 1];             // + a spare entry for the lanes without a slot
+    __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];
+    __shared__ uint32_t s_rec[3 * GB];
+    __shared__ uint32_t s_wsum[GW];
+    __shared__ int32_t s_ovf[GW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u64 lanes_below = (1ull << lane) - 1ull;
+    for (int i = tid; i < GROUP_HS; i += TPB) s_key[i] = 0xffffffffu;
+    for (int i = tid; i < GW * (GROUP_HS + 1); i += TPB) { (&s_word[0][0])[i] = 0ull; (&s_cnt[0][0])[i] = 0u; }
+    __syncthreads();
+
     const int32_t N = gc.H * gc.W;
-    int32_t cells[PPT];
+    const int64_t blk_base = (int64_t)blockIdx.x * GB;
+    // frame / pixel of the wavefront's first point (all-pixel ingest); P <= max_points < 2^31
+    const uint32_t jw = (uint32_t)blk_base + (uint32_t)(wv * RPW * 64);
+    const int fw = (int)(jw / (uint32_t)N);
+    const int32_t iw = (int32_t)(jw - (uint32_t)fw * (uint32_t)N);
+    int32_t cells[RPW];
+    uint32_t sr[RPW], ralo[RPW], rahi[RPW], rrgb[RPW];
+    int ovf_cnt = 0;
 #pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
         int32_t cell = -2;
+        ralo[r] = rahi[r] = rrgb[r] = 0u;
         if (j < P) {
             int f;
             int32_t i;
@@ -111,12 +150,11 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 f = frame_of(offsets, n_frames, j);
                 i = idx[j];
             } else {
-                // frame of the round's first point on the scalar unit; a round straddles at most one frame boundary
-                // when N >= TPB (smaller frames take the per-thread division)
-                const uint32_t j0 = blockIdx.x * (uint32_t)FB + (uint32_t)(r * TPB);      // P <= max_points < 2^31
-                int fb = (int)(j0 / (uint32_t)N);
-                int32_t ib = (int32_t)(j0 - (uint32_t)fb * (uint32_t)N) + (int32_t)threadIdx.x;
-                if (N >= TPB) {
+                // a wavefront's RPW * 64 consecutive points straddle at most one frame boundary when N >= GB (smaller frames
+                // take the per-thread division)
+                int fb = fw;
+                int32_t ib = iw + r * 64 + lane;
+                if (N >= GB) {
                     if (ib >= N) { ib -= N; ++fb; }
                 } else {
                     fb += ib / N;
@@ -172,11 +210,9 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
                 if (p_r2f) p_r2f[j] = (float)r2;      // memory_2.py:885 grid_feat_dis is float32 (token cache only)
                 if (alpha_in) alpha = alpha_in[j];
-                PointRec rec;
-                rec.alo = (uint32_t)__double2loint(alpha);
-                rec.ahi = (uint32_t)__double2hiint(alpha);
-                rec.rgbv = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
-                p_rec[j] = rec;
+                ralo[r] = (uint32_t)__double2loint(alpha);
+                rahi[r] = (uint32_t)__double2hiint(alpha);
+                rrgb[r] = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
             }
             // first-touch claim: the smallest j wins an empty cell.  Of a stretch of lanes in one cell only the first
             // (smallest j) competes, and only while the cell is empty or claimed by a later point — so a batch in which
@@ -193,24 +229,118 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 unsigned long long base = 0;
                 if (lane == (int)(__ffsll((long long)fm) - 1)) base = atomicAdd((unsigned long long *)&dscal[DS_B_NNEW], (unsigned long long)__popcll(fm));
                 base = __shfl(base, __ffsll((long long)fm) - 1);
-                if (first) new_cells[base + __popcll(fm & ((1ull << lane) - 1ull))] = cell;
+                if (first) new_cells[base + __popcll(fm & lanes_below)] = cell;
             }
         }
         cells[r] = cell;
+        // ---- slot of the cell, rank of the point among the wavefront's points of that cell --------------------------------
+        uint32_t e = GROUP_OVF;
+        if (cell >= 0) {
+            uint32_t h = ((uint32_t)cell * 2654435761u) >> (32 - GROUP_HS_LOG2);
+#pragma unroll 1
+            for (int t = 0; t < GROUP_PROBES; ++t) {
+                uint32_t k = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (k == 0xffffffffu) {
+                    k = atomicCAS(&s_key[h], 0xffffffffu, (uint32_t)cell);
+                    if (k == 0xffffffffu) k = (uint32_t)cell;
+                }
+                if (k == (uint32_t)cell) { e = h; break; }
+                h = (h + 1) & (GROUP_HS - 1);
+            }
+        }
+        const bool grouped = e != GROUP_OVF;
+        const uint32_t slot = grouped ? e : (uint32_t)GROUP_HS;        // lanes without a slot meet in the spare entry (OR 0)
+        atomicOr((unsigned long long *)&s_word[wv][slot], grouped ? 1ull << lane : 0ull);
+        wave_lds_order();
+        const u64 word = __hip_atomic_load(&s_word[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t before = __hip_atomic_load(&s_cnt[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        wave_lds_order();
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, 0u));
+        uint32_t lr = before + rank;
+        if (grouped && rank == 0u) {             // the cell's first lane of the round: count the round, clear the word
+            __hip_atomic_store(&s_cnt[wv][slot], before + (uint32_t)__popcll(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(&s_word[wv][slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        wave_lds_order();
+        const u64 om = __ballot(cell >= 0 && !grouped);
+        if (!grouped) lr = (uint32_t)ovf_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+        ovf_cnt += __popcll(om);
+        sr[r] = cell >= 0 ? (e | (lr << 16)) : 0xffffffffu;
     }
-    // runs and passing points of the block
-    bool head[PPT];
-    block_heads(cells, cap_mask, s_edge, head);
-    int nh = 0, np = 0;
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        nh += (head[r] && cells[r] != -2) ? 1 : 0;
-        np += cells[r] >= 0 ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) { nh += __shfl_xor(nh, o); np += __shfl_xor(np, o); }
-    if (lane == 0) { atomicAdd(&s_heads, nh); atomicAdd(&s_pass, np); }
     __syncthreads();
-    if (threadIdx.x == 0) { blk_runs[blockIdx.x] = s_heads; blk_pass[blockIdx.x] = s_pass; }
+    // ---- group sizes -> positions: exclusive prefix over the slots (points | runs << 16), then over the wavefronts ----------
+    if (lane == 0) s_ovf[wv] = ovf_cnt;
+    uint32_t v[EPT], tv = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid * EPT + k;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < GW; ++w) tot += s_cnt[w][e];
+        const uint32_t nr = (tot + (1u << cap_log2) - 1u) >> cap_log2;     // a run's length has to fit its key bits
+        v[k] = tot | (nr << 16);
+        tv += v[k];
+    }
+    const uint32_t incl = wave_incl_sum_u32(tv);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t prefix = incl - tv, total = 0;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) {
+        const uint32_t ws = s_wsum[w];
+        if (w < wv) prefix += ws;
+        total += ws;
+    }
+    const int64_t stage_base = blk_base;         // the block's staging slice: at most one run per point
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid * EPT + k;
+        const uint32_t base = prefix & 0xffffu, rbase = prefix >> 16, nr = v[k] >> 16;
+        uint32_t acc = base;
+#pragma unroll
+        for (int w = 0; w < GW; ++w) { const uint32_t c = s_cnt[w][e]; s_cnt[w][e] = acc; acc += c; }
+        for (uint32_t i = 0; i < nr; ++i) {
+            stage_cell[stage_base + rbase + i] = s_key[e];
+            stage_pos[stage_base + rbase + i] = (uint32_t)blk_base + base + (i << cap_log2);
+        }
+        prefix += v[k];
+    }
+    const uint32_t n_grouped = total & 0xffffu, n_gruns = total >> 16;
+    __syncthreads();
+    uint32_t ovf_base = n_grouped, n_ovf = 0;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) {
+        const uint32_t c = (uint32_t)s_ovf[w];
+        if (w < wv) ovf_base += c;
+        n_ovf += c;
+    }
+    const uint32_t n_valid = n_grouped + n_ovf;
+    // ---- records into the block's slice, group by group (through LDS: the global stores are whole lines) -------------------
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        if (sr[r] == 0xffffffffu) continue;
+        const uint32_t e = sr[r] & 0xffffu, lr = sr[r] >> 16;
+        uint32_t pos;
+        if (e == GROUP_OVF) {
+            pos = ovf_base + lr;
+            stage_cell[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)cells[r];
+            stage_pos[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)blk_base + pos;
+        } else pos = (uint32_t)s_cnt[wv][e] + lr;
+        s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rrgb[r];
+        if (g_cell) g_cell[blk_base + pos] = cells[r];
+    }
+    __syncthreads();
+    {
+        uint32_t *dst = (uint32_t *)(p_rec + blk_base);       // 12 * GB bytes per block: 16-byte aligned
+        const uint32_t nd = 3u * n_valid, nq = nd >> 2;
+        for (uint32_t i = tid; i < nq; i += TPB) ((uint4 *)dst)[i] = ((const uint4 *)s_rec)[i];
+        if (tid < (int)(nd & 3u)) dst[4 * nq + tid] = s_rec[4 * nq + tid];
+        if (g_cell) {
+            const int64_t end = P - blk_base < GB ? P - blk_base : GB;
+            for (int64_t i = n_valid + tid; i < end; i += TPB) g_cell[blk_base + i] = -1;
+        }
+    }
+    if (tid == 0) { blk_runs[blockIdx.x] = (int32_t)(n_gruns + n_ovf); blk_pass[blockIdx.x] = (int32_t)n_valid; }
 }
 
 // scalars of the batch, on the device: run / passing-point totals from the block scans, the new voxels' id range
@@ -267,64 +397,59 @@ __global__ __launch_bounds__(TPB) void k_new_assign(int64_t n, int64_t n_ok, con
 }
 
 // ---- runs -----------------------------------------------------------------------------------------------------------
-// One pass over the cells of a block: every run r (in order j) -> sort key = voxel id | (length - 1) << vb (id field all
-// ones: no voxel — invalid depth / outside the grid / over capacity), value = first point.  Runs end inside their block
-// (forced head at every block start), so the length comes from the block's own head bits.  Exact mode: the passing
-// points are listed in order as well.
-__global__ __launch_bounds__(TPB) void k_runs(int64_t P, int vb, int cap_mask, const int32_t *__restrict__ p_cell,
-                                              const int32_t *__restrict__ occ, const int32_t *__restrict__ blk_run_off,
-                                              const int32_t *__restrict__ blk_pass_off, uint32_t *__restrict__ rkey,
-                                              uint32_t *__restrict__ rval, int32_t *__restrict__ pass_list)
+// The runs k_points staged per block (cell, first position in p_rec; a block's runs tile its slice [base, base + passing
+// points) in staging order, so a run's length is the distance to the next one) -> sort key = voxel id | (length - 1) << vb
+// (id field all ones: no voxel — over capacity), value = first position.  One wavefront per block of points; the ids exist
+// by now (k_new_assign).
+template <int GB>
+__global__ __launch_bounds__(TPB) void k_run_keys(int64_t nblk, int vb, const uint32_t *__restrict__ stage_cell,
+                                                  const uint32_t *__restrict__ stage_pos, const int32_t *__restrict__ occ,
+                                                  const int32_t *__restrict__ blk_runs, const int32_t *__restrict__ blk_run_off,
+                                                  const int32_t *__restrict__ blk_pass, uint32_t *__restrict__ rkey,
+                                                  uint32_t *__restrict__ rval)
 {
-    __shared__ int32_t s_edge[PPT][TPB / 64];
-    __shared__ u64 s_hbits[FB / 64], s_pbits[FB / 64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int32_t cells[PPT];
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        cells[r] = j < P ? p_cell[j] : -2;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const int n = blk_runs[b];
+    const int32_t off = blk_run_off[b];
+    const uint32_t end = (uint32_t)(b * GB) + (uint32_t)blk_pass[b];
+    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
+    const uint32_t *sc = stage_cell + b * GB, *sp = stage_pos + b * GB;
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t pos = sp[i], nxt = i + 1 < n ? sp[i + 1] : end;
+        const int32_t v = occ[sc[i]];
+        rkey[off + i] = v >= 0 ? ((uint32_t)v | ((nxt - pos - 1u) << vb)) : vmask;
+        rval[off + i] = pos;
     }
-    int32_t vid[PPT];
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) vid[r] = occ[cells[r] > 0 ? cells[r] : 0];       // all loads in flight before use
-    bool head[PPT];
-    block_heads(cells, cap_mask, s_edge, head);
-    // word w = r * 4 + wave covers the points [64 w, 64 w + 64) of the block; points beyond P count as heads (run ends)
+}
+
+// exact mode: the passing points of the batch, listed in order j (the token cache fills in that order, memory_2.py:878-886)
+template <int GB>
+__global__ __launch_bounds__(TPB) void k_pass_list(int64_t P, const int32_t *__restrict__ p_cell,
+                                                   const int32_t *__restrict__ blk_pass_off, int32_t *__restrict__ pass_list)
+{
+    constexpr int PPT = GB / TPB;
+    __shared__ u64 s_pbits[GB / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bool pass[PPT];
+    // word w = r * 4 + wave covers the points [64 w, 64 w + 64) of the block
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
-        const u64 hb = __ballot(head[r]), pb = __ballot(cells[r] >= 0);
-        if (lane == 0) { s_hbits[r * (TPB / 64) + wid] = hb; s_pbits[r * (TPB / 64) + wid] = pb; }
+        const int64_t j = (int64_t)blockIdx.x * GB + r * TPB + threadIdx.x;
+        pass[r] = j < P && p_cell[j] >= 0;
+        const u64 pb = __ballot(pass[r]);
+        if (lane == 0) s_pbits[r * (TPB / 64) + wid] = pb;
     }
     __syncthreads();
-    const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
-    const int32_t run_base = blk_run_off[blockIdx.x];
-    const int32_t pass_base = pass_list ? blk_pass_off[blockIdx.x] : 0;
+    const int32_t pass_base = blk_pass_off[blockIdx.x];
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
+        if (!pass[r]) continue;
         const int w = r * (TPB / 64) + wid;
-        const int64_t j = (int64_t)blockIdx.x * FB + r * TPB + threadIdx.x;
-        if (cells[r] == -2) continue;
-        const u64 below = (1ull << lane) - 1ull;
-        if (pass_list && cells[r] >= 0) {
-            int rank = __popcll(s_pbits[w] & below);
-            for (int k = 0; k < w; ++k) rank += __popcll(s_pbits[k]);
-            pass_list[pass_base + rank] = (int32_t)j;
-        }
-        if (!head[r]) continue;
-        int rank = __popcll(s_hbits[w] & below);
-        for (int k = 0; k < w; ++k) rank += __popcll(s_hbits[k]);
-        // next head after this point (the block's end otherwise)
-        int nxt = FB;
-        const u64 above = lane == 63 ? 0ull : (s_hbits[w] & (~0ull << (lane + 1)));
-        if (above) nxt = w * 64 + __ffsll((long long)above) - 1;
-        else
-            for (int k = w + 1; k < FB / 64; ++k)
-                if (s_hbits[k]) { nxt = k * 64 + __ffsll((long long)s_hbits[k]) - 1; break; }
-        const int len = nxt - (w * 64 + lane);
-        const int32_t v = cells[r] >= 0 ? vid[r] : -1;
-        rkey[run_base + rank] = v >= 0 ? ((uint32_t)v | ((uint32_t)(len - 1) << vb)) : vmask;
-        rval[run_base + rank] = (uint32_t)j;
+        int rank = __popcll(s_pbits[w] & ((1ull << lane) - 1ull));
+        for (int k = 0; k < w; ++k) rank += __popcll(s_pbits[k]);
+        pass_list[pass_base + rank] = (int32_t)((int64_t)blockIdx.x * GB + r * TPB + threadIdx.x);
     }
 }
 
@@ -1084,32 +1209,29 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     BSC_HIP(hipMemsetAsync(x->dscal + DS_B_NNEW, 0, sizeof(int64_t), s));
     GeomConst gc = make_geom_const(x);
     // a run's length travels in the key bits beside the voxel id: the id field is sized for the voxel capacity, the
-    // rest (at most 10 bits: runs end with their 1024-point block) holds length - 1
+    // rest (at most 10 bits) holds length - 1; k_points cuts longer groups into several runs
     const int vb = ceil_log2_u64((uint64_t)x->c.voxel_capacity + 2);
     const int lb = 32 - vb < 10 ? 32 - vb : 10;
-    const int cap_mask = (1 << lb) - 1;
-    const int64_t nblk = (P + FB - 1) / FB;
+    const int GBP = x->group_rpw * 256;                 // points per k_points workgroup
+    const int64_t nblk = (P + GBP - 1) / GBP;
     const dim3 fgrid((unsigned)nblk);
     const bool all_px_dense = !exact && idx == nullptr && x->geom_fast;     // the patch comes from the pixel: no p_patf
     uint32_t *patf = all_px_dense ? (uint32_t *)nullptr : x->p_patf;
     float *r2f = exact ? x->p_r2f : (float *)nullptr;
     const float inv_w = 1.0f / (float)x->c.width;
+    int32_t *g_cell = x->log_cap ? x->log_cell + x->log_n : (int32_t *)nullptr;    // bsc_point_log_*: cells in record order
     stat_begin(x, BSC_STAT_INGEST);
     stat_begin(x, BSC_STAT_POINTS);
-    if (gc.fast)
-        hipLaunchKernelGGL(k_points<true>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
-                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->blk_cnt, x->blk_pass);
-    else
-        hipLaunchKernelGGL(k_points<false>, fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,
-                           x->d_transforms, alpha, P, inv_w, cap_mask, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells,
-                           x->dscal, x->blk_cnt, x->blk_pass);
+#define BSC_LAUNCH_POINTS(FASTV, RPWV)                                                                                         \
+    hipLaunchKernelGGL((k_points<FASTV, RPWV>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,       \
+                       x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells, x->dscal,     \
+                       x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
+    if (gc.fast) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8); else BSC_LAUNCH_POINTS(true, 4); }
+    else { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(false, 8); else BSC_LAUNCH_POINTS(false, 4); }
+#undef BSC_LAUNCH_POINTS
     stat_end(x, BSC_STAT_POINTS, 0.0);
-    if (x->log_cap) {           // bsc_point_log_*: the call's cells and records, in order j
-        BSC_HIP(hipMemcpyAsync(x->log_cell + x->log_n, x->p_cell, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
+    if (x->log_cap)             // the call's records, block-grouped like p_rec (every voxel's points still in order j)
         BSC_HIP(hipMemcpyAsync(x->log_rec + x->log_n, p_rec, sizeof(PointRec) * (size_t)P, hipMemcpyDeviceToDevice, s));
-        x->log_n += P;
-    }
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
@@ -1137,6 +1259,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
         return BSC_E_CAPACITY;
     }
+    if (x->log_cap) x->log_n += P;             // the log keeps the call only once it can no longer fail
     // The per-voxel point order (k_runs .. k_seg_order) feeds only the rgb chain, which runs on the side stream anyway: it is
     // enqueued THERE, as soon as the ids exist, and runs beside the pair sort / dense reduce of this call on the main stream.
     // Both halves are chains of short memory-bound kernels with launch gaps between them; side by side each fills the other's
@@ -1158,17 +1281,29 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // their expansion is the per-voxel point order
     const int64_t R = x->hscal[DS_B_NRUN];
     uint32_t *sj = x->sval_b_s[set];
-    hipLaunchKernelGGL(k_runs, fgrid, block, 0, so, P, vb, cap_mask, x->p_cell, x->occ, x->blk_off, x->blk_pass_off, x->skey_a,
-                       x->sval_a, exact ? x->pass_list : (int32_t *)nullptr);
+    {
+        const dim3 rgrid((unsigned)((nblk + TPB / 64 - 1) / (TPB / 64)));
+        if (x->group_rpw == 8) {
+            hipLaunchKernelGGL(k_run_keys<2048>, rgrid, block, 0, so, nblk, vb, x->stage_cell, x->stage_pos, x->occ, x->blk_cnt,
+                               x->blk_off, x->blk_pass, x->skey_a, x->sval_a);
+            if (exact) hipLaunchKernelGGL(k_pass_list<2048>, fgrid, block, 0, so, P, x->p_cell, x->blk_pass_off, x->pass_list);
+        } else {
+            hipLaunchKernelGGL(k_run_keys<1024>, rgrid, block, 0, so, nblk, vb, x->stage_cell, x->stage_pos, x->occ, x->blk_cnt,
+                               x->blk_off, x->blk_pass, x->skey_a, x->sval_a);
+            if (exact) hipLaunchKernelGGL(k_pass_list<1024>, fgrid, block, 0, so, P, x->p_cell, x->blk_pass_off, x->pass_list);
+        }
+    }
     if (side_order) { BSC_HIP(hipEventRecord(x->ev_runs, so)); x->ev_runs_valid = true; }
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
-    BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
-    const int64_t neb = (R + EB - 1) / EB;
-    hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan);
-    BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
-                       x->seg_k0, x->seg_vid, x->bscal_s[set]);
+    if (R > 0) {        // a batch without a single passing point has no runs (k_totals left the segment count at 0)
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+        const int64_t neb = (R + EB - 1) / EB;
+        hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan);
+        BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
+                           x->seg_k0, x->seg_vid, x->bscal_s[set]);
+    }
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
     if (n_bound > seg_cap) n_bound = seg_cap;
