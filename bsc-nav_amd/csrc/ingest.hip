@@ -99,33 +99,63 @@ __device__ __forceinline__ void wave_lds_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+// first-touch claim of a cell by the point j (memory_2.py:888-894): the smallest j wins an empty cell; the claimer that found
+// the cell EMPTY lists it — exactly one entry per new voxel.  Wave-aggregated append.
+__device__ __forceinline__ void claim_cells(bool want, int32_t cell, int64_t j, int32_t *occ, int32_t *__restrict__ new_cells,
+                                            int64_t *dscal, int lane)
+{
+    bool first = false;
+    if (want) {
+        const int32_t mine = INT_MIN + (int32_t)j, cur = occ[cell];
+        if (cur < 0 && cur > mine) first = atomicMin(&occ[cell], mine) == -1;
+    }
+    const u64 fm = __ballot(first);
+    if (fm) {
+        const int leader = __ffsll((long long)fm) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd((unsigned long long *)&dscal[DS_B_NNEW], (unsigned long long)__popcll(fm));
+        base = __shfl(base, leader);
+        if (first) new_cells[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = cell;
+    }
+}
+
 // FAST: geom_point_fast (pinhole intrinsics, patch tables; GeomConst.fast) — otherwise the generic fma chains.
 // RPW: rounds of 64 points per wavefront; GB = GW * RPW * 64 points per workgroup.
-template <bool FAST, int RPW>
+// PLAIN: every pixel of every frame, patch from the pixel, device alpha, no token-cache columns, no point log (the dense
+// build): idx, p_patf, p_r2f, alpha_in and g_cell are null and their code is compiled out.
+template <bool FAST, int RPW, bool PLAIN>
 __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__restrict__ depth,
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
-                                                const int32_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+                                                const int32_t *__restrict__ idx_, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
-                                                const double *__restrict__ alpha_in, int64_t P, float inv_w, int cap_log2,
-                                                int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf,
-                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f,
+                                                const double *__restrict__ alpha_in_, int64_t P, float inv_w, int cap_log2,
+                                                int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf_,
+                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f_,
                                                 int32_t *__restrict__ new_cells, int64_t *dscal,
                                                 int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass,
                                                 uint32_t *__restrict__ stage_cell, uint32_t *__restrict__ stage_pos,
-                                                int32_t *__restrict__ g_cell)
+                                                int32_t *__restrict__ g_cell_)
 {
     constexpr int GB = GW * RPW * 64;
     constexpr int EPT = GROUP_HS / TPB;         // slots per thread in the prefix pass
+    constexpr int WORD_BYTES = GW * (GROUP_HS + 1) * 8, REC_BYTES = 12 * GB;
+    const int32_t *__restrict__ idx = PLAIN ? nullptr : idx_;
+    const double *__restrict__ alpha_in = PLAIN ? nullptr : alpha_in_;
+    uint32_t *__restrict__ p_patf = PLAIN ? nullptr : p_patf_;
+    float *__restrict__ p_r2f = PLAIN ? nullptr : p_r2f_;
+    int32_t *__restrict__ g_cell = PLAIN ? nullptr : g_cell_;
     __shared__ uint32_t s_key[GROUP_HS];
-    __shared__ u64 s_word[GW][GROUP_HS + 1];             // + a spare entry for the lanes without a slot
-    __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];
-    __shared__ uint32_t s_rec[3 * GB];
+    __shared__ uint32_t s_first[GROUP_HS + 1];           // first point (index inside the block) of the slot's cell
+    // the per-wavefront ballot words live until the last round; the record staging starts after it: one buffer
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[WORD_BYTES > REC_BYTES ? WORD_BYTES : REC_BYTES];
+    __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];          // + a spare entry for the lanes without a slot
     __shared__ uint32_t s_wsum[GW];
     __shared__ int32_t s_ovf[GW];
+    u64(*s_word)[GROUP_HS + 1] = (u64(*)[GROUP_HS + 1])s_raw;
+    uint32_t *s_rec = (uint32_t *)s_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u64 lanes_below = (1ull << lane) - 1ull;
-    for (int i = tid; i < GROUP_HS; i += TPB) s_key[i] = 0xffffffffu;
+    for (int i = tid; i < GROUP_HS; i += TPB) { s_key[i] = 0xffffffffu; s_first[i] = 0xffffffffu; }
     for (int i = tid; i < GW * (GROUP_HS + 1); i += TPB) { (&s_word[0][0])[i] = 0ull; (&s_cnt[0][0])[i] = 0u; }
     __syncthreads();
 
@@ -135,12 +165,22 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     const uint32_t jw = (uint32_t)blk_base + (uint32_t)(wv * RPW * 64);
     const int fw = (int)(jw / (uint32_t)N);
     const int32_t iw = (int32_t)(jw - (uint32_t)fw * (uint32_t)N);
+    // pc_transform of the lane's current frame, in vector registers: loaded once per wavefront, again by the lanes that
+    // cross into the next frame
+    double T[12];
+    int fT = fw < n_frames ? fw : n_frames - 1;
+    {
+        const double *Tv = transforms + 16 * (int64_t)fT;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = Tv[k];
+    }
     int32_t cells[RPW];
     uint32_t sr[RPW], ralo[RPW], rahi[RPW], rrgb[RPW];
     int ovf_cnt = 0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
+        const int p_local = wv * RPW * 64 + r * 64 + lane;
+        const int64_t j = blk_base + p_local;
         int32_t cell = -2;
         ralo[r] = rahi[r] = rrgb[r] = 0u;
         if (j < P) {
@@ -164,17 +204,11 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 i = ib;
             }
             const float z = depth[(int64_t)f * N + i];
-            // the frame's pc_transform: through the scalar cache when the wavefront lies inside one frame
-            double T[12];
-            const int f0 = __builtin_amdgcn_readfirstlane(f);
-            if (__all(f == f0)) {
-                const double *Ts = transforms + 16 * (int64_t)f0;
-#pragma unroll
-                for (int k = 0; k < 12; ++k) T[k] = Ts[k];
-            } else {
+            if (f != fT) {
                 const double *Tv = transforms + 16 * (int64_t)f;
 #pragma unroll
                 for (int k = 0; k < 12; ++k) T[k] = Tv[k];
+                fT = f;
             }
             int32_t sx = 0, sy = 0;
             uint32_t patch = 0;
@@ -214,23 +248,6 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 rahi[r] = (uint32_t)__double2hiint(alpha);
                 rrgb[r] = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
             }
-            // first-touch claim: the smallest j wins an empty cell.  Of a stretch of lanes in one cell only the first
-            // (smallest j) competes, and only while the cell is empty or claimed by a later point — so a batch in which
-            // every voxel is new costs about one atomic per cell and wavefront instead of one per point.
-            const int32_t prev_cell = __shfl_up(cell, 1);
-            bool first = false;
-            if (cell >= 0 && (lane == 0 || prev_cell != cell)) {
-                const int32_t mine = INT_MIN + (int32_t)j, cur = occ[cell];
-                if (cur < 0 && cur > mine) first = atomicMin(&occ[cell], mine) == -1;
-            }
-            // the claimer that found the cell empty lists it: exactly one entry per new voxel
-            const u64 fm = __ballot(first);
-            if (fm) {
-                unsigned long long base = 0;
-                if (lane == (int)(__ffsll((long long)fm) - 1)) base = atomicAdd((unsigned long long *)&dscal[DS_B_NNEW], (unsigned long long)__popcll(fm));
-                base = __shfl(base, __ffsll((long long)fm) - 1);
-                if (first) new_cells[base + __popcll(fm & lanes_below)] = cell;
-            }
         }
         cells[r] = cell;
         // ---- slot of the cell, rank of the point among the wavefront's points of that cell --------------------------------
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         if (grouped && rank == 0u) {             // the cell's first lane of the round: count the round, clear the word
             __hip_atomic_store(&s_cnt[wv][slot], before + (uint32_t)__popcll(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_store(&s_word[wv][slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (before == 0u) atomicMin(&s_first[slot], (uint32_t)p_local);     // the wavefront's first point of the cell
         }
         wave_lds_order();
         const u64 om = __ballot(cell >= 0 && !grouped);
@@ -280,6 +298,13 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         const uint32_t nr = (tot + (1u << cap_log2) - 1u) >> cap_log2;     // a run's length has to fit its key bits
         v[k] = tot | (nr << 16);
         tv += v[k];
+    }
+    // first-touch claims, ONE per cell of the block (its first point), instead of one per stretch of same-cell lanes
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid * EPT + k;
+        const bool has = (v[k] & 0xffffu) != 0u;
+        claim_cells(has, has ? (int32_t)s_key[e] : 0, blk_base + (has ? s_first[e] : 0u), occ, new_cells, dscal, lane);
     }
     const uint32_t incl = wave_incl_sum_u32(tv);
     if (lane == 63) s_wsum[wv] = incl;
@@ -318,16 +343,22 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     // ---- records into the block's slice, group by group (through LDS: the global stores are whole lines) -------------------
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        if (sr[r] == 0xffffffffu) continue;
+        const bool valid = sr[r] != 0xffffffffu;
         const uint32_t e = sr[r] & 0xffffu, lr = sr[r] >> 16;
-        uint32_t pos;
-        if (e == GROUP_OVF) {
-            pos = ovf_base + lr;
-            stage_cell[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)cells[r];
-            stage_pos[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)blk_base + pos;
-        } else pos = (uint32_t)s_cnt[wv][e] + lr;
-        s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rrgb[r];
-        if (g_cell) g_cell[blk_base + pos] = cells[r];
+        const bool ovf = valid && e == GROUP_OVF;
+        uint32_t pos = 0;
+        if (valid) pos = ovf ? ovf_base + lr : s_cnt[wv][e] + lr;
+        if (n_ovf) {            // (uniform) points without a slot: runs of one, claimed point by point
+            if (ovf) {
+                stage_cell[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)cells[r];
+                stage_pos[stage_base + n_gruns + (pos - n_grouped)] = (uint32_t)blk_base + pos;
+            }
+            claim_cells(ovf, cells[r], blk_base + wv * RPW * 64 + r * 64 + lane, occ, new_cells, dscal, lane);
+        }
+        if (valid) {
+            s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rrgb[r];
+            if (g_cell) g_cell[blk_base + pos] = cells[r];
+        }
     }
     __syncthreads();
     {
@@ -1222,12 +1253,14 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     int32_t *g_cell = x->log_cap ? x->log_cell + x->log_n : (int32_t *)nullptr;    // bsc_point_log_*: cells in record order
     stat_begin(x, BSC_STAT_INGEST);
     stat_begin(x, BSC_STAT_POINTS);
-#define BSC_LAUNCH_POINTS(FASTV, RPWV)                                                                                         \
-    hipLaunchKernelGGL((k_points<FASTV, RPWV>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames,       \
+#define BSC_LAUNCH_POINTS(FASTV, RPWV, PLAINV)                                                                                 \
+    hipLaunchKernelGGL((k_points<FASTV, RPWV, PLAINV>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, \
                        x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells, x->dscal,     \
                        x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
-    if (gc.fast) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8); else BSC_LAUNCH_POINTS(true, 4); }
-    else { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(false, 8); else BSC_LAUNCH_POINTS(false, 4); }
+    const bool plain = !idx && !patf && !r2f && !alpha && !g_cell;
+    if (gc.fast && plain) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8, true); else BSC_LAUNCH_POINTS(true, 4, true); }
+    else if (gc.fast) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8, false); else BSC_LAUNCH_POINTS(true, 4, false); }
+    else { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(false, 8, false); else BSC_LAUNCH_POINTS(false, 4, false); }
 #undef BSC_LAUNCH_POINTS
     stat_end(x, BSC_STAT_POINTS, 0.0);
     if (x->log_cap)             // the call's records, block-grouped like p_rec (every voxel's points still in order j)
