@@ -231,8 +231,11 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
-    ALLOC(x->stage_cell, np + 2048); ALLOC(x->stage_pos, np + 2048);
-    x->group_rpw = getenv("BSC_GROUP_RPW") && atoi(getenv("BSC_GROUP_RPW")) == 8 ? 8 : 4;
+    ALLOC(x->stage_cell, np + 4096); ALLOC(x->stage_pos, np + 4096);
+    {
+        const int rpw = getenv("BSC_GROUP_RPW") ? atoi(getenv("BSC_GROUP_RPW")) : 8;
+        x->group_rpw = rpw == 16 ? 16 : (rpw == 8 ? 8 : 4);
+    }
     ALLOC(x->new_cells, np); ALLOC(x->run_val_b, np); ALLOC(x->run_scan, np); ALLOC(x->seg_k0, np); ALLOC(x->seg_vid, np);
     x->nblk_cap = np / 1024 + 16;
     ALLOC(x->blk_cnt, x->nblk_cap); ALLOC(x->blk_off, x->nblk_cap);

@@ -560,7 +560,7 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
 
 #define LONG_MIN_LOG2 6                          // segments of >= 64 points
 #define LONG_EARLY 512                           // points of a new voxel that the quad chain steps first
-#define HOT_MIN_LOG2 16                          // segments of >= 65536 points are split over the wavefronts of a workgroup
+#define HOT_MIN_LOG2 15                          // segments of >= 32768 points are split over the wavefronts of a workgroup
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
 #define CHAIN_WAVES 512
 __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
@@ -714,7 +714,6 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
 // is the sequential one by construction.  A voxel that collects 2e5 points in a call takes ~3000 rounds of ~100
 // instructions instead of 2e5 dependent steps of ~28 (6 ms -> 0.5 ms), and the loads of a round are 64 independent
 // gathers instead of 4.
-#define LONG_WG 512
 #define LONG_WAVES 16384
 __device__ __forceinline__ float wave_incl_sum_f32(float x)
 {
@@ -855,14 +854,14 @@ __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_
 // settled); (C) chunk k+1's assumed entry must equal chunk k's exit: the first chunk that fails is run again from the true
 // state, and so on down the line.  A binade crossing or a colour change inside the segment costs the rest of it a second
 // run; otherwise a segment of n points takes n / (64 * wavefronts) rounds.
-__global__ __launch_bounds__(LONG_WG) void k_chain_long(const uint32_t *__restrict__ sj, int64_t *bscal,
+template <int NWV>      // wavefronts per workgroup: the width of the hot-segment split
+__global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restrict__ sj, int64_t *bscal,
                                                         const int4 *__restrict__ seg_info,
                                                         const PointRec *__restrict__ p_rec,
                                                         const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
                                                         float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                                         int gs, int64_t order_base)
 {
-    constexpr int NWV = LONG_WG / 64;
     __shared__ float s_sum[NWV];
     __shared__ ChainState s_entry[NWV], s_exit[NWV];
     const int lane = threadIdx.x & 63;
@@ -1195,10 +1194,17 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     // a wavefront per ~4096 points of the batch, at most long_waves (a frame-by-frame call launches a handful)
     int64_t nw = x->chain_points / 4096;
     nw = nw < 64 ? 64 : (nw > long_waves ? long_waves : nw);
-    if (x->long_chain)
-        hipLaunchKernelGGL(k_chain_long, dim3((unsigned)(nw * 64 / LONG_WG)), dim3(LONG_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
-                           x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
-                           x->c.grid_size, x->chain_order_base);
+    static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 16;
+    if (x->long_chain) {
+        if (long_nwv == 16)
+            hipLaunchKernelGGL(k_chain_long<16>, dim3((unsigned)((nw + 15) / 16)), dim3(1024), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
+                               x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
+                               x->c.grid_size, x->chain_order_base);
+        else
+            hipLaunchKernelGGL(k_chain_long<8>, dim3((unsigned)((nw + 7) / 8)), dim3(512), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
+                               x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
+                               x->c.grid_size, x->chain_order_base);
+    }
     hipLaunchKernelGGL(k_hwin, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],
                        x->rgb_pos, x->hmap, x->p_rec_s[set], x->cv_map, x->c.grid_size, x->chain_order_base);
     stat_end(x, BSC_STAT_CHAIN, 0.0, x->side);
@@ -1258,9 +1264,16 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                        x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells, x->dscal,     \
                        x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
     const bool plain = !idx && !patf && !r2f && !alpha && !g_cell;
-    if (gc.fast && plain) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8, true); else BSC_LAUNCH_POINTS(true, 4, true); }
-    else if (gc.fast) { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(true, 8, false); else BSC_LAUNCH_POINTS(true, 4, false); }
-    else { if (x->group_rpw == 8) BSC_LAUNCH_POINTS(false, 8, false); else BSC_LAUNCH_POINTS(false, 4, false); }
+#define BSC_LAUNCH_POINTS_R(FASTV, PLAINV)                                                                                     \
+    do {                                                                                                                       \
+        if (x->group_rpw == 16) BSC_LAUNCH_POINTS(FASTV, 16, PLAINV);                                                          \
+        else if (x->group_rpw == 8) BSC_LAUNCH_POINTS(FASTV, 8, PLAINV);                                                       \
+        else BSC_LAUNCH_POINTS(FASTV, 4, PLAINV);                                                                              \
+    } while (0)
+    if (gc.fast && plain) BSC_LAUNCH_POINTS_R(true, true);
+    else if (gc.fast) BSC_LAUNCH_POINTS_R(true, false);
+    else BSC_LAUNCH_POINTS_R(false, false);
+#undef BSC_LAUNCH_POINTS_R
 #undef BSC_LAUNCH_POINTS
     stat_end(x, BSC_STAT_POINTS, 0.0);
     if (x->log_cap)             // the call's records, block-grouped like p_rec (every voxel's points still in order j)
@@ -1316,15 +1329,16 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     uint32_t *sj = x->sval_b_s[set];
     {
         const dim3 rgrid((unsigned)((nblk + TPB / 64 - 1) / (TPB / 64)));
-        if (x->group_rpw == 8) {
-            hipLaunchKernelGGL(k_run_keys<2048>, rgrid, block, 0, so, nblk, vb, x->stage_cell, x->stage_pos, x->occ, x->blk_cnt,
-                               x->blk_off, x->blk_pass, x->skey_a, x->sval_a);
-            if (exact) hipLaunchKernelGGL(k_pass_list<2048>, fgrid, block, 0, so, P, x->p_cell, x->blk_pass_off, x->pass_list);
-        } else {
-            hipLaunchKernelGGL(k_run_keys<1024>, rgrid, block, 0, so, nblk, vb, x->stage_cell, x->stage_pos, x->occ, x->blk_cnt,
-                               x->blk_off, x->blk_pass, x->skey_a, x->sval_a);
-            if (exact) hipLaunchKernelGGL(k_pass_list<1024>, fgrid, block, 0, so, P, x->p_cell, x->blk_pass_off, x->pass_list);
-        }
+#define BSC_LAUNCH_RUN_KEYS(GBV)                                                                                               \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL(k_run_keys<GBV>, rgrid, block, 0, so, nblk, vb, x->stage_cell, x->stage_pos, x->occ, x->blk_cnt,    \
+                           x->blk_off, x->blk_pass, x->skey_a, x->sval_a);                                                     \
+        if (exact) hipLaunchKernelGGL(k_pass_list<GBV>, fgrid, block, 0, so, P, x->p_cell, x->blk_pass_off, x->pass_list);     \
+    } while (0)
+        if (x->group_rpw == 16) BSC_LAUNCH_RUN_KEYS(4096);
+        else if (x->group_rpw == 8) BSC_LAUNCH_RUN_KEYS(2048);
+        else BSC_LAUNCH_RUN_KEYS(1024);
+#undef BSC_LAUNCH_RUN_KEYS
     }
     if (side_order) { BSC_HIP(hipEventRecord(x->ev_runs, so)); x->ev_runs_valid = true; }
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
@@ -1372,6 +1386,8 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     stat_end(x, BSC_STAT_INGEST, 0.0);
     BSC_HIP(hipGetLastError());
     x->order_base += P;
+    static const bool chain_eager = getenv("BSC_CHAIN_EAGER") != nullptr;
+    if (chain_eager) BSC_TRY(launch_pending_chain(x));      // A/B: the chain right behind its order stage instead of at the next call
     if (x->c.mode == BSC_MODE_EXACT) {
         // memory_2.py:880-886: rows fill the cache in order; the point that finds it full triggers the
         // flush and loses its own token.
