@@ -8,7 +8,7 @@ OBJ="$HERE/_obj"
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 pids=()
-for f in prims ingest dense flush localize cluster frontier encoder_ops host_rng capi; do
+for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_gemm host_rng capi; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/bsc_internal.h" -nt "$obj" ] || [ "$HERE/geometry_dev.h" -nt "$obj" ] || [ "$HERE/../../include/bscnav.h" -nt "$obj" ]; then
     ( hipcc $FLAGS -c "$src" -o "$obj" ) &
@@ -16,5 +16,5 @@ for f in prims ingest dense flush localize cluster frontier encoder_ops host_rng
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/prims.o "$OBJ"/ingest.o "$OBJ"/dense.o "$OBJ"/flush.o "$OBJ"/localize.o "$OBJ"/cluster.o "$OBJ"/frontier.o "$OBJ"/encoder_ops.o "$OBJ"/host_rng.o "$OBJ"/capi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/prims.o "$OBJ"/ingest.o "$OBJ"/dense.o "$OBJ"/flush.o "$OBJ"/localize.o "$OBJ"/cluster.o "$OBJ"/frontier.o "$OBJ"/encoder_ops.o "$OBJ"/encoder_gemm.o "$OBJ"/host_rng.o "$OBJ"/capi.o
 echo "built $OUT"

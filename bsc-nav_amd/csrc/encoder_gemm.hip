@@ -1,0 +1,399 @@
+// encoder_gemm.hip — the encoder's dense layers at the reference's precision on the 16-bit matrix cores.
+//
+// The reference runs DINOv2 in f32 (memory_2.py:43, 738-739).  gfx950 has no TF32 and its f32 MFMA peaks at 157 TFLOP/s, so an f32
+// GEMM of the vendor library runs ~115 TFLOP/s; the 16-bit MFMA peaks at 2.5 PFLOP/s.  An f32 value is, to 22 significant bits,
+// the sum of two fp16 pieces  h = fp16(x), l = fp16(x - h)  (the difference is exact in f32; both roundings to nearest), so
+//     x w = xh wh + xh wl + xl wh + O(2^-22 |x w|)
+// and the three piece products are exact in the matrix core's f32 accumulator: three v_mfma_f32_32x32x16_f16 per f32 product
+// term at 16x the f32 MFMA rate.  (Three bf16 pieces need six products for the same accuracy; with three products they leave
+// 2^-16 — k_cosine_bf16x3 of localize.hip is the six-product form.  fp16 pieces have a 5-bit exponent: the weights are scaled by
+// a power of two per matrix so that their largest element sits near 2^3, the activation operand by a per-layer power of two, and
+// the scales leave through the epilogue exactly; what remains of the narrow range is that the l piece of an element 2^10 below the
+// operand's typical magnitude goes subnormal, i.e. is kept to an ABSOLUTE 2^-25 — far below the 2^-22 relative error of the
+// typical term.  |x a_scale| must stay below 65504.)
+//
+//   C[m][n] = epilogue( out_scale * sum_k A[m][k] W[n][k] + bias[n] )        A (M,K) f32 row-major, W (N,K) as nn.Linear holds it
+//
+//   workgroup  256 rows of A x 256 rows of W, 8 wavefronts; wavefront w owns the 32 rows [32 w, 32 w + 32) of the tile
+//   A operand  straight from global memory in fragment layout — lane (i = lane & 31, g = lane >> 5) loads the 16 floats
+//              [32 c + 16 g, + 16) of its row (one 128-byte line per row and K chunk over the two lane groups) and splits
+//              them in registers (v_cvt_pk_f16_f32);
+//   W operand  pieces precomputed once per weight matrix (bsc_enc_split_weights: planes h, l of (N,K) fp16), staged per 32-wide
+//              K chunk through LDS (80-byte row pitch: conflict-free 16-byte reads), double-buffered;
+//   MFMA       D[i][j] += A[i][k] W[j][k]: a lane of the accumulator tile holds ONE column n and 16 rows, so a store instruction
+//              writes 128 contiguous bytes of a row of C, and the bias is one register per tile;
+//   epilogue   bias, bias + GELU(tanh), bias + residual (C may alias the residual) — nothing elementwise is left between GEMMs.
+// Workgroup ids map so that the workgroups of an XCD (id mod 8) walk the column tiles of ONE row tile back to back: the 786 KB
+// A tile is fetched into that XCD's L2 once.
+#include "bsc_internal.h"
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GS_KC 32                 // K chunk
+#define GS_PITCH 40              // fp16 elements per staged weight row (80 bytes)
+#define GS_TPB 256
+
+enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
+
+__device__ __forceinline__ uint32_t pack_f16_rne(float lo, float hi)        // v_cvt_pk_f16_f32
+{
+    const f32x2_t v = {lo, hi};
+    const half2_t r = __builtin_convertvector(v, half2_t);
+    return *(const uint32_t *)&r;
+}
+
+// (a, b) -> packed fp16 pieces h, l of both
+__device__ __forceinline__ void split2(float a, float b, uint32_t &h, uint32_t &l)
+{
+    h = pack_f16_rne(a, b);
+    const half2_t hv = *(const half2_t *)&h;
+    const f32x2_t hb = __builtin_convertvector(hv, f32x2_t);
+    l = pack_f16_rne(a - hb[0], b - hb[1]);
+}
+
+// W (N,K) f32 -> planes h, l of (n_pad, K) fp16 pieces of scale * W (rows N..n_pad-1 zero)
+__global__ __launch_bounds__(GS_TPB) void k_split_weights(const float *__restrict__ W, int64_t n_el, int64_t n_pad_el, float scale,
+                                                          uint16_t *__restrict__ out)
+{
+    const int64_t i = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) * 2;
+    if (i >= n_pad_el) return;
+    uint32_t h = 0, l = 0;
+    if (i < n_el) split2(W[i] * scale, W[i + 1] * scale, h, l);
+    *(uint32_t *)(out + i) = h;
+    *(uint32_t *)(out + n_pad_el + i) = l;
+}
+
+__device__ __forceinline__ float gelu_tanh(float x)
+{
+    // torch.nn.functional.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), with
+    // 1 + tanh(u) = 2 - 2 / (1 + e^(2u)) on the hardware's exp2 / rcp (each within an ulp; the sum is taken against 1)
+    const float kBeta = 0.7978845608028654f * 0.044715f, kAlpha = 0.7978845608028654f;
+    const float u = fmaf(kBeta, x * x * x, kAlpha * x);
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);          // e^(2u)
+    return x * (1.0f - __builtin_amdgcn_rcpf(1.0f + e));
+}
+
+// ---- activation pieces --------------------------------------------------------------------------------------------------------
+// Layout P32 of an (M,K) activation matrix as fp16 pieces: row m = K/32 chunks of 64 halfs, chunk c = [h of k = 32c..32c+31 |
+// l of the same] — one 128-byte line per row and K chunk holds both pieces, as the f32 row did.
+__device__ __forceinline__ int64_t p32_off(int64_t m, int K, int k) { return m * 2 * K + (int64_t)(k >> 5) * 64 + (k & 31); }
+
+// LayerNorm of f32 rows straight into pieces (the input of the qkv / fc1 GEMMs): one wavefront per row, two passes over
+// registers (mean, then centred variance — as torch.nn.functional.layer_norm does in f32)
+template <int VPL>      // float4 per lane: width = 256 * VPL
+__global__ __launch_bounds__(GS_TPB) void k_layernorm_split(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int64_t rows, float eps, float a_scale,
+                                                            uint16_t *__restrict__ out)
+{
+    constexpr int Wd = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const float4 *xr = (const float4 *)(x + row * Wd);
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { v[j] = xr[lane + 64 * j]; sum += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / Wd);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / Wd) + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int k = 4 * (lane + 64 * j);
+        const float4 gm = ((const float4 *)gamma)[lane + 64 * j], bt = ((const float4 *)beta)[lane + 64 * j];
+        const float y0 = (v[j].x * rstd * gm.x + bt.x) * a_scale, y1 = (v[j].y * rstd * gm.y + bt.y) * a_scale;
+        const float y2 = (v[j].z * rstd * gm.z + bt.z) * a_scale, y3 = (v[j].w * rstd * gm.w + bt.w) * a_scale;
+        uint32_t h0, l0, h1, l1;
+        split2(y0, y1, h0, l0);
+        split2(y2, y3, h1, l1);
+        uint16_t *o = out + p32_off(row, Wd, k);
+        *(uint2 *)o = make_uint2(h0, h1);
+        *(uint2 *)(o + 32) = make_uint2(l0, l1);
+    }
+}
+
+// f32 rows -> pieces (attention output, patch matrix)
+__global__ __launch_bounds__(GS_TPB) void k_split_rows(const float *__restrict__ x, int64_t M, int K, float a_scale,
+                                                       uint16_t *__restrict__ out)
+{
+    const int64_t e = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) * 4;
+    if (e >= M * K) return;
+    const int64_t m = e / K;
+    const int k = (int)(e - m * K);
+    const float4 v = *(const float4 *)(x + e);
+    uint32_t h0, l0, h1, l1;
+    split2(v.x * a_scale, v.y * a_scale, h0, l0);
+    split2(v.z * a_scale, v.w * a_scale, h1, l1);
+    uint16_t *o = out + p32_off(m, K, k);
+    *(uint2 *)o = make_uint2(h0, h1);
+    *(uint2 *)(o + 32) = make_uint2(l0, l1);
+}
+
+// Workgroup tile (WR * MR * 32) rows x (WC * NT * 32) columns; wavefront (wr, wc) owns MR row fragments x NT column tiles:
+// every weight fragment read from LDS feeds MR * 3 MFMAs, every activation fragment NT * 3.
+// APIECES: A comes as P32 pieces (made by the producing kernel) — otherwise as f32 rows, split in registers.
+// CPIECES: C leaves as P32 pieces scaled by c_scale (the hidden tensor of the MLP: read by the next GEMM only).
+template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
+__global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restrict__ Av, int64_t M, int K,
+                                                             const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
+                                                             const float *__restrict__ bias, const float *R, void *Cv,
+                                                             float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];           // [2][2][WC * NT * 32][GS_PITCH]
+    constexpr int WROWS = WC * NT * 32;
+    constexpr int TROWS = WR * MR * 32;
+    constexpr int BUF = 2 * WROWS * GS_PITCH;
+    constexpr int NTHR = 64 * WR * WC;
+    constexpr int NLD = 2 * WROWS * 4 / NTHR;                                 // 16-byte pieces of a weight chunk per thread
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w / WC, wc = w - wr * WC;
+    const int i = lane & 31, g = lane >> 5;
+    // XCD k (= id mod 8) takes the row tiles k, k + 8, ... and walks all column tiles of one before the next
+    const int64_t wg = blockIdx.x;
+    const int xcd = (int)(wg & 7);
+    const int64_t q = wg >> 3;
+    const int tn = (int)(q % n_tiles_n);
+    const int64_t tm = (q / n_tiles_n) * 8 + xcd;
+    if (tm >= n_tiles_m) return;
+    const int64_t row0 = tm * TROWS + wr * (MR * 32);
+    const int n0 = tn * WROWS;
+    // per-lane row base: f32 rows (16 floats of the chunk per lane) or P32 pieces (8 halfs of either piece per sub-step)
+    const char *arow[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int64_t row = row0 + mr * 32 + i;
+        const int64_t rc = row < M ? row : M - 1;                           // clamped: padded rows are not stored
+        // lane group g contracts k = 16 g + 8 sstep + (0..7) of the chunk in sub-step sstep — the same split of the 32 on both operands
+        arow[mr] = APIECES ? (const char *)((const uint16_t *)Av + rc * 2 * K + g * 16) : (const char *)((const float *)Av + rc * K + g * 16);
+    }
+    const int nchunks = K / GS_KC;
+    f32x16 acc[MR][NT];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mr][t][r] = 0.f;
+    // prefetch registers as first-class vector values (an array that is live across the chunk loop would be left in scratch)
+    typedef uint32_t xf_t __attribute__((ext_vector_type(16 * MR)));
+    typedef uint32_t qr_t __attribute__((ext_vector_type(4 * NLD)));
+    xf_t xf, xg;             // A: the chunk about to be used, and the one after it (two chunks of load latency hidden)
+    qr_t qr;
+    auto load_a = [&](xf_t &xf, int c) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                // f32: floats [4 v4, 4 v4 + 4) of the lane's 16; pieces: v4 = 2 piece + sub-step -> halfs [16 g + 8 sstep, + 8) of the piece
+                const uint4 v = APIECES ? *(const uint4 *)(arow[mr] + (int64_t)c * 128 + (v4 >> 1) * 64 + (v4 & 1) * 16)
+                                        : *(const uint4 *)(arow[mr] + (int64_t)c * 128 + 16 * v4);
+                xf[16 * mr + 4 * v4] = v.x; xf[16 * mr + 4 * v4 + 1] = v.y; xf[16 * mr + 4 * v4 + 2] = v.z; xf[16 * mr + 4 * v4 + 3] = v.w;
+            }
+    };
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = tid + NTHR * j, p = e / (WROWS * 4), rem = e - p * (WROWS * 4), n = rem >> 2, part = rem & 3;
+            const uint4 v = *(const uint4 *)(Wp + (int64_t)p * w_plane + (int64_t)(n0 + n) * K + c * GS_KC + part * 8);
+            qr[4 * j] = v.x; qr[4 * j + 1] = v.y; qr[4 * j + 2] = v.z; qr[4 * j + 3] = v.w;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = tid + NTHR * j, p = e / (WROWS * 4), rem = e - p * (WROWS * 4), n = rem >> 2, part = rem & 3;
+            *(uint4 *)&Ws[buf * BUF + (p * WROWS + n) * GS_PITCH + part * 8] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
+        }
+    };
+    load_a(xf, 0);
+    load_w(0);
+    if (nchunks > 1) load_a(xg, 1);
+    store_w(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        // this chunk's rows as fp16 pieces (two sub-steps of 8 halfs), then the next chunk's loads go in flight
+        uint32_t ah[MR][2][4], al[MR][2][4];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            if (APIECES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ah[mr][0][e] = xf[16 * mr + e]; ah[mr][1][e] = xf[16 * mr + 4 + e];
+                    al[mr][0][e] = xf[16 * mr + 8 + e]; al[mr][1][e] = xf[16 * mr + 12 + e];
+                }
+            } else {
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    split2(__uint_as_float(xf[16 * mr + 4 * v4]) * a_scale, __uint_as_float(xf[16 * mr + 4 * v4 + 1]) * a_scale,
+                           ah[mr][v4 >> 1][2 * (v4 & 1)], al[mr][v4 >> 1][2 * (v4 & 1)]);
+                    split2(__uint_as_float(xf[16 * mr + 4 * v4 + 2]) * a_scale, __uint_as_float(xf[16 * mr + 4 * v4 + 3]) * a_scale,
+                           ah[mr][v4 >> 1][2 * (v4 & 1) + 1], al[mr][v4 >> 1][2 * (v4 & 1) + 1]);
+                }
+            }
+        }
+        xf = xg;
+        if (c + 2 < nchunks) load_a(xg, c + 2);
+        if (c + 1 < nchunks) load_w(c + 1);
+        const uint16_t *wb = &Ws[buf * BUF + (wc * NT * 32 + i) * GS_PITCH + g * 16];
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+            // one piece of the weights at a time; smallest terms first; consecutive MFMAs go to different accumulators
+            half8_t wf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *(const half8_t *)(wb + (1 * WROWS + t * 32) * GS_PITCH + sstep * 8);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)ah[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // h l
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *(const half8_t *)(wb + (0 * WROWS + t * 32) * GS_PITCH + sstep * 8);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)al[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // l h
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)ah[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // h h
+        }
+        if (c + 1 < nchunks) store_w(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulator tile (mr, t): lane (i, g) holds column n0 + 32 (wc NT + t) + i and the rows (r & 3) + 8 (r >> 2) + 4 g of fragment mr
+    const bool full = row0 + MR * 32 <= M && n0 + WROWS <= N;               // (uniform) no bounds checks inside the tile
+    float *C = (float *)Cv;
+    uint16_t *Cp = (uint16_t *)Cv;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + (wc * NT + t) * 32 + i;
+        const float b = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = row0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (!full && (m >= M || n >= N)) continue;
+                float v = fmaf(acc[mr][t][r], out_scale, b);
+                if (EPI == GS_EPI_GELU) v = gelu_tanh(v);
+                if (EPI == GS_EPI_RESID) v += R[m * N + n];
+                if (CPIECES) {
+                    v *= c_scale;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    uint16_t *o = Cp + p32_off(m, N, n);
+                    o[0] = *(const uint16_t *)&h;
+                    o[32] = *(const uint16_t *)&l;
+                } else C[m * N + n] = v;
+            }
+    }
+}
+
+extern "C" bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32_t K, float scale, void *pieces_dev, void *hip_stream)
+{
+    if (!w_dev || !pieces_dev || N <= 0 || K <= 0 || (K & 1)) { bsc_set_error("bsc_enc_split_weights: invalid argument"); return BSC_E_INVALID; }
+    const int64_t n_pad = ((int64_t)N + 255) / 256 * 256;
+    const int64_t n_el = (int64_t)N * K, n_pad_el = n_pad * K;
+    hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((n_pad_el / 2 + GS_TPB - 1) / GS_TPB)), dim3(GS_TPB), 0, (hipStream_t)hip_stream,
+                       w_dev, n_el, n_pad_el, scale, (uint16_t *)pieces_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
+                                         const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
+                                         int32_t epilogue, int32_t a_pieces, float c_pieces_scale, void *hip_stream)
+{
+    if (!a_dev || !pieces_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || (K % GS_KC) || epilogue < 0 || epilogue > 2 ||
+        (epilogue == GS_EPI_RESID && !resid_dev) || (c_pieces_scale != 0.f && (N % 32))) {
+        bsc_set_error("bsc_enc_gemm_split: invalid argument (K must be a multiple of 32; piece output needs N %% 32 == 0)");
+        return BSC_E_INVALID;
+    }
+    static const bool wide = !(getenv("BSC_GEMM_TILE") && atoi(getenv("BSC_GEMM_TILE")) == 2);   // 32 x 256 per wavefront (A/B: 2 = 64 x 128)
+    constexpr int TROWS = 256, TCOLS = 256;                        // workgroup tile of every variant
+    const int64_t n_pad = ((int64_t)N + 255) / 256 * 256;
+    const int n_tiles_n = (int)(n_pad / TCOLS);
+    const int64_t n_tiles_m = (M + TROWS - 1) / TROWS;
+    const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
+    const int64_t n_wg = groups * n_tiles_n * 8;
+    const size_t lds = 2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
+#define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
+    do {                                                                                                                             \
+        static bool attr_set = false;                                                                                                \
+        if (!attr_set) {                                                                                                             \
+            BSC_HIP(hipFuncSetAttribute((const void *)k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                      \
+            attr_set = true;                                                                                                         \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(512), lds, s, a_dev, M, K, \
+                           (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
+                           c_pieces_scale, n_tiles_n, (int)n_tiles_m);                                                               \
+    } while (0)
+#define BSC_GEMM_LAUNCH(EPIV, APV, CPV)                                                                                              \
+    do {                                                                                                                             \
+        if (wide) BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, APV, CPV);                                                                      \
+        else BSC_GEMM_LAUNCH2(2, 4, 4, 2, EPIV, APV, CPV);                                                                           \
+    } while (0)
+    if (epilogue == GS_EPI_GELU) {
+        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, true, true);
+        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU, true, false);
+        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, false, true);
+        else BSC_GEMM_LAUNCH(GS_EPI_GELU, false, false);
+    } else if (epilogue == GS_EPI_RESID) {
+        if (cp) { bsc_set_error("bsc_enc_gemm_split: the residual epilogue writes f32"); return BSC_E_INVALID; }
+        if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, true, false);
+        else BSC_GEMM_LAUNCH(GS_EPI_RESID, false, false);
+    } else {
+        if (cp) { bsc_set_error("bsc_enc_gemm_split: piece output is for the GELU epilogue"); return BSC_E_INVALID; }
+        if (ap) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, false);
+        else BSC_GEMM_LAUNCH(GS_EPI_BIAS, false, false);
+    }
+#undef BSC_GEMM_LAUNCH
+#undef BSC_GEMM_LAUNCH2
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_layernorm_split(const float *x_dev, const float *gamma_dev, const float *beta_dev, int64_t rows,
+                                              int32_t width, float eps, float a_scale, void *pieces_dev, void *hip_stream)
+{
+    if (!x_dev || !gamma_dev || !beta_dev || !pieces_dev || rows <= 0 || (width != 256 && width != 512 && width != 768 && width != 1024)) {
+        bsc_set_error("bsc_enc_layernorm_split: width must be 256, 512, 768 or 1024");
+        return BSC_E_INVALID;
+    }
+    const dim3 grid((unsigned)((rows * 64 + GS_TPB - 1) / GS_TPB)), block(GS_TPB);
+    hipStream_t s = (hipStream_t)hip_stream;
+    uint16_t *out = (uint16_t *)pieces_dev;
+    switch (width / 256) {
+    case 1: hipLaunchKernelGGL(k_layernorm_split<1>, grid, block, 0, s, x_dev, gamma_dev, beta_dev, rows, eps, a_scale, out); break;
+    case 2: hipLaunchKernelGGL(k_layernorm_split<2>, grid, block, 0, s, x_dev, gamma_dev, beta_dev, rows, eps, a_scale, out); break;
+    case 3: hipLaunchKernelGGL(k_layernorm_split<3>, grid, block, 0, s, x_dev, gamma_dev, beta_dev, rows, eps, a_scale, out); break;
+    default: hipLaunchKernelGGL(k_layernorm_split<4>, grid, block, 0, s, x_dev, gamma_dev, beta_dev, rows, eps, a_scale, out); break;
+    }
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t K, float a_scale, void *pieces_dev, void *hip_stream)
+{
+    if (!x_dev || !pieces_dev || M <= 0 || K <= 0 || (K % 32)) { bsc_set_error("bsc_enc_split_rows: K must be a multiple of 32"); return BSC_E_INVALID; }
+    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((M * K / 4 + GS_TPB - 1) / GS_TPB)), dim3(GS_TPB), 0, (hipStream_t)hip_stream, x_dev, M,
+                       K, a_scale, (uint16_t *)pieces_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}

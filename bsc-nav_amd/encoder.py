@@ -6,8 +6,9 @@ interface: rgb u8 (H,W,3) -> /255 -> resize (query_h, query_w) -> ImageNet norma
 final-LayerNorm'd patch tokens, reshaped (g, g, D) and indexed [py, px].
 
 `RandomViT` is a plain ViT (B/16: 12x768x12, L/14: 24x1024x16 with 4 register tokens) with
-trunc_normal(0.02) weights.  Its dense GEMMs run on MFMA through PyTorch-ROCm (hipBLASLt) in bf16;
-outputs are returned in fp32 for the voxel kernels.
+trunc_normal(0.02) weights.  In bf16 its dense GEMMs run on MFMA through PyTorch-ROCm (hipBLASLt); in f32 (the
+reference's precision) they run in-tree on the fp16 matrix cores with split operands (`SplitLinear`,
+csrc/encoder_gemm.hip: bias / GELU / residual in the epilogue).  Outputs are returned in fp32 for the voxel kernels.
 """
 import ctypes as C
 import os
@@ -30,6 +31,70 @@ VIT_SHAPES = {
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class SplitLinear:
+    """nn.Linear at f32 accuracy on the fp16 matrix cores (bsc_enc_gemm_split): the weight's two fp16 pieces are made once
+    (scaled by the power of two that puts its largest element in (4, 8]), the activation rows are split in registers.
+    epilogue: 0 bias, 1 bias + GELU(tanh), 2 bias + residual (in place when out is resid)."""
+
+    BIAS, GELU, RESID = 0, 1, 2
+
+    def __init__(self, lin):
+        from . import _lib
+        w = lin.weight.detach()
+        assert w.is_cuda and w.dtype == torch.float32 and w.shape[1] % 32 == 0
+        self.N, self.K = w.shape
+        amax = float(w.abs().max())
+        self.scale = 2.0 ** (3 - int(torch.ceil(torch.log2(torch.tensor(max(amax, 1e-30))))))
+        n_pad = (self.N + 255) // 256 * 256
+        self.pieces = torch.empty((2, n_pad, self.K), dtype=torch.float16, device=w.device)
+        self.bias = None if lin.bias is None else lin.bias.detach().contiguous()
+        lib = _lib.load()
+        _lib.check(lib.bsc_enc_split_weights(C.c_void_p(w.contiguous().data_ptr()), self.N, self.K, self.scale,
+                                             C.c_void_p(self.pieces.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
+
+    def __call__(self, x2d, epilogue=0, resid=None, out=None, a_scale=1.0, a_pieces=False, c_pieces_scale=0.0):
+        """x2d: (M,K) f32 rows, or (a_pieces) their (M,2K) fp16 pieces as `split_rows` / `layernorm_split` / a GELU epilogue
+        with c_pieces_scale made them, already scaled by a_scale.  -> (M,N) f32, or (c_pieces_scale) (M,2N) fp16 pieces."""
+        from . import _lib
+        M = x2d.shape[0]
+        if a_pieces:
+            assert x2d.dtype == torch.float16 and x2d.is_contiguous() and x2d.shape[1] == 2 * self.K
+        else:
+            assert x2d.dtype == torch.float32 and x2d.is_contiguous() and x2d.shape[1] == self.K
+        if out is None:
+            out = (torch.empty((M, 2 * self.N), dtype=torch.float16, device=x2d.device) if c_pieces_scale else
+                   torch.empty((M, self.N), dtype=torch.float32, device=x2d.device))
+        _lib.check(_lib.load().bsc_enc_gemm_split(
+            C.c_void_p(x2d.data_ptr()), M, self.K, C.c_void_p(self.pieces.data_ptr()), self.N,
+            None if self.bias is None else C.c_void_p(self.bias.data_ptr()),
+            None if resid is None else C.c_void_p(resid.data_ptr()), C.c_void_p(out.data_ptr()), float(a_scale),
+            1.0 / (float(a_scale) * self.scale), int(epilogue), 1 if a_pieces else 0, float(c_pieces_scale),
+            C.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream)))
+        return out
+
+
+def layernorm_split(x2d, ln, a_scale=1.0):
+    """LayerNorm of f32 rows written as the fp16 pieces the split GEMM reads (bsc_enc_layernorm_split)."""
+    from . import _lib
+    M, Wd = x2d.shape
+    out = torch.empty((M, 2 * Wd), dtype=torch.float16, device=x2d.device)
+    _lib.check(_lib.load().bsc_enc_layernorm_split(
+        C.c_void_p(x2d.data_ptr()), C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()), M, Wd, float(ln.eps),
+        float(a_scale), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream)))
+    return out
+
+
+def split_rows(x2d, a_scale=1.0):
+    """f32 rows -> fp16 pieces (bsc_enc_split_rows)."""
+    from . import _lib
+    M, K = x2d.shape
+    out = torch.empty((M, 2 * K), dtype=torch.float16, device=x2d.device)
+    _lib.check(_lib.load().bsc_enc_split_rows(C.c_void_p(x2d.data_ptr()), M, K, float(a_scale), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream)))
+    return out
 
 
 class _Block(nn.Module):
@@ -90,6 +155,8 @@ class RandomViT(nn.Module):
         self.fused = fused
         self.fused_attention = fused and os.environ.get("BSC_ENC_ATTENTION", "1") == "1"   # 0: library SDPA
         self.lagged = os.environ.get("BSC_ENC_LAGGED", "1") == "1"     # 0: residual adds in the LayerNorm kernel
+        # f32 weights: dense layers through the in-tree split-operand MFMA GEMM (0: PyTorch-ROCm f32 GEMMs)
+        self.split_gemm = dtype == torch.float32 and os.environ.get("BSC_ENC_SPLIT_GEMM", "1") == "1"
         s = VIT_SHAPES[arch]
         self.arch, self.image_size, self.patch = arch, image_size, s["patch"]
         self.grid = image_size // s["patch"]
@@ -208,6 +275,8 @@ class RandomViT(nn.Module):
     def _forward_patches(self, t, keep_dtype=False):
         """(B, g*g, 3*p*p) unfolded, normalised patches -> {'x_norm_patchtokens': (B, g*g, D)} (f32 unless keep_dtype)."""
         B = t.shape[0]
+        if self.split_gemm and t.is_cuda and t.dtype == torch.float32 and self.head is None:
+            return {"x_norm_patchtokens": self._forward_f32_split(t)}
         t = self.patch_embed(t)
         fuse = self.fused and t.is_cuda and t.dtype == torch.bfloat16 and self.width % 256 == 0
         T = 1 + self.registers + self.grid * self.grid
@@ -255,6 +324,50 @@ class RandomViT(nn.Module):
         if self.head is not None:
             t = self.head(t)
         return {"x_norm_patchtokens": t if keep_dtype else t.float()}
+
+    def _split(self, lin):
+        """the fp16 pieces of a Linear's weight, made on first use (f32 weights on the device)"""
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = id(lin)
+        if key not in cache or cache[key][0] != lin.weight.data_ptr():
+            cache[key] = (lin.weight.data_ptr(), SplitLinear(lin))
+        return cache[key][1]
+
+    def _forward_f32_split(self, t):
+        """The f32 forward (the reference's precision) with every dense layer on the fp16 matrix cores at f32 accuracy:
+        bias, GELU and the residual adds ride in the GEMM epilogues; LayerNorm and attention stay f32 PyTorch ops."""
+        B, n_patch, kin = t.shape
+        Wd, heads = self.width, self.blocks[0].heads
+        hd = Wd // heads
+        SL = SplitLinear
+        if kin % 32 == 0:
+            x = self._split(self.patch_embed)(t.reshape(B * n_patch, kin).contiguous()).view(B, n_patch, Wd)
+        else:
+            x = self.patch_embed(t)
+        x = torch.cat([self.cls.expand(B, -1, -1), x], dim=1) + self.pos
+        if self.reg is not None:
+            x = torch.cat([x[:, :1], self.reg.expand(B, -1, -1), x[:, 1:]], dim=1)
+        T = x.shape[1]
+        u = x.contiguous().view(B * T, Wd)
+        ln_ok = Wd in (256, 512, 768, 1024)
+
+        def ln_in(ln):          # LayerNorm output as the next GEMM's operand: pieces straight from the LayerNorm kernel
+            if ln_ok:
+                return layernorm_split(u, ln), True
+            return F.layer_norm(u, (Wd,), ln.weight, ln.bias, ln.eps), False
+
+        for blk in self.blocks:
+            y, yp = ln_in(blk.ln1)
+            qkv = self._split(blk.qkv)(y, a_pieces=yp).view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+            a = a.transpose(1, 2).reshape(B * T, Wd)
+            self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0)
+            y, yp = ln_in(blk.ln2)
+            # the hidden tensor exists only as pieces (scaled by 4): written by fc1's GELU epilogue, read by fc2
+            h = self._split(blk.fc1)(y, SL.GELU, a_pieces=yp, c_pieces_scale=4.0)
+            self._split(blk.fc2)(h, SL.RESID, resid=u, out=u, a_scale=4.0, a_pieces=True)
+        y = F.layer_norm(u, (Wd,), self.norm.weight, self.norm.bias, self.norm.eps)
+        return y.view(B, T, Wd)[:, 1 + self.registers:].contiguous()
 
     def _bias_sums(self, device):
         """f32 running sums of the biases of the residual updates (proj, fc2 of every block): row k = what the stream lacks

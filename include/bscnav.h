@@ -263,6 +263,27 @@ bsc_status bsc_enc_attention(const void *qkv_dev, int32_t B, int32_t T, int32_t 
 bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim, void *out_dev,
                                  int32_t *work2_dev, void *hip_stream);
 
+/* The encoder's dense layers at the REFERENCE'S precision (memory_2.py:43,738-739: DINOv2 runs f32) on the fp16 matrix cores:
+ * every f32 operand as two fp16 pieces h = fp16(x), l = fp16(x - h) (22 significant bits), products hh + hl + lh accumulated
+ * in f32 (encoder_gemm.hip).  Replaces the f32 nn.Linear calls of the reference's ViT forward.
+ *   bsc_enc_split_weights  W (N,K) f32 as nn.Linear holds it -> pieces_dev: 2 planes of (ceil(N/256)*256, K) fp16 of scale * W
+ *                          (scale: a power of two that puts the largest |w| near 8; once per weight matrix)
+ *   bsc_enc_gemm_split     C (M,N) = epilogue(out_scale * (a_scale A) (scale W)^T + bias): epilogue 0 bias, 1 bias + GELU(tanh),
+ *                          2 bias + residual (c_dev may alias resid_dev); out_scale = 1 / (a_scale * scale); K % 32 == 0;
+ *                          |a_scale * A| < 65504 (fp16 range).  a_pieces != 0: a_dev holds the activation pieces already (layout
+ *                          below; a_scale was applied by their producer) — otherwise f32 rows, split in registers.
+ *                          c_pieces_scale != 0 (GELU epilogue): c_dev receives pieces of c_pieces_scale * C instead of f32.
+ *   piece layout of an (M,K) activation matrix: fp16, row m = K/32 chunks of 64, chunk c = [h of k in 32c..32c+31 | l of the same]
+ *   bsc_enc_layernorm_split  LayerNorm of f32 rows (width 256..1024) written as pieces of a_scale * y
+ *   bsc_enc_split_rows       f32 rows -> pieces of a_scale * x */
+bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32_t K, float scale, void *pieces_dev, void *hip_stream);
+bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N, const float *bias_dev,
+                              const float *resid_dev, void *c_dev, float a_scale, float out_scale, int32_t epilogue,
+                              int32_t a_pieces, float c_pieces_scale, void *hip_stream);
+bsc_status bsc_enc_layernorm_split(const float *x_dev, const float *gamma_dev, const float *beta_dev, int64_t rows, int32_t width,
+                                   float eps, float a_scale, void *pieces_dev, void *hip_stream);
+bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t K, float a_scale, void *pieces_dev, void *hip_stream);
+
 /* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
  * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM
  * (memory_2.py:733-736 and transform_, :71-74, fused into one pass). */
