@@ -1,0 +1,93 @@
+"""The reference-precision encoder (memory_2.py:43,738-739: DINOv2 runs f32): the in-tree split-operand MFMA GEMM
+(bsc_enc_gemm_split, csrc/encoder_gemm.hip) against a plain PyTorch fp32 evaluation of the same op and against fp64."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pieces_back(p, M, K, scale=1.0):
+    """(M, 2K) fp16 pieces in the chunk-interleaved layout -> (M, K) float64 of h + l"""
+    v = p.view(M, K // 32, 2, 32)
+    return (v[:, :, 0].double() + v[:, :, 1].double()).reshape(M, K) / scale
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 768, 2304), (777, 3072, 768), (257, 64, 96), (31, 32, 8)])
+@pytest.mark.parametrize("epilogue", [0, 1, 2])
+def test_split_gemm_matches_fp32_linear(M, K, N, epilogue):
+    """out = epilogue(A W^T + b): within a few f32 ulps of the fp64 result — at least as close as torch's own f32 GEMM — for f32
+    rows and for pre-split pieces, ragged M / N (tile edges), every epilogue."""
+    import torch
+    import torch.nn.functional as F
+    from bsc_nav_amd import encoder
+    torch.manual_seed(M + K + N + epilogue)
+    lin = torch.nn.Linear(K, N).cuda().float()
+    torch.nn.init.trunc_normal_(lin.weight, std=0.02)
+    A = torch.randn(M, K, device="cuda")
+    R = torch.randn(M, N, device="cuda")
+    sl = encoder.SplitLinear(lin)
+    ref64 = A.double() @ lin.weight.double().t() + lin.bias.double()
+    ref32 = A @ lin.weight.t() + lin.bias                      # the plain PyTorch fp32 reference of the op
+    if epilogue == 1:
+        ref64, ref32 = F.gelu(ref64, approximate="tanh"), F.gelu(ref32, approximate="tanh")
+    if epilogue == 2:
+        ref64, ref32 = ref64 + R.double(), ref32 + R
+    res = R.clone() if epilogue == 2 else None
+    out = sl(A, epilogue, resid=res)
+    outp = sl(encoder.split_rows(A, 4.0), epilogue, resid=res, a_scale=4.0, a_pieces=True)
+    e32 = (ref32.double() - ref64).abs().max().item()
+    tol = max(2.0 * e32, 2e-6)
+    assert (out.double() - ref64).abs().max().item() <= tol
+    assert (outp.double() - ref64).abs().max().item() <= tol
+    # and within 1e-5 of the fp32 op itself (more where the fp32 op is itself further than that from fp64: K = 3072)
+    assert (out - ref32).abs().max().item() <= max(1e-5, 2.0 * e32)
+    if epilogue == 2:       # in place: C aliases the residual
+        r2 = R.clone()
+        sl(A, 2, resid=r2, out=r2)
+        assert torch.equal(r2, out)
+    if epilogue == 1 and N % 32 == 0:      # the hidden tensor as pieces (what fc2 reads)
+        cp = sl(A, 1, c_pieces_scale=4.0)
+        assert cp.dtype == torch.float16 and cp.shape == (M, 2 * N)
+        assert (_pieces_back(cp, M, N, 4.0) - ref64).abs().max().item() <= tol + 1e-6
+
+
+def test_layernorm_split_and_split_rows():
+    import torch
+    import torch.nn.functional as F
+    from bsc_nav_amd import encoder
+    torch.manual_seed(5)
+    for Wd in (256, 768, 1024):
+        ln = torch.nn.LayerNorm(Wd, eps=1e-6).cuda()
+        ln.weight.data.uniform_(0.5, 1.5)
+        ln.bias.data.uniform_(-0.5, 0.5)
+        x = torch.randn(1001, Wd, device="cuda") * 3 + 0.5
+        ref = F.layer_norm(x.double(), (Wd,), ln.weight.double(), ln.bias.double(), 1e-6)
+        got = _pieces_back(encoder.layernorm_split(x, ln, 2.0), 1001, Wd, 2.0)
+        assert (got - ref).abs().max().item() < 4e-6
+        back = _pieces_back(encoder.split_rows(x, 0.5), 1001, Wd, 0.5)
+        assert (back - x.double()).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
+
+
+@pytest.mark.parametrize("arch", ["vit_b16", "vit_tiny_test"])
+def test_f32_encoder_on_split_gemms_matches_pytorch_f32(arch):
+    """Tokens of the f32 ViT with every dense layer on the fp16 matrix cores against the same module on PyTorch's f32 GEMMs
+    (within 2e-5 of it at a token rms of 1) and against an fp64 evaluation (no further from it than PyTorch f32 is, x1.5)."""
+    import torch
+    from bsc_nav_amd import encoder
+    vit = encoder.RandomViT(arch, image_size=224, seed=1, dtype=torch.float32).cuda()
+    for ln in [m for m in vit.modules() if isinstance(m, torch.nn.LayerNorm)]:
+        ln.weight.data = 1 + 0.1 * torch.randn_like(ln.weight)
+        ln.bias.data = 0.1 * torch.randn_like(ln.bias)
+    rgb = torch.randint(0, 255, (5, 96, 128, 4), dtype=torch.uint8, device="cuda")
+    assert vit.split_gemm
+    a = vit.patch_tokens(rgb)
+    vit.split_gemm = False
+    b = vit.patch_tokens(rgb)
+    v64 = encoder.RandomViT(arch, image_size=224, seed=1, dtype=torch.float64).cuda()
+    v64.load_state_dict({k: v.double() for k, v in vit.state_dict().items()})
+    v64.fused = False
+    c = v64.forward_features(v64.preprocess(rgb).double())["x_norm_patchtokens"].reshape(a.shape)
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    assert (a - b).abs().max().item() < 2e-5
+    e_split, e_torch = (a.double() - c).abs().max().item(), (b.double() - c).abs().max().item()
+    assert e_split <= max(1.5 * e_torch, 5e-6), (e_split, e_torch)
