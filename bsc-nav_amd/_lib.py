@@ -78,6 +78,7 @@ SIGNATURES = {
     "bsc_enc_gemm_split": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_layernorm_split": (_I32, [_VP, _VP, _VP, _I64, _I32, C.c_float, C.c_float, _VP, _VP]),
     "bsc_enc_split_rows": (_I32, [_VP, _I64, _I32, C.c_float, _VP, _VP]),
+    "bsc_enc_attention_split": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, C.c_float, _VP, _VP]),
     "bsc_enc_add_layernorm": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _I32, C.c_float, _VP]),
 }
 

@@ -302,6 +302,272 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     }
 }
 
+// ---- attention at f32 accuracy on fp16 pieces ------------------------------------------------------------------------------------
+// softmax(Q K^T / 8) V per (image, head) with every matrix product as three piece products (v_mfma_f32_16x16x32_f16), f32
+// softmax.  Layout of the work as in k_attention (encoder_ops.hip): persistent workgroups walk the (image, head) items with the
+// next item's K / V loads in flight; K and V^T of the head live in LDS — as h and l planes —; a wavefront takes strips of 16
+// queries whose fragments come straight from global memory.  qkv: P32 pieces of the (B T, 3 H 64) matrix the qkv GEMM wrote;
+// out: P32 pieces of out_scale * attention output (B T, H 64), what the projection GEMM reads.  P is scaled by 2^8 before it is
+// split (probabilities of 1/T would push their l piece into fp16's subnormals), the factor leaves with the row sum.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int N> struct gs_u32vec { typedef uint32_t type __attribute__((ext_vector_type(N))); };
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int NLD, int NTHR>
+__device__ __forceinline__ void atts_issue_loads(typename gs_u32vec<4 * NLD>::type &k8, typename gs_u32vec<4 * NLD>::type &v8,
+                                                 const uint16_t *__restrict__ qkv, int item, int T, int H, int tid)
+{
+    const int64_t tok_stride = (int64_t)2 * 3 * H * 64;             // halfs per token row of the piece matrix
+    const int b = item / H, h = item % H;
+    const uint16_t *Kp = qkv + (int64_t)b * T * tok_stride + (int64_t)2 * (H * 64 + h * 64);
+    const uint16_t *Vp = qkv + (int64_t)b * T * tok_stride + (int64_t)2 * (2 * H * 64 + h * 64);
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int idx = tid + NTHR * r;
+        const int t = idx >> 4, pc = idx & 15;                      // 16 sixteen-byte pieces per token: [h 0-31 | l 0-31 | h 32-63 | l 32-63]
+        const int tc = t < T ? t : T - 1;
+        const uint4 k = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + pc * 8);
+        const uint4 v = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + pc * 8);
+        k8[4 * r] = k.x; k8[4 * r + 1] = k.y; k8[4 * r + 2] = k.z; k8[4 * r + 3] = k.w;
+        v8[4 * r] = v.x; v8[4 * r + 1] = v.y; v8[4 * r + 2] = v.z; v8[4 * r + 3] = v.w;
+    }
+}
+
+// PF: the next item's K / V pieces are loaded into registers before the strips of the current one (needs the register budget of
+// one wavefront per SIMD); otherwise an item's loads are waited for on the spot
+template <int NT, int NW, bool PF>
+__global__ __launch_bounds__(64 * NW) void k_attention_split(const uint16_t *__restrict__ qkv, int T, int H, int items,
+                                                             uint16_t *__restrict__ out, float out_scale, int *work)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t att_lds[];
+    __shared__ int s_ticket;
+    constexpr int NTHR = 64 * NW;
+    constexpr int TP = NT * 16;
+    constexpr int KP = 64 + 8;                              // K row pitch (halfs)
+    constexpr int VP = 4 * (((TP / 4 - 1) | 7) + 1) + 8;    // V^T row pitch: granules of 4 keys (xor-swizzled) + pad
+    constexpr int NLD = (TP * 16 + NTHR - 1) / NTHR;        // 16-byte pieces of K (and of V) per thread
+    constexpr int NSTRIP = (NT + NW - 1) / NW;              // strips of 16 queries per wavefront
+    uint16_t *sK = att_lds;                                 // [2 pieces][TP * KP]
+    uint16_t *sVt = att_lds + 2 * TP * KP;                  // [2 pieces][64 * VP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t tok_stride = (int64_t)2 * 3 * H * 64;
+    const float c = 0.125f * 1.44269504088896340736f;               // 1/sqrt(64) * log2(e)
+    const int nstrip = (T + 15) >> 4;
+    typename gs_u32vec<4 * NLD>::type k8, v8;
+
+    int item = blockIdx.x;
+    if (work) {
+        if (tid == 0) s_ticket = atomicAdd(&work[0], 1);
+        __syncthreads();
+        item = s_ticket;
+    }
+    if (PF) atts_issue_loads<NLD, NTHR>(k8, v8, qkv, item < items ? item : items - 1, T, H, tid);
+    int nxt = item;
+    for (; item < items; item = nxt) {
+        const int b = item / H, h = item % H;
+        const uint16_t *Qp = qkv + (int64_t)b * T * tok_stride + (int64_t)2 * h * 64;
+        if (!PF) atts_issue_loads<NLD, NTHR>(k8, v8, qkv, item, T, H, tid);
+        __syncthreads();                                            // the previous item's strips are done with LDS
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int idx = tid + NTHR * r;
+            const int t = idx >> 4, pc = idx & 15;
+            if (idx < TP * 16) {
+                const bool in = t < T;
+                const int piece = (pc >> 2) & 1, ch = (pc >> 3) * 4 + (pc & 3);     // ch: which 8 of the 64 head dims
+                const uint32_t keep = in ? 0xffffffffu : 0u;        // padded keys: zero rows (a vector select would go through scratch)
+                *(uint4 *)&sK[piece * TP * KP + t * KP + ch * 8] =
+                    make_uint4(k8[4 * r] & keep, k8[4 * r + 1] & keep, k8[4 * r + 2] & keep, k8[4 * r + 3] & keep);
+                const uint32_t vv[4] = {v8[4 * r] & keep, v8[4 * r + 1] & keep, v8[4 * r + 2] & keep, v8[4 * r + 3] & keep};
+                // V^T[d][t] lives at granule (t >> 2) ^ (d >> 3) of row d (bank spread for the 16-bit scatter and the reads)
+                const int col = 4 * ((t >> 2) ^ ch) + (t & 3);
+                uint16_t *vt = sVt + piece * 64 * VP;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vt[(ch * 8 + 2 * e) * VP + col] = (uint16_t)(vv[e] & 0xffffu);
+                    vt[(ch * 8 + 2 * e + 1) * VP + col] = (uint16_t)(vv[e] >> 16);
+                }
+            }
+        }
+        if (work && tid == 0) s_ticket = atomicAdd(&work[0], 1);    // everyone has read the previous ticket (barrier above)
+        // query fragments of the wavefront's first strip: lane (n, g) = query q0 + n, dims [32 kk + 8 g, + 8) of either piece
+        u32x4_t qh[2], ql[2];
+        {
+            const int q = wave * 16 + n;
+            const uint16_t *qr = Qp + (int64_t)(q < T ? q : T - 1) * tok_stride + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) { qh[kk] = *(const u32x4_t *)(qr + kk * 64); ql[kk] = *(const u32x4_t *)(qr + kk * 64 + 32); }
+        }
+        __syncthreads();
+        nxt = work ? s_ticket : item + (int)gridDim.x;
+        if (PF) atts_issue_loads<NLD, NTHR>(k8, v8, qkv, nxt < items ? nxt : items - 1, T, H, tid);      // in flight during the strips below
+#pragma unroll 1
+        for (int si = 0; si < NSTRIP; ++si) {
+            const int strip = wave + NW * si;
+            if (strip >= nstrip) break;
+            const int q0 = strip * 16;
+            half8_t bqh[2], bql[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) { bqh[kk] = __builtin_bit_cast(half8_t, qh[kk]); bql[kk] = __builtin_bit_cast(half8_t, ql[kk]); }
+            if (si + 1 < NSTRIP) {                                  // the next strip's query fragments
+                const int q = (strip + NW) * 16 + n;
+                const uint16_t *qr = Qp + (int64_t)(q < T ? q : T - 1) * tok_stride + g * 8;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) { qh[kk] = *(const u32x4_t *)(qr + kk * 64); ql[kk] = *(const u32x4_t *)(qr + kk * 64 + 32); }
+            }
+            f32x4_t acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const half8_t ah = *(const half8_t *)&sK[(t * 16 + n) * KP + kk * 32 + g * 8];
+                    const half8_t al = *(const half8_t *)&sK[TP * KP + (t * 16 + n) * KP + kk * 32 + g * 8];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bql[kk], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bqh[kk], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bqh[kk], acc[t], 0, 0, 0);
+                }
+                // keep the fragment loads of later key tiles behind this tile's MFMAs: left alone, the scheduler hoists all
+                // 4 NT of them (16 NT registers) to the top of the strip
+                if (t & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            // padded keys leave the softmax with -inf (the lane's key limit is made opaque per strip: see k_attention)
+            int lim = T - g * 4;
+            asm volatile("" : "+v"(lim));
+            if (T > 16 * (NT - 2)) {
+#pragma unroll
+                for (int t = NT - 2; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (t * 16 + i >= lim) acc[t][i] = -INFINITY;
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (t * 16 + i >= lim) acc[t][i] = -INFINITY;
+            }
+            f32x4_t mv = acc[0];
+#pragma unroll
+            for (int t = 1; t < NT; ++t) mv = __builtin_elementwise_max(mv, acc[t]);
+            float m = fmaxf(fmaxf(mv[0], mv[1]), fmaxf(mv[2], mv[3]));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            // p = 2^8 exp((s - m) / 8): the 2^8 rides in the exponent
+            const f32x4_t cv = {c, c, c, c}, nmc = {8.f - m * c, 8.f - m * c, 8.f - m * c, 8.f - m * c};
+            f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4_t e = __builtin_elementwise_fma(acc[t], cv, nmc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+                acc[t] = e;
+                sv += e;
+            }
+            float sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            f32x4_t o[4];
+            const uint16_t *v0p[4], *v1p[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                const int d = dt * 16 + n;
+                v0p[dt] = &sVt[d * VP + 4 * (g ^ (d >> 3))];
+                v1p[dt] = &sVt[d * VP + 4 * ((4 + g) ^ (d >> 3))];
+            }
+#pragma unroll
+            for (int ks = 0; ks < NT / 2; ++ks) {
+                uint32_t ph0, ph1, ph2, ph3, pl0, pl1, pl2, pl3;
+                split2(acc[2 * ks][0], acc[2 * ks][1], ph0, pl0);
+                split2(acc[2 * ks][2], acc[2 * ks][3], ph1, pl1);
+                split2(acc[2 * ks + 1][0], acc[2 * ks + 1][1], ph2, pl2);
+                split2(acc[2 * ks + 1][2], acc[2 * ks + 1][3], ph3, pl3);
+                const half8_t ah = __builtin_bit_cast(half8_t, (u32x4_t){ph0, ph1, ph2, ph3});
+                const half8_t al = __builtin_bit_cast(half8_t, (u32x4_t){pl0, pl1, pl2, pl3});
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const uint2 h0 = *(const uint2 *)(v0p[dt] + 32 * ks), h1 = *(const uint2 *)(v1p[dt] + 32 * ks);
+                    const uint2 l0 = *(const uint2 *)(v0p[dt] + 64 * VP + 32 * ks), l1 = *(const uint2 *)(v1p[dt] + 64 * VP + 32 * ks);
+                    const half8_t vh = __builtin_bit_cast(half8_t, (u32x4_t){h0.x, h0.y, h1.x, h1.y});
+                    const half8_t vl = __builtin_bit_cast(half8_t, (u32x4_t){l0.x, l0.y, l1.x, l1.y});
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vh, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vh, o[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // o[dt][i] = 2^8 sum O[query q0 + 4g + i][d = 16 dt + n]; the row sums (x 2^8 as well) sit with the lanes whose n is that query
+            const float inv = out_scale / sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = __shfl(inv, g * 4 + i);
+                const int q = q0 + g * 4 + i;
+                if (q < T) {
+                    uint16_t *dst = out + ((int64_t)b * T + q) * 2 * H * 64 + (int64_t)2 * h * 64 + n;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const float v = o[dt][i] * r;
+                        const _Float16 hh = (_Float16)v;
+                        const _Float16 ll = (_Float16)(v - (float)hh);
+                        uint16_t *d2 = dst + (dt >> 1) * 64 + (dt & 1) * 16;          // chunk 2 h + (dt >> 1): [h 32 | l 32]
+                        d2[0] = *(const uint16_t *)&hh;
+                        d2[32] = *(const uint16_t *)&ll;
+                    }
+                }
+            }
+        }
+    }
+    // the last workgroup to leave re-arms the counters for the next launch on this stream
+    if (work && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&work[1], 1) == (int)gridDim.x - 1) {
+            work[0] = 0;
+            work[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
+extern "C" bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                                              void *out_pieces_dev, float out_scale, int32_t *work2_dev, void *hip_stream)
+{
+    if (!qkv_pieces_dev || !out_pieces_dev || B < 1 || T < 1 || heads < 1) return BSC_E_INVALID;
+    if (head_dim != 64 || T > 288) {
+        bsc_set_error("bsc_enc_attention_split: head_dim 64 and T <= 288 only (got %d, %d)", head_dim, T);
+        return BSC_E_INVALID;
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    static int n_cu = 0;                // one workgroup per CU
+    if (!n_cu) {
+        int dev = 0;
+        BSC_HIP(hipGetDevice(&dev));
+        BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int64_t items = (int64_t)B * heads;
+    const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
+#define BSC_ATT_LAUNCH(NTV, NWV, PFV)                                                                                                   \
+    do {                                                                                                                             \
+        constexpr int TPv = NTV * 16, VPv = 4 * (((TPv / 4 - 1) | 7) + 1) + 8;                                                       \
+        const size_t lds = (size_t)2 * (TPv * 72 + 64 * VPv) * sizeof(uint16_t);                                                     \
+        static bool attr_set = false;                                                                                                \
+        if (!attr_set) {                                                                                                             \
+            BSC_HIP(hipFuncSetAttribute((const void *)k_attention_split<NTV, NWV, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                                         \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((k_attention_split<NTV, NWV, PFV>), grid, dim3(64 * NWV), lds, s, (const uint16_t *)qkv_pieces_dev, T, heads,  \
+                           (int)items, (uint16_t *)out_pieces_dev, out_scale, (int *)work2_dev);                                     \
+    } while (0)
+    // 4 wavefronts, one per SIMD, with the 512-register budget: the next item's K / V pieces wait in registers during the strips
+    static const int att_mode = getenv("BSC_ATT_SPLIT_MODE") ? atoi(getenv("BSC_ATT_SPLIT_MODE")) : 0;
+    if (T <= 224) { if (att_mode == 1) BSC_ATT_LAUNCH(14, 4, true); else BSC_ATT_LAUNCH(14, 7, false); }
+    else { if (att_mode == 1) BSC_ATT_LAUNCH(18, 4, true); else BSC_ATT_LAUNCH(18, 8, false); }
+#undef BSC_ATT_LAUNCH
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
 extern "C" bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32_t K, float scale, void *pieces_dev, void *hip_stream)
 {
     if (!w_dev || !pieces_dev || N <= 0 || K <= 0 || (K & 1)) { bsc_set_error("bsc_enc_split_weights: invalid argument"); return BSC_E_INVALID; }
@@ -359,8 +625,9 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
         if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, true, false);
         else BSC_GEMM_LAUNCH(GS_EPI_RESID, false, false);
     } else {
-        if (cp) { bsc_set_error("bsc_enc_gemm_split: piece output is for the GELU epilogue"); return BSC_E_INVALID; }
-        if (ap) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, false);
+        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, true);
+        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, false);
+        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, false, true);
         else BSC_GEMM_LAUNCH(GS_EPI_BIAS, false, false);
     }
 #undef BSC_GEMM_LAUNCH

@@ -33,6 +33,34 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+_ATT_WORK = {}            # (device, stream) -> ticket / finished counters of the persistent attention kernels
+_ATT_WORK_OVERRIDE = []   # a GraphedEncoder's own pair while it warms up and captures
+
+
+def attention_work(device):
+    """Ticket / finished counters of the attention kernels: launches on one stream are ordered and may share a pair; a
+    captured graph owns its pair (GraphedEncoder allocates it before the capture), so two graphs replayed on different
+    streams never meet in one."""
+    if _ATT_WORK_OVERRIDE:
+        return _ATT_WORK_OVERRIDE[-1]
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _ATT_WORK:
+        _ATT_WORK[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return _ATT_WORK[key]
+
+
+def attention_split(qkv_pieces, B, T, heads, out_scale=1.0):
+    """softmax(Q K^T / 8) V at f32 accuracy on the fp16 matrix cores (bsc_enc_attention_split): qkv_pieces = the pieces the qkv
+    GEMM wrote, (B T, 2 * 3 * heads * 64) fp16 -> pieces of out_scale * attention, (B T, 2 * heads * 64) fp16."""
+    from . import _lib
+    out = torch.empty((B * T, 2 * heads * 64), dtype=torch.float16, device=qkv_pieces.device)
+    _lib.check(_lib.load().bsc_enc_attention_split(
+        C.c_void_p(qkv_pieces.data_ptr()), B, T, heads, 64, C.c_void_p(out.data_ptr()), float(out_scale),
+        C.c_void_p(attention_work(qkv_pieces.device).data_ptr()),
+        C.c_void_p(torch.cuda.current_stream(qkv_pieces.device).cuda_stream)))
+    return out
+
+
 class SplitLinear:
     """nn.Linear at f32 accuracy on the fp16 matrix cores (bsc_enc_gemm_split): the weight's two fp16 pieces are made once
     (scaled by the power of two that puts its largest element in (4, 8]), the activation rows are split in registers.
@@ -118,12 +146,8 @@ class _Block(nn.Module):
         # ticket / finished counters: one pair per (device, stream) — launches on one stream are ordered and may share
         # them, two forwards of this module on different streams (a graph replay beside an eager query embedding) may not
         stream = torch.cuda.current_stream(y.device)
-        key = (y.device, stream.cuda_stream)
-        works = self.__dict__.setdefault("_att_works", {})
-        if key not in works:
-            works[key] = torch.zeros(2, dtype=torch.int32, device=y.device)
         _lib.check(_lib.load().bsc_enc_attention_dyn(C.c_void_p(qkv.data_ptr()), B, T, self.heads, hd,
-                                                     C.c_void_p(a.data_ptr()), C.c_void_p(works[key].data_ptr()),
+                                                     C.c_void_p(a.data_ptr()), C.c_void_p(attention_work(y.device).data_ptr()),
                                                      C.c_void_p(stream.cuda_stream)))
         return a
 
@@ -356,12 +380,19 @@ class RandomViT(nn.Module):
                 return layernorm_split(u, ln), True
             return F.layer_norm(u, (Wd,), ln.weight, ln.bias, ln.eps), False
 
+        own_attention = hd == 64 and T <= 288 and os.environ.get("BSC_ENC_SPLIT_ATTENTION", "1") == "1"
         for blk in self.blocks:
             y, yp = ln_in(blk.ln1)
-            qkv = self._split(blk.qkv)(y, a_pieces=yp).view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
-            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-            a = a.transpose(1, 2).reshape(B * T, Wd)
-            self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0)
+            if own_attention:
+                # q, k, v leave the GEMM as pieces, the attention kernel reads and writes pieces: no f32 copy, no transpose
+                qkv = self._split(blk.qkv)(y, a_pieces=yp, c_pieces_scale=1.0)
+                a = attention_split(qkv, B, T, heads, out_scale=16.0)
+                self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0, a_pieces=True)
+            else:
+                qkv = self._split(blk.qkv)(y, a_pieces=yp).view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+                a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+                a = a.transpose(1, 2).reshape(B * T, Wd)
+                self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0)
             y, yp = ln_in(blk.ln2)
             # the hidden tensor exists only as pieces (scaled by 4): written by fc1's GELU epilogue, read by fc2
             h = self._split(blk.fc1)(y, SL.GELU, a_pieces=yp, c_pieces_scale=4.0)
@@ -481,6 +512,16 @@ class GraphedEncoder:
         probe = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
         self.from_patches = vit.can_fuse_preprocess(probe) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
         s = torch.cuda.Stream()
+        # this graph's attention counters: allocated before the capture (outside the graph's private pool), used by every
+        # attention launch of the warm-up and of the captured forward
+        self.att_work = torch.zeros(2, dtype=torch.int32, device="cuda")
+        _ATT_WORK_OVERRIDE.append(self.att_work)
+        try:
+            self._capture(vit, batch, probe, keep_dtype, s)
+        finally:
+            _ATT_WORK_OVERRIDE.pop()
+
+    def _capture(self, vit, batch, probe, keep_dtype, s):
         if self.from_patches:
             self.static_in = vit.preprocess_patches(probe)
             run = lambda: vit._forward_patches(self.static_in, keep_dtype)["x_norm_patchtokens"].reshape(

@@ -272,10 +272,14 @@ bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int3
  *                          2 bias + residual (c_dev may alias resid_dev); out_scale = 1 / (a_scale * scale); K % 32 == 0;
  *                          |a_scale * A| < 65504 (fp16 range).  a_pieces != 0: a_dev holds the activation pieces already (layout
  *                          below; a_scale was applied by their producer) — otherwise f32 rows, split in registers.
- *                          c_pieces_scale != 0 (GELU epilogue): c_dev receives pieces of c_pieces_scale * C instead of f32.
+ *                          c_pieces_scale != 0 (epilogues 0, 1): c_dev receives pieces of c_pieces_scale * C instead of f32.
  *   piece layout of an (M,K) activation matrix: fp16, row m = K/32 chunks of 64, chunk c = [h of k in 32c..32c+31 | l of the same]
  *   bsc_enc_layernorm_split  LayerNorm of f32 rows (width 256..1024) written as pieces of a_scale * y
- *   bsc_enc_split_rows       f32 rows -> pieces of a_scale * x */
+ *   bsc_enc_split_rows       f32 rows -> pieces of a_scale * x
+ *   bsc_enc_attention_split  softmax(Q K^T / sqrt(64)) V per (image, head) at f32 accuracy (three piece products per matrix
+ *                            product, f32 softmax): qkv_pieces_dev = pieces of the (B T, 3 heads 64) output of the qkv GEMM
+ *                            (c_pieces_scale 1), out = pieces of out_scale * attention (B T, heads 64), the projection GEMM's
+ *                            operand; head_dim 64, T <= 288; work2_dev as bsc_enc_attention_dyn (NULL: static schedule) */
 bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32_t K, float scale, void *pieces_dev, void *hip_stream);
 bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N, const float *bias_dev,
                               const float *resid_dev, void *c_dev, float a_scale, float out_scale, int32_t epilogue,
@@ -283,6 +287,8 @@ bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const voi
 bsc_status bsc_enc_layernorm_split(const float *x_dev, const float *gamma_dev, const float *beta_dev, int64_t rows, int32_t width,
                                    float eps, float a_scale, void *pieces_dev, void *hip_stream);
 bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t K, float a_scale, void *pieces_dev, void *hip_stream);
+bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                                   void *out_pieces_dev, float out_scale, int32_t *work2_dev, void *hip_stream);
 
 /* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
  * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM

@@ -91,3 +91,23 @@ def test_f32_encoder_on_split_gemms_matches_pytorch_f32(arch):
     assert (a - b).abs().max().item() < 2e-5
     e_split, e_torch = (a.double() - c).abs().max().item(), (b.double() - c).abs().max().item()
     assert e_split <= max(1.5 * e_torch, 5e-6), (e_split, e_torch)
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 197, 12), (2, 261, 16), (1, 17, 2), (2, 224, 1)])
+def test_attention_split_matches_fp32_softmax(B, T, H):
+    """softmax(Q K^T / 8) V on fp16 pieces against PyTorch's f32 attention and an fp64 evaluation: within 1e-5 of the former,
+    no further from fp64 than it (x2), incl. ragged key tiles (T not a multiple of 16) and both LDS shapes (T <= 224, <= 288)."""
+    import torch
+    import torch.nn.functional as F
+    from bsc_nav_amd import encoder
+    torch.manual_seed(B * 1000 + T + H)
+    qkv = torch.randn(B * T, 3 * H * 64, device="cuda") * 0.7
+    qp = encoder.split_rows(qkv, 1.0)
+    out = encoder.attention_split(qp, B, T, H, out_scale=16.0)
+    got = _pieces_back(out, B * T, H * 64, 16.0)
+    v = qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref64 = F.scaled_dot_product_attention(v[0].double(), v[1].double(), v[2].double()).transpose(1, 2).reshape(B * T, H * 64)
+    ref32 = F.scaled_dot_product_attention(v[0], v[1], v[2]).transpose(1, 2).reshape(B * T, H * 64)
+    e32 = (ref32.double() - ref64).abs().max().item()
+    assert (got - ref64).abs().max().item() <= max(2.0 * e32, 2e-6)
+    assert (got - ref32.double()).abs().max().item() <= 1e-5
