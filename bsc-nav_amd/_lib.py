@@ -72,6 +72,7 @@ SIGNATURES = {
     "bsc_enc_attention": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP]),
     "bsc_enc_attention_dyn": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "bsc_enc_preprocess_patches": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
+    "bsc_enc_preprocess_patches_typed": (_I32, [_VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _VP, _VP, _VP]),
     "bsc_host_choice_draws": (_I32, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "bsc_host_shuffled_sample": (_I32, [_VP, _VP, _I64, _I32, _VP, _VP]),
     "bsc_enc_split_weights": (_I32, [_VP, _I32, _I32, C.c_float, _VP, _VP]),

@@ -379,8 +379,23 @@ __device__ __forceinline__ void aa_taps(int o, float scale, int in_size, int &lo
     for (int i = 0; i < PP_TAPS; ++i) w[i] *= inv;
 }
 
+// one element of the unfolded patch matrix (row, k of K): mode 0 bf16, 1 f32, 2 fp16 pieces in the chunk-interleaved layout of the
+// split-operand GEMM (encoder_gemm.hip: row = K / 32 chunks of [32 h | 32 l]; K % 32 == 0)
+__device__ __forceinline__ void pp_store(void *out, int mode, int64_t row, int K, int k, float v)
+{
+    if (mode == 0) ((uint16_t *)out)[row * K + k] = f2bf(v);
+    else if (mode == 1) ((float *)out)[row * K + k] = v;
+    else {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        uint16_t *o = (uint16_t *)out + row * 2 * K + (int64_t)(k >> 5) * 64 + (k & 31);
+        o[0] = *(const uint16_t *)&h;
+        o[32] = *(const uint16_t *)&l;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__restrict__ rgb, int B, int H, int W, int C,
-                                                            int S, int p, uint16_t *__restrict__ out, float m0, float m1,
+                                                            int S, int p, void *__restrict__ out, int mode, float m0, float m1,
                                                             float m2, float s0, float s1, float s2)
 {
     const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -420,10 +435,10 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__res
         }
     }
     const int g = S / p, gy = y / p, gx = x / p, py = y - gy * p, px = x - gx * p;
-    uint16_t *dst = out + ((int64_t)b * g * g + (int64_t)gy * g + gx) * (3 * p * p) + py * p + px;
-    dst[0] = f2bf((a0 * (1.f / 255.f) - m0) / s0);
-    dst[p * p] = f2bf((a1 * (1.f / 255.f) - m1) / s1);
-    dst[2 * p * p] = f2bf((a2 * (1.f / 255.f) - m2) / s2);
+    const int64_t row = (int64_t)b * g * g + (int64_t)gy * g + gx;
+    pp_store(out, mode, row, 3 * p * p, py * p + px, (a0 * (1.f / 255.f) - m0) / s0);
+    pp_store(out, mode, row, 3 * p * p, p * p + py * p + px, (a1 * (1.f / 255.f) - m1) / s1);
+    pp_store(out, mode, row, 3 * p * p, 2 * p * p + py * p + px, (a2 * (1.f / 255.f) - m2) / s2);
 }
 
 // RGBA frames, one workgroup per output patch.  The taps of every output row and column (first input index, count, 12
@@ -452,7 +467,7 @@ __global__ void k_pp_taps(int S, int H, int W, PpTap *__restrict__ ty, PpTap *__
 template <int TXN>      // column taps evaluated per row (>= the largest tap count of any output column)
 __global__ __launch_bounds__(TPB) void k_preprocess_patches_tiled(const uint32_t *__restrict__ rgba, int B, int H, int W, int S,
                                                                   int p, const PpTap *__restrict__ ty,
-                                                                  const PpTap *__restrict__ tx, uint16_t *__restrict__ out,
+                                                                  const PpTap *__restrict__ tx, void *__restrict__ out, int mode,
                                                                   float m0, float m1, float m2, float s0, float s1, float s2)
 {
     __shared__ uint32_t tile[PPT_MAXH][PPT_MAXW + 1];
@@ -488,17 +503,25 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches_tiled(const uint32_t
         const float wyi = wyp->w[i];
         a0 += wyi * r0; a1 += wyi * r1; a2 += wyi * r2;
     }
-    uint16_t *dst = out + ((int64_t)b * g * g + patch) * (3 * p * p) + py * p + px;
-    dst[0] = f2bf((a0 * (1.f / 255.f) - m0) / s0);
-    dst[p * p] = f2bf((a1 * (1.f / 255.f) - m1) / s1);
-    dst[2 * p * p] = f2bf((a2 * (1.f / 255.f) - m2) / s2);
+    const int64_t row = (int64_t)b * g * g + patch;
+    pp_store(out, mode, row, 3 * p * p, py * p + px, (a0 * (1.f / 255.f) - m0) / s0);
+    pp_store(out, mode, row, 3 * p * p, p * p + py * p + px, (a1 * (1.f / 255.f) - m1) / s1);
+    pp_store(out, mode, row, 3 * p * p, 2 * p * p + py * p + px, (a2 * (1.f / 255.f) - m2) / s2);
 }
 
 extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C,
                                                  int32_t S, int32_t patch, void *out_dev, const float *mean3_host,
                                                  const float *std3_host, void *hip_stream)
 {
-    if (!rgb_dev || !out_dev || !mean3_host || !std3_host || B < 1 || C < 3 || patch < 1 || S % patch != 0) {
+    return bsc_enc_preprocess_patches_typed(rgb_dev, B, H, W, C, S, patch, out_dev, 0, mean3_host, std3_host, hip_stream);
+}
+
+extern "C" bsc_status bsc_enc_preprocess_patches_typed(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C,
+                                                       int32_t S, int32_t patch, void *out_dev, int32_t out_mode,
+                                                       const float *mean3_host, const float *std3_host, void *hip_stream)
+{
+    if (!rgb_dev || !out_dev || !mean3_host || !std3_host || B < 1 || C < 3 || patch < 1 || S % patch != 0 || out_mode < 0 ||
+        out_mode > 2 || (out_mode == 2 && (3 * patch * patch) % 32 != 0)) {
         bsc_set_error("bsc_enc_preprocess_patches: invalid argument");
         return BSC_E_INVALID;
     }
@@ -526,7 +549,7 @@ extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B,
 #define PPT_LAUNCH(TXN)                                                                                               \
         hipLaunchKernelGGL((k_preprocess_patches_tiled<TXN>), dim3((unsigned)((int64_t)B * g * g)), dim3(TPB), 0,         \
                            (hipStream_t)hip_stream, (const uint32_t *)rgb_dev, B, H, W, S, patch, tab[dev], tab[dev] + S, \
-                           (uint16_t *)out_dev, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],  \
+                           out_dev, out_mode, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],    \
                            std3_host[2])
         if (2.f * supw + 2.f <= 8.f) PPT_LAUNCH(8);     // a column has at most floor(2 * support) + 2 taps
         else PPT_LAUNCH(PP_TAPS);
@@ -536,7 +559,7 @@ extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B,
     }
     const int64_t n = (int64_t)B * S * S;
     hipLaunchKernelGGL(k_preprocess_patches, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)hip_stream,
-                       (const uint8_t *)rgb_dev, B, H, W, C, S, patch, (uint16_t *)out_dev, mean3_host[0], mean3_host[1],
+                       (const uint8_t *)rgb_dev, B, H, W, C, S, patch, out_dev, out_mode, mean3_host[0], mean3_host[1],
                        mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     BSC_HIP(hipGetLastError());
     return BSC_OK;

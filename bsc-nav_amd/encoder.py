@@ -357,15 +357,17 @@ class RandomViT(nn.Module):
             cache[key] = (lin.weight.data_ptr(), SplitLinear(lin))
         return cache[key][1]
 
-    def _forward_f32_split(self, t):
+    def _forward_f32_split(self, t, t_pieces=False):
         """The f32 forward (the reference's precision) with every dense layer on the fp16 matrix cores at f32 accuracy:
-        bias, GELU and the residual adds ride in the GEMM epilogues; LayerNorm and attention stay f32 PyTorch ops."""
-        B, n_patch, kin = t.shape
+        bias, GELU and the residual adds ride in the GEMM epilogues, LayerNorm and the MLP's hidden tensor leave as operand
+        pieces, attention runs on pieces (bsc_enc_attention_split).  t: the unfolded patch matrix, f32 or (t_pieces) pieces."""
+        B, n_patch = t.shape[0], t.shape[1]
+        kin = t.shape[2] // 2 if t_pieces else t.shape[2]
         Wd, heads = self.width, self.blocks[0].heads
         hd = Wd // heads
         SL = SplitLinear
         if kin % 32 == 0:
-            x = self._split(self.patch_embed)(t.reshape(B * n_patch, kin).contiguous()).view(B, n_patch, Wd)
+            x = self._split(self.patch_embed)(t.reshape(B * n_patch, t.shape[2]).contiguous(), a_pieces=t_pieces).view(B, n_patch, Wd)
         else:
             x = self.patch_embed(t)
         x = torch.cat([self.cls.expand(B, -1, -1), x], dim=1) + self.pos
@@ -469,18 +471,30 @@ class RandomViT(nn.Module):
     def can_fuse_preprocess(self, rgb):
         return self.fused and rgb.is_cuda and self.compute_dtype == torch.bfloat16 and rgb.is_contiguous()
 
+    def can_fuse_preprocess_f32(self, rgb):
+        """the f32 encoder on split GEMMs takes its patch matrix from the same fused kernel: as fp16 pieces when the patch
+        embedding can read them (3 p^2 % 32 == 0), otherwise as f32"""
+        return self.fused and self.split_gemm and rgb.is_cuda and rgb.is_contiguous() and self.head is None
+
     @torch.no_grad()
-    def preprocess_patches(self, rgb, out=None):
-        """u8 frames (B,H,W,C) -> normalised, unfolded bf16 patch matrix (B, g*g, 3*p*p) in one pass
-        (bsc_enc_preprocess_patches: /255, antialiased bilinear resize, ImageNet normalise, unfold)."""
+    def preprocess_patches(self, rgb, out=None, mode=0):
+        """u8 frames (B,H,W,C) -> normalised, unfolded patch matrix (B, g*g, 3*p*p) in one pass (bsc_enc_preprocess_patches:
+        /255, antialiased bilinear resize, ImageNet normalise, unfold): mode 0 bf16, 1 f32, 2 fp16 pieces (B, g*g, 2*3*p*p)."""
         from . import _lib
         B, H, W, Cc = rgb.shape
         g, p = self.grid, self.patch
-        patches = out if out is not None else torch.empty((B, g * g, 3 * p * p), dtype=torch.bfloat16, device=rgb.device)
+        kin = 3 * p * p
+        if mode == 0:
+            shape, dt = (B, g * g, kin), torch.bfloat16
+        elif mode == 1:
+            shape, dt = (B, g * g, kin), torch.float32
+        else:
+            shape, dt = (B, g * g, 2 * kin), torch.float16
+        patches = out if out is not None else torch.empty(shape, dtype=dt, device=rgb.device)
         mean = (C.c_float * 3)(*IMAGENET_MEAN)
         std = (C.c_float * 3)(*IMAGENET_STD)
-        _lib.check(_lib.load().bsc_enc_preprocess_patches(
-            C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mean, std,
+        _lib.check(_lib.load().bsc_enc_preprocess_patches_typed(
+            C.c_void_p(rgb.data_ptr()), B, H, W, Cc, self.image_size, p, C.c_void_p(patches.data_ptr()), mode, mean, std,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return patches
 
@@ -490,6 +504,9 @@ class RandomViT(nn.Module):
         (keep_dtype) the encoder's own bf16, which bsc_ingest_typed widens exactly on load."""
         if self.can_fuse_preprocess(rgb):
             t = self._forward_patches(self.preprocess_patches(rgb), keep_dtype)["x_norm_patchtokens"]
+        elif self.can_fuse_preprocess_f32(rgb):
+            pieces = (3 * self.patch * self.patch) % 32 == 0
+            t = self._forward_f32_split(self.preprocess_patches(rgb, mode=2 if pieces else 1), pieces)
         else:
             t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
         return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()

@@ -296,6 +296,11 @@ bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_t B, int32_
 bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C, int32_t S,
                                       int32_t patch, void *out_dev, const float *mean3_host, const float *std3_host,
                                       void *hip_stream);
+/* the same pass with a choice of output: out_mode 0 bf16 (as above), 1 f32, 2 fp16 pieces for the split-operand patch-embedding
+ * GEMM (3 patch^2 % 32 == 0) — the reference-precision encoder starts from these */
+bsc_status bsc_enc_preprocess_patches_typed(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C, int32_t S,
+                                            int32_t patch, void *out_dev, int32_t out_mode, const float *mean3_host,
+                                            const float *std3_host, void *hip_stream);
 
 /* HIP-event timing of the stages of the path, recorded around every launch on the stream the stage runs on.
  * which: 0 dense feature reduce (k_dense_reduce), 1 cosine scan of bsc_localize, 2 k_points (geometry + claims),
