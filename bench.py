@@ -14,15 +14,20 @@ itself (python -m torch.distributed.run on 127.0.0.1) and exits non-zero when fe
 torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0) carrying, beside the contract keys:
-  roofline        the whole bsc_ingest call priced per SURVEY.md §8(d) (algorithmic bytes of the batch / HIP-event time
-                  of the call's main-stream work), dominant kernel named; roofline_kernels: every stage with its own bytes
+  roofline        the whole bsc_ingest call priced per SURVEY.md §8(d): algorithmic bytes of the batch / WALL time of the call
+                  followed by bsc_sync, alone (main stream + order stage + rgb chain on the side stream); the main-stream
+                  HIP-event times ride as side keys; dominant kernel named; roofline_kernels: every stage with its own bytes
+  exact_mode      the reference-semantics mode (token cache, <= 10 raw tokens per voxel, random replacement, host-shuffled
+                  sub-sampling at depth_sample_rate 1000 and 50): frames/s frame by frame through obs2voxeltoken and batched
   workloads       the same pipeline on "hall" (24 x 24 m, 10^5..10^6 voxels) and "iid" (one voxel per point) depth:
                   frames/s, voxels, U/P, fraction of the §8(d) HBM bound
   configs         BASELINE configs[2] per GPU (ViT-L/14, 1024-D, 512^3) and configs[3]/[4] localize at 2^20 x 1024
   cpu_baseline    the plain-C oracle (port of the reference loop) on this box's host cores: 1 core and all cores
   value_f32_encoder / memory_path_frames_per_s / tokens_bf16_*   the same pipeline at the reference's encoder precision
-                  (f32 weights, activations and tokens), the memory path alone (f64 geometry, f32 accumulate: what the
-                  parity tests cover), and the error of the stored feature means of the timed bf16 configuration against it
+                  (f32 weights, activations and tokens; dense layers and attention in-tree on the fp16 matrix cores with split
+                  operands, csrc/encoder_gemm.hip), timed like `value`; the memory path alone (f64 geometry, f32 accumulate:
+                  what the parity tests cover); the error of the stored feature means of the timed bf16 configuration
+Every leg besides the headline is guarded: a failure leaves {"error": ...} under its key instead of losing the line.
 """
 import argparse
 import json
@@ -53,6 +58,7 @@ if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" n
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+PMC_FILE = "r04_pmc_ingest_kernels.json"
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0
 MFMA_F32_PEAK_TF = 157.3
@@ -83,6 +89,7 @@ def parse():
     ap.add_argument("--no-localize", action="store_true", help="skip the localize top-K latency measurements")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32 encoder) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the hall / iid workloads and the C3 leg")
+    ap.add_argument("--no-exact", action="store_true", help="skip the reference-semantics (exact mode) leg")
     return ap.parse_args()
 
 
@@ -94,11 +101,11 @@ def ingest_alg_bytes(F, N, g, D, tok_bytes, U, P_sampled=0):
 
 def pmc_traffic():
     """HBM-side bytes per bsc_ingest call from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r03_pmc_ingest_kernels.json, scripts/pmc_summary.py: read / write requests of the L2's memory side counted by
+    (profiles/r04_pmc_ingest_kernels.json, scripts/pmc_summary.py: read / write requests of the L2's memory side counted by
     request size — 32 / 64 / 128 B —, two separate --pmc passes, summed over the call's kernels; the counters are checked on
     known-byte kernels in profiles/r03_pmc_calibration.txt).  The file names the commit it was measured at; None when absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_ingest_kernels.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
         return float(d["ingest_traffic_bytes_per_call"]), d.get("commit")
     except Exception:
@@ -219,16 +226,18 @@ def stage_rooflines(p, iso, tok_bytes):
     return out
 
 
-def reference_precision_leg(a, p, local_rank, steps=3):
+def reference_precision_leg(a, p, local_rank, repeats=3):
     """The pipeline at the reference's encoder precision (memory_2.py:43,738-739: DINOv2 runs f32): the same architecture and
-    the same random weights NOT rounded to bf16, f32 activations through PyTorch-ROCm's f32 GEMMs, f32 tokens into
-    bsc_ingest — frames/s of `steps` steps after one warm-up, encoder and ingest back to back on one stream.  And what the
-    bf16 configuration that `value` times costs in accuracy: the stored per-voxel feature means of one batch ingested with
-    the bf16 encoder + bf16 tokens against the f32 encoder + f32 tokens (same frames, same voxels)."""
+    the same random weights NOT rounded to bf16, f32 activations and tokens.  The dense layers and attention run in-tree on the
+    fp16 matrix cores with split operands at f32 accuracy (csrc/encoder_gemm.hip; tests/test_gpu_encoder_f32.py: closer to an
+    fp64 evaluation than PyTorch's f32 GEMMs are).  Timed like `value`: the K steps after the warm-up, `repeats` times on a reset
+    map, median; encoder and ingest back to back on one stream.  Side keys: the same with PyTorch-ROCm's f32 GEMMs + SDPA (one
+    short pass), and what the bf16 configuration that `value` times costs in accuracy — the stored per-voxel feature means of
+    one batch ingested with the bf16 encoder + bf16 tokens against the f32 encoder + f32 tokens (same frames, same voxels)."""
     B = p.B
     from bsc_nav_amd import encoder
     tuning_was_on = None
-    try:                                            # library-default f32 GEMM solutions: no TunableOp search for this leg
+    try:                                            # library-default f32 GEMM solutions for the PyTorch comparison pass
         tuning_was_on = torch.cuda.tunable.tuning_is_enabled()
         torch.cuda.tunable.tuning_enable(False)
     except Exception:
@@ -239,23 +248,42 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     def eng():
         return B.VoxelEngine(p.H, p.W, a.grid, 0.1, -half, half, p.g, p.D, mode=a.mode, voxel_capacity=3_000_000,
                              max_points=p.batch * p.N, device=local_rank)
+
+    def run(e, lo, hi):
+        for s in range(lo, hi):
+            e.ingest(p.depths[s], p.rgbs[s], vit32.patch_tokens(p.rgbs[s]), p.Ts[s * p.batch:(s + 1) * p.batch])
+
     e32 = eng()
-    n = min(steps + 1, p.n_steps)
+    n = p.n_steps
+    w = min(a.warmup, n - 1)
     e32.ingest(p.depths[0], p.rgbs[0], vit32.patch_tokens(p.rgbs[0]), p.Ts[:p.batch])
     acc32, cnt32 = e32.export_dense()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(1, n):
-        e32.ingest(p.depths[s], p.rgbs[s], vit32.patch_tokens(p.rgbs[s]), p.Ts[s * p.batch:(s + 1) * p.batch])
-    e32.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for rep in range(repeats):
+        e32.reset()
+        run(e32, 0, w)
+        e32.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(e32, w, n)
+        e32.sync(); torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
-    vit32.patch_tokens(p.rgbs[0])
+    for _ in range(3):
+        vit32.patch_tokens(p.rgbs[0])
     ev[1].record()
     torch.cuda.synchronize()
-    enc_ms = ev[0].elapsed_time(ev[1])
+    enc_ms = ev[0].elapsed_time(ev[1]) / 3
+    # the same leg on PyTorch-ROCm's own f32 GEMMs / SDPA (what round 3 reported), one short pass
+    vit32.split_gemm = False
+    e32.reset()
+    run(e32, 0, 1)
+    e32.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(e32, 1, min(n, 4))
+    e32.sync(); torch.cuda.synchronize()
+    dt_torch, n_torch = time.perf_counter() - t0, min(n, 4) - 1
     e32.close()
     e16 = eng()
     e16.ingest(p.depths[0], p.rgbs[0], p.vit.patch_tokens(p.rgbs[0], True), p.Ts[:p.batch])
@@ -272,15 +300,101 @@ def reference_precision_leg(a, p, local_rank, steps=3):
     c = np.maximum(cnt32, 1)[:, None].astype(np.float32)
     m16, m32 = acc16 / c if a.mode == "mean" else acc16, acc32 / c if a.mode == "mean" else acc32
     d = np.abs(m16 - m32)
-    return {"value_f32_encoder": (n - 1) * p.batch / dt, "f32_encoder_ms_per_step": enc_ms,
-            "f32_encoder_tflops": p.vit.flops_per_frame() * p.batch / (enc_ms * 1e-3) / 1e12,
+    fl = p.vit.flops_per_frame() * p.batch
+    return {"value_f32_encoder": (n - w) * p.batch / dt, "f32_steps": n - w, "f32_repeats": repeats, "f32_seconds_per_repeat": times,
+            "f32_encoder_ms_per_step": enc_ms, "f32_encoder_tflops": fl / (enc_ms * 1e-3) / 1e12,
+            "f32_encoder_fp16_mfma_tflops": 3.0 * fl / (enc_ms * 1e-3) / 1e12,
+            "f32_encoder_frac_of_16bit_mfma_peak": 3.0 * fl / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+            "value_f32_encoder_pytorch_gemms": n_torch * p.batch / dt_torch,
             "tokens_bf16_max_abs_err": float(d.max()), "tokens_bf16_mean_abs_err": float(d.mean()),
             "tokens_rms": float(np.sqrt((m32.astype(np.float64) ** 2).mean())),
-            "note": f"value_f32_encoder: {n - 1} steps x {p.batch} frames, f32 encoder (PyTorch-ROCm f32 GEMMs, no bf16 anywhere) + "
-                    "f32 tokens + bsc_ingest, one stream; tokens_bf16_*: per-voxel feature means of one batch, bf16 encoder + bf16 "
-                    "tokens (the configuration `value` times) against f32 encoder + f32 tokens.  The north star's 1e-3 "
-                    "feature bound is met by the memory path for the tokens it is given (f32 accumulate; tests), not by "
-                    "a bf16 encoder against an f32 one"}
+            "note": f"value_f32_encoder: {n - w} steps x {p.batch} frames after {w} warm-up steps, median of {repeats} repeats; f32 "
+                    "encoder with every dense layer and attention on the fp16 matrix cores as split operands (x = h + l, products "
+                    "hh + hl + lh in the f32 accumulator: 3 MFMA flops per f32 flop; tokens within 1e-5 of PyTorch f32 and closer to "
+                    "fp64 than it) + f32 tokens + bsc_ingest, one stream; value_f32_encoder_pytorch_gemms: the same with PyTorch-ROCm's "
+                    f"f32 GEMMs and SDPA, {n_torch} steps, one pass; tokens_bf16_*: per-voxel feature means of one batch, bf16 encoder + "
+                    "bf16 tokens (the configuration `value` times) against f32 encoder + f32 tokens.  The north star's 1e-3 feature bound "
+                    "is met by the memory path for the tokens it is given (f32 accumulate; tests), not by a bf16 encoder against an f32 one"}
+
+
+def exact_mode_leg(a, local_rank, frames=192):
+    """The reference-semantics mode (the only one whose every output is pinned to the reference's goldens): token cache of
+    50 000 rows flushed into <= 10 raw tokens per voxel with random.choice replacement, host-shuffled sub-sampling on NumPy's
+    global stream (memory_2.py:747-749), host alpha.  640x480 frames, 16x16x1024 tokens from a stand-in provider (the encoder is
+    not part of this leg), 256^3 grid, depth_sample_rate 1000 (the reference's default, args.py) and 50: frame by frame through
+    VoxelTokenMemory.obs2voxeltoken — host frames in, as the reference's loop hands them over — with and without the sampling
+    drawn one frame ahead on a host thread (prefetched_sampling), and batched through ingest_frames (device frames)."""
+    import random
+    import tempfile
+    import types
+    import bsc_nav_amd as B
+    from bsc_nav_amd import synthetic, geometry
+    H, W, g, D, gs = a.height, a.width, 16, 1024, 256
+    poses = synthetic.random_walk_poses(3, frames)
+    rgb, depth, _ = synthetic.make_frames(3, frames, H, W, "room", poses=poses)
+    rgb_h, depth_h = rgb.cpu().numpy(), depth.cpu().numpy()
+    tok = torch.randn(1, g * g, D, device="cuda")
+    dino = types.SimpleNamespace(forward_features=lambda x: {"x_norm_patchtokens": tok})
+    out = {"frames": frames, "tokens": f"{g}x{g}x{D}", "grid": gs}
+    t0 = time.perf_counter()
+    n_sh = 16
+    for _ in range(n_sh):
+        geometry.sample_indices_fast(H * W, 1000)
+    out["host_shuffle_ms_per_frame"] = (time.perf_counter() - t0) / n_sh * 1e3
+    for rate in (1000, 50):
+        res = {}
+        for name in ("obs2voxeltoken", "obs2voxeltoken_prefetched_sampling", "ingest_frames_batch32"):
+            tmp = tempfile.mkdtemp(prefix="bsc_exact_")
+            args = B.MemoryArgs(width=W, height=H, grid_size=gs, cell_size=0.1, floor_height=-12.8, map_height=12.8,
+                                depth_sample_rate=rate, query_width=224, query_height=224, memory_path=tmp, scene_name="bench",
+                                token_dim=D)
+            mem = B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False, feature_mode="exact", voxel_capacity=400_000,
+                                     token_capacity=4_000_000, max_points=32 * ((H * W + rate - 1) // rate) + 64)
+            np.random.seed(0); random.seed(0)
+            w = 8
+            torch.cuda.synchronize()
+            if name.startswith("obs2voxeltoken"):
+                def loop(lo, hi):
+                    for f in range(lo, hi):
+                        mem.obs2voxeltoken({"rgb": rgb_h[f], "depth": depth_h[f]}, poses[f])
+                if name.endswith("prefetched_sampling"):
+                    with mem.prefetched_sampling(H * W):
+                        loop(0, w)
+                        mem.engine.sync(); torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        loop(w, frames)
+                        mem.engine.sync(); torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                else:
+                    loop(0, w)
+                    mem.engine.sync(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    loop(w, frames)
+                    mem.engine.sync(); torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                n = frames - w
+            else:
+                toks = tok.view(1, g, g, D).expand(32, g, g, D).contiguous()
+                with mem.prefetched_sampling(H * W, depth=40):
+                    mem.ingest_frames(rgb[:32], depth[:32], poses[:32], tokens=toks)
+                    mem.engine.sync(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for lo in range(32, frames - 31, 32):
+                        mem.ingest_frames(rgb[lo:lo + 32], depth[lo:lo + 32], poses[lo:lo + 32], tokens=toks)
+                    mem.engine.sync(); torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                n = (frames - 32) // 32 * 32
+            k = mem.engine.counters()
+            res[name] = {"frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "voxels": k["max_id"], "store_tokens": k["store_tokens"],
+                         "flushes": k["flushes"]}
+            mem.engine.close()
+        res["host_shuffle_share_frame_by_frame"] = out["host_shuffle_ms_per_frame"] / res["obs2voxeltoken"]["ms_per_frame"]
+        out[f"depth_sample_rate_{rate}"] = res
+    out["note"] = ("frame by frame: host numpy frames -> H2D copies, host-side pose chain + NumPy-stream Fisher-Yates over all "
+                   f"{H * W} pixels (bsc_host_shuffled_sample) + host alpha, then one bsc_ingest call per frame; "
+                   "prefetched_sampling draws the shuffle of frame f+1 on a host thread under the work of frame f (the stream "
+                   "stays sequential); the reference's own loop runs ~8.5 frames/s at rate 1000 (BASELINE.md)")
+    return out
 
 
 def localize_store_leg(B, a, local_rank, D=1024, V=1 << 20, gL=512):
@@ -564,7 +678,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         times.append(dt)
-        if world == 1:
+        if rank == 0:
             stage_timed = p.stage_ms()
             c1 = p.eng.counters()
     dt = statistics.median(times)
@@ -582,28 +696,62 @@ def main():
             "repeats": len(times), "seconds_per_repeat": times, "timed_seconds_total": sum(times),
             "config": {"workload": f"{a.batch * a.steps} synthetic {p.W}x{p.H} RGB-D frames per GPU ({a.kind} depth, every "
                                    f"pixel), {a.arch} random weights {D}-D tokens {g}x{g}, {a.grid}^3 grid of 0.1 m cells, "
-                                   f"dense {a.mode} reduce" + (", + RCCL reduce-scatter merge" if world > 1 else ""),
+                                   f"dense {a.mode} reduce" + ((", + RCCL reduce-scatter merge" if backend == "nccl" else
+                                                                f", + {backend} reduce-scatter merge (RCCL stand-in on a box without {world} GPUs)")
+                                                               if world > 1 else ""),
                        "frames_per_step": a.batch, "parallelism": f"frames sharded x{world}"},
         }
         if merge_info:
             out["config"]["merge"] = merge_info
-    if rank == 0 and world == 1:
+    def guarded(key, fn, into=None):
+        """an optional leg: its result under `key`, or {"error": ...} — never the loss of the headline line"""
+        tgt = out if into is None else into
+        try:
+            r = fn()
+            if key is None:
+                tgt.update(r)
+            else:
+                tgt[key] = r
+        except Exception as e:           # noqa: BLE001
+            import traceback
+            tgt[key or "error"] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc(limit=2).splitlines()[-2].strip()}
+            try:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+
+    if rank == 0:
+        # the bsc_ingest call of THIS rank priced per SURVEY.md §8(d); at N > 1 the in-pipeline stage times of rank 0 (the
+        # isolated wall figure needs the chip to itself and is measured at N = 1 only)
         U = (c1["voxel_rmw"] - c0["voxel_rmw"]) / a.steps           # voxel rows touched per call
-        iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8))
         alg = ingest_alg_bytes(a.batch, N, g, D, tok_bytes, U)
+        if world > 1:
+            ing_ms = stage_timed["bsc_ingest"]
+            out["roofline"] = {"bound": "hbm", "kernel": "bsc_ingest of rank 0 (main-stream HIP-event time inside the pipeline; per rank)",
+                               "achieved": alg / ing_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
+                               "traffic": None, "bytes_per_call": alg, "ms_per_call": ing_ms, "voxel_rows_per_call": U,
+                               "stage_ms_in_pipeline": stage_timed}
+            if merge_info and merge_info.get("seconds_inside_timed_region"):
+                mb = merge_info.get("per_rank", 0) * (D * 4 + 4) * (world - 1)      # rows each rank sends in the reduce-scatter
+                merge_info["reduce_scatter_bytes_sent_per_rank"] = mb
+                merge_info["merge_GBs_per_rank"] = mb / merge_info["seconds_inside_timed_region"] / 1e9
+    if rank == 0 and world == 1:
+        iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8))
         ing_ms = stage_timed["bsc_ingest"]
         single = {k: v for k, v in stage_timed.items() if k in ("k_points", "k_keys_pairs", "k_dense_reduce")}
         dom = max(single, key=single.get)
         traffic, traffic_commit = pmc_traffic()
+        wall = iso["ingest_wall_ms"]
         out["roofline"] = {
-            "bound": "hbm", "kernel": "bsc_ingest: the main-stream kernels of one call (SURVEY.md 8d bytes of the batch); the per-voxel point order and the rgb chain "
-                                     "run on the library's side stream beside them and beside the next encoder pass: *_wall_* keys price the call with both",
-            "achieved": alg / ing_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": None if traffic is None else f"profiles/r03_pmc_ingest_kernels.json @ {traffic_commit}",
-            "bytes_per_call": alg, "ms_per_call": ing_ms, "ms_per_call_isolated": iso["stages"]["bsc_ingest"],
-            "frac_isolated": alg / iso["stages"]["bsc_ingest"] / 1e6 / HBM_PEAK_GBS,
-            "ms_per_call_wall_isolated": iso["ingest_wall_ms"],      # the call + bsc_sync alone: main stream, order pipeline and rgb chain (side stream)
-            "frac_wall_isolated": alg / iso["ingest_wall_ms"] / 1e6 / HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "bsc_ingest: one call followed by bsc_sync, alone on the chip — main-stream kernels, the per-voxel point "
+                                     "order and the rgb chain on the library's side stream (SURVEY.md 8d bytes of the batch / that wall time)",
+            "achieved": alg / wall / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / wall / 1e6 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_measured_in_this_run": False,
+            "traffic_source": None if traffic is None else f"profiles/{PMC_FILE} @ {traffic_commit} (rocprofv3 --pmc passes of this command, committed)",
+            "bytes_per_call": alg, "ms_per_call": wall,
+            "ms_per_call_main_stream_isolated": iso["stages"]["bsc_ingest"], "frac_main_stream_isolated": alg / iso["stages"]["bsc_ingest"] / 1e6 / HBM_PEAK_GBS,
+            "ms_per_call_main_stream_in_pipeline": ing_ms, "frac_main_stream_in_pipeline": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
             "voxel_rows_per_call": U, "points_per_call": (c1["points_passed"] - c0["points_passed"]) / a.steps,
             "pairs_per_call": (c1["pairs"] - c0["pairs"]) / a.steps, "U_over_P": U / max(1.0, a.batch * N),
             "dominant_kernel": dom, "dominant_kernel_ms": single[dom], "stage_ms_in_pipeline": stage_timed,
@@ -620,18 +768,22 @@ def main():
                          "voxels": c1["max_id"]}
         out["memory_path_frames_per_s"] = a.batch / (iso["ingest_wall_ms"] * 1e-3)     # bsc_ingest + its rgb chain alone, f32 tokens or bf16 as timed
         if not a.no_f32:
-            out.update(reference_precision_leg(a, p, local_rank))
+            guarded(None, lambda: reference_precision_leg(a, p, local_rank))
         # ---- CPU baseline on the same frames (before they are freed) ----
         if not a.no_cpu_baseline:
-            one, allc = cpu_baseline(a, p, a.cpu_seconds)
-            out["cpu_baseline"] = one
-            out["cpu_baseline_all_cores"] = allc
+            def cpu_leg():
+                one, allc = cpu_baseline(a, p, a.cpu_seconds)
+                return {"cpu_baseline": one, "cpu_baseline_all_cores": allc}
+            guarded(None, cpu_leg)
+            if "cpu_baseline" not in out:
+                out["cpu_baseline"] = out.pop("error", {"error": "cpu baseline failed"})
         vit = p.vit
         p.close()
         # ---- the same pipeline on the other depth distributions, and BASELINE configs[2] per GPU ----
         if not a.no_workloads:
             out["workloads"] = {"room": {"frames_per_s": out["value"], "voxels": out["stages"]["voxels"], "U_over_P": out["roofline"]["U_over_P"],
-                                         "ingest_ms_per_step": out["roofline"]["ms_per_call"], "frac_of_hbm_bound": out["roofline"]["frac"]}}
+                                         "ingest_ms_per_step": out["roofline"]["ms_per_call_main_stream_in_pipeline"],
+                                         "frac_of_hbm_bound": out["roofline"]["frac_main_stream_in_pipeline"]}}
             # as many steps as the headline where the map keeps growing over the run (a short run is mostly start-up: every
             # voxel new), half of them for the one-voxel-per-point stress case.  "cold": the timed steps follow two warm-up
             # steps on an empty map (new voxels all along the run); "warm": the same frames again over the map the cold pass
@@ -664,32 +816,45 @@ def main():
                         "ingest_ms_per_step": st["bsc_ingest"], "bytes_per_call": algk,
                         "frac_of_hbm_bound": algk / st["bsc_ingest"] / 1e6 / HBM_PEAK_GBS, "stage_ms": st}
 
-            for kind, steps in (("hall", a.steps), ("iid", max(4, a.steps // 2)), ("room_off", a.steps)):
+            def kind_leg(kind, steps):
                 q = Pipeline(a, kind, a.arch, a.grid, a.batch, steps + 2, rank, local_rank, vit=vit)
-                out["workloads"][kind] = workload(q, steps, reps=3 if kind != "iid" else 2)
-                q.close()
+                try:
+                    return workload(q, steps, reps=3 if kind != "iid" else 2)
+                finally:
+                    q.close()
+
+            for kind, steps in (("hall", a.steps), ("iid", max(4, a.steps // 2)), ("room_off", a.steps)):
+                guarded(kind, lambda: kind_leg(kind, steps), into=out["workloads"])
+
             # configs[2] (C3) per GPU: ViT-L/14 tokens (16x16x1024) into a 512^3 grid, as many steps as the headline
-            a3 = argparse.Namespace(**vars(a))
-            b3, s3 = 128, max(a.steps, 8)
-            q = Pipeline(a3, "hall", "vit_l14", 512, b3, s3 + 2, rank, local_rank, vcap=3_000_000)
-            w3 = workload(q, s3)
-            iso3 = q.isolated(2, min(s3 + 2, 10))
-            tf3 = q.vit.flops_per_frame() * b3 / (iso3["encoder_ms"] * 1e-3) / 1e12
-            out["configs"] = {"C3_vit_l14_1024d_grid512_per_gpu": {
-                "frames_per_s": w3["frames_per_s_warm"], "frames_per_s_cold": w3["frames_per_s_cold"],
-                "frames_per_s_warm": w3["frames_per_s_warm"], "frames_per_step": b3, "steps": s3, "repeats": w3["repeats"],
-                "encoder_ms_per_step": iso3["encoder_ms"], "ingest_ms_per_step": iso3["stages"]["bsc_ingest"],
-                "memory_path_frames_per_s": b3 / (iso3["ingest_wall_ms"] * 1e-3), "encoder_tflops": tf3,
-                "encoder_frac_of_bf16_mfma_peak": tf3 / MFMA_BF16_PEAK_TF, "voxels": w3["voxels"], "depth": "hall"}}
-            q.close()
+            def c3_leg():
+                a3 = argparse.Namespace(**vars(a))
+                b3, s3 = 128, max(a.steps, 8)
+                q = Pipeline(a3, "hall", "vit_l14", 512, b3, s3 + 2, rank, local_rank, vcap=3_000_000)
+                try:
+                    w3 = workload(q, s3)
+                    iso3 = q.isolated(2, min(s3 + 2, 10))
+                    tf3 = q.vit.flops_per_frame() * b3 / (iso3["encoder_ms"] * 1e-3) / 1e12
+                    return {"frames_per_s": w3["frames_per_s_cold"], "frames_per_s_cold": w3["frames_per_s_cold"],
+                            "frames_per_s_warm": w3["frames_per_s_warm"], "frames_per_step": b3, "steps": s3, "repeats": w3["repeats"],
+                            "encoder_ms_per_step": iso3["encoder_ms"], "ingest_ms_per_step": iso3["stages"]["bsc_ingest"],
+                            "memory_path_frames_per_s": b3 / (iso3["ingest_wall_ms"] * 1e-3), "encoder_tflops": tf3,
+                            "encoder_frac_of_bf16_mfma_peak": tf3 / MFMA_BF16_PEAK_TF, "voxels": w3["voxels"], "depth": "hall"}
+                finally:
+                    q.close()
+            out.setdefault("configs", {})
+            guarded("C3_vit_l14_1024d_grid512_per_gpu", c3_leg, into=out["configs"])
         del vit
         torch.cuda.empty_cache()
+        if not a.no_exact:
+            guarded("exact_mode", lambda: exact_mode_leg(a, local_rank))
         if not a.no_localize:
             # second half of the metric: localize top-K latency over a 2^20-voxel map (BASELINE configs[3]/[4] size)
-            out["localize"] = localize_leg(B, a, local_rank, D)
+            guarded("localize", lambda: localize_leg(B, a, local_rank, D))
+            out.setdefault("configs", {})
             if D != 1024:
-                out.setdefault("configs", {})["C4_C5_localize_2pow20_x_1024_grid512"] = localize_leg(B, a, local_rank, 1024)
-            out.setdefault("configs", {})["C4_store_shape_2pow20_voxels_M_1to10_x_1024"] = localize_store_leg(B, a, local_rank)
+                guarded("C4_C5_localize_2pow20_x_1024_grid512", lambda: localize_leg(B, a, local_rank, 1024), into=out["configs"])
+            guarded("C4_store_shape_2pow20_voxels_M_1to10_x_1024", lambda: localize_store_leg(B, a, local_rank), into=out["configs"])
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -100,3 +100,68 @@ def sample_indices_fast(n_pixels, rate):
                                                     scratch.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
     np.random.set_state((st[0], key, pos.value, st[3], st[4]))
     return out
+
+
+class SamplePrefetcher:
+    """The reference's per-frame shuffled sub-sampling (memory_2.py:747-749), drawn AHEAD of its use by a host thread.
+
+    The permutation of frame f + 1 does not depend on frame f's data — only on the position of NumPy's global MT19937 stream —
+    so a worker thread draws the index arrays one after the other from a private copy of the stream (bsc_host_shuffled_sample
+    releases the GIL) while the GPU works on the current frame.  `next()` hands them out in order; `close()` puts the global
+    stream where the reference would have left it after the frames actually consumed.  Valid while nothing else draws from
+    np.random between the frames (the dataset loop, ingest_frames)."""
+
+    def __init__(self, n_pixels, rate, depth=4):
+        import ctypes as C
+        import queue
+        import threading
+        from . import _lib
+        st = np.random.get_state()
+        self._fallback = st[0] != "MT19937"
+        self.n_pixels, self.rate = int(n_pixels), int(rate)
+        self._tail = st
+        if self._fallback:
+            return
+        self._lib, self._C = _lib.load(), C
+        self._check = _lib.check
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._stop = False
+        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        self._pos = C.c_int32(int(st[2]))
+        self._rest = (st[3], st[4])
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        C = self._C
+        scratch = np.empty(self.n_pixels, np.int32)
+        while not self._stop:
+            out = np.empty((self.n_pixels + self.rate - 1) // self.rate, np.int32)
+            self._check(self._lib.bsc_host_shuffled_sample(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos), self.n_pixels,
+                                                           self.rate, scratch.ctypes.data_as(C.c_void_p),
+                                                           out.ctypes.data_as(C.c_void_p)))
+            item = (out, ("MT19937", self._key.copy(), self._pos.value) + self._rest)
+            while not self._stop:
+                try:
+                    self._q.put(item, timeout=0.05)
+                    break
+                except Exception:
+                    pass
+
+    def next(self):
+        if self._fallback:
+            return sample_indices(self.n_pixels, self.rate)
+        idx, state = self._q.get()
+        self._tail = state
+        return idx
+
+    def close(self):
+        if not self._fallback:
+            self._stop = True
+            while self._thread.is_alive():          # unblock a producer waiting on the full queue
+                try:
+                    self._q.get_nowait()
+                except Exception:
+                    pass
+                self._thread.join(timeout=0.01)
+            np.random.set_state(self._tail)

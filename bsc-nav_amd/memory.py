@@ -241,7 +241,7 @@ class VoxelTokenMemory:
         rgb = np.ascontiguousarray(np.array(obs["rgb"])[:, :, :3])
         depth = np.ascontiguousarray(np.array(obs["depth"]), dtype=np.float32)
         patch_tokens = self._get_patch_token(rgb).float().contiguous()
-        idx = sample_indices(depth.size, self.depth_sample_rate)              # global NumPy RNG, as the reference
+        idx = self._next_sample(depth.size)                                   # global NumPy RNG, as the reference
         alpha = None
         if self.alpha_source == "host":
             with np.errstate(all="ignore"):
@@ -250,6 +250,29 @@ class VoxelTokenMemory:
                            torch.from_numpy(rgb).to(self.device).unsqueeze(0), patch_tokens.unsqueeze(0), T[None],
                            torch.from_numpy(idx).to(self.device), np.array([0, len(idx)], np.int64), alpha)
         self._touch()
+
+    def _next_sample(self, n_pixels):
+        pf = getattr(self, "_prefetcher", None)
+        if pf is not None and pf.n_pixels == n_pixels and pf.rate == self.depth_sample_rate:
+            return pf.next()
+        return sample_indices(n_pixels, self.depth_sample_rate)
+
+    def prefetched_sampling(self, n_pixels=None, depth=4):
+        """Context manager: while it is open, the shuffled sub-sampling of the coming frames is drawn ahead on a host thread
+        (geometry.SamplePrefetcher) — same permutations, same final state of np.random's stream, the ~1 ms Fisher-Yates of
+        frame f + 1 under the GPU work of frame f.  For loops that own np.random between frames (the dataset loop)."""
+        import contextlib
+        from .geometry import SamplePrefetcher
+
+        @contextlib.contextmanager
+        def ctx():
+            self._prefetcher = SamplePrefetcher(n_pixels or self.cfg.height * self.cfg.width, self.depth_sample_rate, depth)
+            try:
+                yield self
+            finally:
+                pf, self._prefetcher = self._prefetcher, None
+                pf.close()
+        return ctx()
 
     def ingest_frames(self, rgb, depth, poses, tokens=None):
         """Batched ingest (new): rgb (F,H,W,C) u8, depth (F,H,W) f32 device tensors, poses (F,7).
@@ -265,7 +288,7 @@ class VoxelTokenMemory:
             self.engine.ingest(depth, rgb, tokens, Ts)
             return
         N = depth.shape[1] * depth.shape[2]
-        idxs = [sample_indices(N, self.depth_sample_rate) for _ in range(F)]
+        idxs = [self._next_sample(N) for _ in range(F)]
         off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])]).astype(np.int64)
         alpha = None
         if host_alpha:          # same setting as obs2voxeltoken: rgb bytes / weights bit-exact (one D2H copy of the depth)

@@ -101,3 +101,34 @@ def test_host_choice_draws_match_python_random():
         random.setstate((version, tuple(key.tolist()) + (pos.value,), gauss))
         assert out.tolist() == want, (seed, k, n)
         assert [random.random() for _ in range(3)] == tail
+
+
+def test_sample_prefetcher_keeps_the_reference_stream():
+    """geometry.SamplePrefetcher: the host thread that draws the shuffles of coming frames ahead hands out exactly the arrays
+    the sequential calls would have, and close() leaves np.random's stream where they would have left it — however far the
+    thread had run ahead."""
+    import time
+    import numpy as np
+    from bsc_nav_amd import geometry as G
+    n, rate = 4801, 13
+    np.random.seed(11)
+    want = [G.sample_indices(n, rate) for _ in range(9)]
+    tail = np.random.randint(0, 1 << 30, 4)
+    np.random.seed(11)
+    pf = G.SamplePrefetcher(n, rate, depth=3)
+    got = [pf.next() for _ in range(5)]
+    time.sleep(0.05)                         # let the worker fill its queue past what is consumed
+    got += [pf.next() for _ in range(4)]
+    pf.close()
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail)
+    pf2 = G.SamplePrefetcher(n, rate)        # opened and closed without a draw: the stream does not move
+    pf2.close()
+    np.random.seed(11)
+    G.sample_indices(n, rate)
+    s1 = np.random.get_state()[2]
+    np.random.seed(11)
+    pf3 = G.SamplePrefetcher(n, rate)
+    pf3.next()
+    pf3.close()
+    assert np.random.get_state()[2] == s1
