@@ -349,7 +349,7 @@ def exact_mode_leg(a, local_rank, frames=192):
                                 depth_sample_rate=rate, query_width=224, query_height=224, memory_path=tmp, scene_name="bench",
                                 token_dim=D)
             mem = B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False, feature_mode="exact", voxel_capacity=400_000,
-                                     token_capacity=4_000_000, max_points=32 * ((H * W + rate - 1) // rate) + 64)
+                                     token_capacity=4_000_000, max_frames_per_call=32)
             np.random.seed(0); random.seed(0)
             w = 8
             torch.cuda.synchronize()
