@@ -4,6 +4,9 @@ The reference loops over habitat episodes, derives a memory directory per scene 
 directory exists (load instead of build) and otherwise explores the scene with the simulator.  The simulator
 is out of scope here; the same call order runs over any `FrameSource`:
     initial_memory() -> per frame obs2voxeltoken / ingest_frames -> final flush -> save.
+`EnvExplorer` is the frame source for callers that DO hold a simulator: it turns an injected NavEnv-like collaborator
+(env.py:49: sims / agent / plnner.pathfinder / move2point) into the stream of (observation, pose) events that
+VoxelTokenMemory.excute / exploring_create_memory / explore_entire_space consume (memory_2.py:1086-1145, 1347-1391).
 """
 import os
 
@@ -11,6 +14,52 @@ import numpy as np
 
 from . import synthetic
 from .memory import VoxelTokenMemory
+
+
+class EnvExplorer:
+    """Event stream over an injected simulator.  Events: ("frame", obs, pose7) after every executed action, ("height", y)
+    after a goal is reached (memory_2.py:1122 base_height), ("skipped", exception) for a goal whose move failed (the
+    reference swallows those, memory_2.py:1126-1128)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.last_obs = None
+
+    def pose(self):
+        st = self.env.agent.get_state()
+        p, q = st.position, st.rotation
+        return np.array([p[0], p[1], p[2], q.x, q.y, q.z, q.w], dtype=np.float64)
+
+    def frames(self, actions):
+        """step the simulator through `actions` ("stop" entries are no-ops, memory_2.py:1088)"""
+        for action in actions:
+            if action == "stop":
+                continue
+            self.last_obs = self.env.sims.step(action)
+            yield "frame", self.last_obs, self.pose()
+
+    def random_goal(self):
+        """a random navigable point on the agent's own island (memory_2.py:1112-1118)"""
+        pf = self.env.plnner.pathfinder
+        here = pf.get_island(self.env.agent.get_state().position)
+        while True:
+            goal = pf.get_random_navigable_point()
+            if pf.is_navigable(goal) and pf.get_island(goal) == here:
+                return goal
+
+    def sweep(self, turn_deg):
+        return ["turn_left"] * int(360 / turn_deg)
+
+    def tour(self, n_goals, turn_deg):
+        """n_goals x (walk to a random goal, then look around once)"""
+        for _ in range(int(n_goals)):
+            try:
+                path, _goal = self.env.move2point(self.random_goal())
+                yield from self.frames(path)
+                yield "height", float(self.env.agent.get_state().position[1])
+                yield from self.frames(self.sweep(turn_deg))
+            except Exception as e:      # noqa: BLE001 — a failed move costs its goal, not the build
+                yield "skipped", e
 
 
 class SyntheticScene:

@@ -516,15 +516,65 @@ class VoxelTokenMemory:
             final.extend(kept)
         self.long_memory_dict = final
 
-    def create_memory(self):
-        raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop over the simulator "
-                                  "(out of scope, SURVEY.md §2 #9); feed frames through obs2voxeltoken() / ingest_frames() "
-                                  "or use dataset.create_memory_for_dataset()")
+    # ---- simulator-driven builds (memory_2.py:1086-1145): thin consumers of dataset.EnvExplorer's event stream ------------
+    def _consume(self, events):
+        """frames into the memory (+ the detector's long-term memory), goal heights into base_height"""
+        for ev in events:
+            if ev[0] == "frame":
+                self.obs2voxeltoken(ev[1], ev[2])
+                self.long_memory(ev[1])
+            elif ev[0] == "height":
+                self.base_height.append(ev[1])
+            elif ev[0] == "skipped":
+                self._log(f"move failed: {ev[1]}")
+
+    def _explorer(self):
+        if self.Env is None:
+            raise RuntimeError("this call drives a simulator: construct VoxelTokenMemory(..., env=<NavEnv-like object>), or feed "
+                               "frames through obs2voxeltoken() / ingest_frames() / dataset.create_memory_for_dataset()")
+        from .dataset import EnvExplorer
+        return EnvExplorer(self.Env)
+
+    def excute(self, obs, actions):
+        """memory_2.py:1086-1101 (the reference's spelling): step the simulator, ingest every frame -> last observation."""
+        ex = self._explorer()
+        ex.last_obs = obs
+        self._consume(ex.frames(actions))
+        return ex.last_obs
 
     def exploring_create_memory(self):
-        raise NotImplementedError("simulator-driven exploration (memory_2.py:1104-1145) is out of scope (SURVEY.md §2 #9); "
-                                  "dataset.create_memory_for_dataset() runs the same call order over a frame source")
+        """memory_2.py:1104-1145: random goals with a 360 degree sweep at each, final flush of the token cache, save."""
+        ex = self._explorer()
+        self.initial_memory()
+        self.init_height = self.Env.agent.get_state().position[1]
+        with self.prefetched_sampling():
+            self._consume(ex.tour(self.cfg.random_move_num, self.cfg.turn_left))
+        if self.feature_mode == "exact":
+            self.update_memory_dist_base()
+        self.save_memory()
 
+    def create_memory(self):
+        raise NotImplementedError("keyboard-driven exploration (memory_2.py:1027-1083) is a UI loop over the simulator's viewer "
+                                  "(out of scope, SURVEY.md §2 #9); use exploring_create_memory() with an injected env, or feed "
+                                  "frames through obs2voxeltoken() / ingest_frames() / dataset.create_memory_for_dataset()")
+
+    def explore_entire_space(self, max_iterations=30):
+        """memory_2.py:1347-1391: look around, find the frontier clusters of the top-down map (frontier.hip), walk to the most
+        informative one, repeat."""
+        ex = self._explorer()
+        self.min_cluster_size, self.ig_radius = 10, 5
+        self.initial_memory()
+        for _ in range(max_iterations):
+            self._consume(ex.frames(ex.sweep(self.cfg.turn_left)))
+            navigable = self.build_navigable_mask()
+            frontiers = self.find_frontiers(navigable)
+            clusters = self.cluster_frontiers(frontiers) if frontiers else []
+            target = self.select_best_cluster_center_by_ig(clusters) if clusters else None
+            if target is None:
+                break
+            self.update_frontier_map(frontiers, clusters, target, navigable)
+            path, _goal = self.Env.move2point(self.Env.get_random_navigable_point_near(self.grid2loc_2d(target[0], target[1])))
+            self._consume(ex.frames(path))
 
     # ---- FrontierExplorer (memory_2.py:1147-1418) -----------------------------------------------------------------
     # The per-cell Python loops of the reference run as HIP kernels over the resident top-down map

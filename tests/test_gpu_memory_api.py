@@ -605,3 +605,95 @@ def test_ingest_frames_with_a_forward_features_only_encoder(tmp_path):
     acc, cnt = mem.engine.export_dense()
     assert mem.max_id > 100 and np.isfinite(acc).all() and int(cnt.sum()) == mem.engine.counters()["points_passed"]
     np.testing.assert_allclose(acc[:, 3:] / cnt[:, None], 1.0, rtol=1e-5)
+
+
+class _FakeEnv:
+    """The slice of NavEnv (env.py:49-296) the memory-building loops touch, over the seeded synthetic room."""
+
+    def __init__(self, H, W, seed=0):
+        import synth
+        self.H, self.W, self.rs = H, W, np.random.RandomState(seed)
+        self.pos, self.k = np.zeros(3), 0
+        self._synth = synth
+        env = self
+
+        class _Sims:
+            def get_sensor_observations(self, _):
+                return env._obs()
+
+            def step(self, action):
+                if action == "move_forward":
+                    th = env.k * np.pi / 6
+                    nxt = env.pos + np.array([-np.sin(th), 0.0, -np.cos(th)]) * 0.25
+                    if np.all(np.abs(nxt[[0, 2]]) < [3.3, 2.3]):
+                        env.pos = nxt
+                elif action == "turn_left":
+                    env.k += 1
+                elif action == "turn_right":
+                    env.k -= 1
+                return env._obs()
+
+        class _Agent:
+            def get_state(self):
+                th = env.k * np.pi / 6
+                return types.SimpleNamespace(position=env.pos.copy(),
+                                             rotation=types.SimpleNamespace(x=0.0, y=np.sin(th / 2), z=0.0, w=np.cos(th / 2)))
+
+        class _Pathfinder:
+            def get_random_navigable_point(self):
+                return np.array([env.rs.uniform(-3, 3), 0.0, env.rs.uniform(-2, 2)])
+
+            def get_island(self, p):
+                return 0
+
+            def is_navigable(self, p):
+                return bool(abs(p[0]) < 3.4 and abs(p[2]) < 2.4)
+
+        self.sims, self.agent = _Sims(), _Agent()
+        self.plnner = types.SimpleNamespace(pathfinder=_Pathfinder())
+        self.original_state = types.SimpleNamespace(position=np.zeros(3, np.float32))
+        self.resets = 0
+
+    def _obs(self):
+        th = self.k * np.pi / 6
+        pose = np.array([*self.pos, 0.0, np.sin(th / 2), 0.0, np.cos(th / 2)])
+        d = self._synth._room_depth(self.H, self.W, pose).astype(np.float32)
+        rgb = self.rs.randint(0, 255, size=(self.H, self.W, 4)).astype(np.uint8)
+        return {"rgb": rgb, "depth": d}
+
+    def reset(self, args, init_state=None, build_map=False):
+        self.resets += 1
+
+    def move2point(self, goal):
+        return ["move_forward"] * 3 + ["turn_left"], goal
+
+    def get_random_navigable_point_near(self, p):
+        return np.asarray(p)
+
+
+def test_simulator_driven_loops_over_a_fake_env(tmp_path):
+    """excute / exploring_create_memory / explore_entire_space (memory_2.py:1086-1145, :1347-1391) driven by a stand-in
+    for NavEnv: the call order of the reference (initial_memory -> steps with obs2voxeltoken -> final flush -> save) produces
+    a memory directory in the reference layout; the frontier loop runs on the resident top-down map."""
+    import bsc_nav_amd as B
+    H, W, g, D = 48, 64, 4, 16
+    args = B.MemoryArgs(width=W, height=H, grid_size=128, floor_height=-6.4, map_height=6.4, depth_sample_rate=5,
+                        query_width=g * 14, query_height=g * 14, token_dim=D, memory_path=str(tmp_path), scene_name="sim",
+                        random_move_num=2, turn_left=90)
+    tok = np.random.RandomState(1).standard_normal((1, g, g, D)).astype(np.float32)
+    dino = FakeDino(tok)
+    env = _FakeEnv(H, W)
+    mem = B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False, env=env)
+    np.random.seed(0); random.seed(0)
+    mem.exploring_create_memory()
+    d = mem.memory_save_path
+    n = int(np.load(d + "/max_id.npy"))
+    assert n > 100 and len(np.load(d + "/base_height.npy")) == 2 and os.path.exists(d + "/feat_features.npy")
+    assert np.load(d + "/grid_rgb_pos.npy").shape == (n, 3) and mem.iter_id == 0          # final flush emptied the cache
+    steps = 2 * (4 + 4)                                                                    # 2 goals x (path of 4 + 360 sweep of 4)
+    assert mem.engine.counters()["points_seen"] == steps * len(range(0, H * W, 5))
+    # the frontier exploration loop on the top-down map the ingest maintains
+    mem2 = B.VoxelTokenMemory(args, preload_dino=dino, need_diffusion=False, env=_FakeEnv(H, W, seed=3), memory_path=str(tmp_path / "sim2"))
+    mem2.explore_entire_space(max_iterations=2)
+    assert mem2.max_id > 100 and (mem2.cv_map.sum(-1) != 0).sum() > 50
+    assert hasattr(mem2, "FrontierMap") or mem2.find_frontiers(mem2.build_navigable_mask()) == []
