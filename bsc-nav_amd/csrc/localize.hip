@@ -304,7 +304,11 @@ __global__ __launch_bounds__(TPB) void k_split_q(const float *__restrict__ qn, i
 
 // WV wavefronts per workgroup, 32 rows each: WV = 8 puts two wavefronts on every SIMD (256 registers each) that share one staged
 // query chunk — one covers the other's LDS / global / barrier waits
-template <int NT, int WV>
+// SIX: all six products of weight >= 2^-16 (hh, hm, mh, hl, mm, lh: 2^-24 per product, what an f32 multiply rounds away); otherwise
+// the three of weight >= 2^-8 (hh, hm, mh): 2^-16 per product term, ~4e-7 on the cosine of unit vectors after the 1/sqrt(D)
+// averaging of D independent terms — inside the 2e-6 the tests hold the scan to and 2 500x inside the north star's 1e-3 —
+// at half the matrix work and without the l plane of the queries.
+template <int NT, int WV, bool SIX>
 __global__ __launch_bounds__(64 * WV) void k_cosine_bf16x3(const float *__restrict__ X, int64_t n_rows, int D,
                                                        const uint16_t *__restrict__ qp, int64_t q_plane, int q0, int q_valid,
                                                        float *__restrict__ sims, int64_t sims_stride)
@@ -378,20 +382,26 @@ __global__ __launch_bounds__(64 * WV) void k_cosine_bf16x3(const float *__restri
             // one piece of the queries at a time (NT fragments live instead of 3 NT): l is used once, m twice, h three times;
             // smallest terms first; consecutive MFMAs go to different accumulators
             bf16x8_t af[NT];
+            if (SIX) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (2 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+                for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (2 * QROWS + t * 32) * BX_PITCH + sstep * 8);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (1 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+            if (SIX) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xm, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xm, acc[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xh, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) af[t] = *(const bf16x8_t *)(qb + (0 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+            if (SIX) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xl, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xl, acc[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], xm, acc[t], 0, 0, 0);
 #pragma unroll
@@ -729,8 +739,14 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
                                       u64 **win_keys, uint32_t **win_vals, int64_t *win_stride, bool *filtered)
 {
     const int64_t nb1 = ((int64_t)ca.n_cand + TK_N - 1) / TK_N;
-    const bool use_filter = allow_filter && nb1 > 4 * SEL_SAMPLE_BLOCKS;
-    const int64_t nbs = use_filter ? SEL_SAMPLE_BLOCKS : nb1;
+    // the K-th best of a sample of nbs blocks lets about K nb1 / nbs candidates through the filter: enough sample blocks that this
+    // stays at a quarter of the survivor lists (K = 100 over 2^20 candidates: 16 blocks, 6 400 survivors; K = 512: 64 blocks;
+    // 3 M candidates, K = 100: 36 blocks) — with the fixed 16 of round 3 every K > ~180 overflowed the lists on every call and
+    // paid the sample, the filter AND the unfiltered fallback
+    int64_t nbs_want = (4 * (int64_t)K * nb1 + SEL_SURVIVOR_CAP - 1) / SEL_SURVIVOR_CAP;
+    if (nbs_want < SEL_SAMPLE_BLOCKS) nbs_want = SEL_SAMPLE_BLOCKS;
+    const bool use_filter = allow_filter && nb1 > 4 * nbs_want;
+    const int64_t nbs = use_filter ? nbs_want : nb1;
     int64_t stride = nbs * K;
     if (use_filter && stride < SEL_SURVIVOR_CAP) stride = SEL_SURVIVOR_CAP;
     BSC_TRY(grow_dev((void **)&x->l_sel_key[0], &x->l_sel_cap[0], sizeof(u64) * stride * nq));
@@ -836,6 +852,10 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         // 64 queries -> bf16 pieces at f32 accuracy (k_cosine_bf16x3); up to 64 -> the f32 MFMA, HBM-bound at that size anyway
         const dim3 mgrid((unsigned)((n_rows + 127) / 128));
         static const bool f32_only = getenv("BSC_COSINE_F32") != nullptr;
+        // six piece products (f32 accuracy, the default) or BSC_COSINE_PIECES=3 (hh, hm, mh): 0.7x the scan time, scores within
+        // ~4e-6 instead of 3e-7 — enough for the north star's 1e-3, not for the 2e-6 the fp64 parity tests ask; read per call
+        const char *pcs = getenv("BSC_COSINE_PIECES");
+        const bool six = !(pcs && atoi(pcs) == 3);
         static const bool wv8 = getenv("BSC_COSINE_WV4") == nullptr;                     // A/B: 8 (default) or 4 wavefronts per workgroup                 // A/B: the round-2 f32 MFMA scan throughout
         const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
         if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
@@ -845,24 +865,27 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
             while (done < nq) {
                 const int left = nq - done;
                 ++passes;
+#define BX_LAUNCH2(NTV, WVV, SIXV, GRID, BLOCK)                                                                                     \
+    do {                                                                                                                            \
+        (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV, WVV, SIXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_cosine_bf16x3<NTV, WVV, SIXV>), GRID, BLOCK, lds, s, rows, n_rows, D, (const uint16_t *)x->l_qp, nel,  \
+                           done, nq, x->l_sims, sstride);                                                                           \
+    } while (0)
 #define BX_LAUNCH(NTV, ADV)                                                                                                        \
     do {                                                                                                                            \
         const size_t lds = (size_t)2 * 3 * (NTV * 32) * BX_PITCH * sizeof(uint16_t);                                               \
-        if (wv8) {                                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_cosine_bf16x3<NTV, 8>), dim3((unsigned)((n_rows + 255) / 256)), dim3(512), lds, s, rows, n_rows, D, \
-                               (const uint16_t *)x->l_qp, nel, done, nq, x->l_sims, sstride);                                       \
-        } else {                                                                                                                    \
-            (void)hipFuncSetAttribute((const void *)k_cosine_bf16x3<NTV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_cosine_bf16x3<NTV, 4>), mgrid, block, lds, s, rows, n_rows, D, (const uint16_t *)x->l_qp, nel,    \
-                               done, nq, x->l_sims, sstride);                                                                       \
-        }                                                                                                                           \
+        const dim3 g8((unsigned)((n_rows + 255) / 256)), b8(512);                                                                   \
+        if (wv8 && six) BX_LAUNCH2(NTV, 8, true, g8, b8);                                                                           \
+        else if (wv8) BX_LAUNCH2(NTV, 8, false, g8, b8);                                                                            \
+        else if (six) BX_LAUNCH2(NTV, 4, true, mgrid, block);                                                                       \
+        else BX_LAUNCH2(NTV, 4, false, mgrid, block);                                                                               \
         done += ADV;                                                                                                                \
     } while (0)
                 if (left > 128) BX_LAUNCH(8, 256);
                 else if (left > 64) BX_LAUNCH(4, 128);
                 else { --passes; break; }                    // the remainder (<= 64 queries) goes to the f32 MFMA below
 #undef BX_LAUNCH
+#undef BX_LAUNCH2
             }
         }
         while (done < nq) {
