@@ -437,5 +437,6 @@ def warmup_collectives(device, group=None):
 def shard_frames(n_frames, group=None):
     """Contiguous frame block of this rank: [start, stop)."""
     rank, world = _world(group)
-    per = (n_frames + world - 1) // world
-    return min(rank * per, n_frames), min((rank + 1) * per, n_frames)
+    base, extra = divmod(int(n_frames), world)          # balanced: the first n % world ranks take one frame more
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)

@@ -24,10 +24,10 @@ def _args(tmp, name):
                         scene_name=name)
 
 
-def _inputs():
+def _inputs(nf=F):
     import synth
-    rgb, depth, poses = synth.make_frames(41, F, H, W, "room")
-    tokens = synth.make_tokens(41, F, G, D)
+    rgb, depth, poses = synth.make_frames(41, nf, H, W, "room")
+    tokens = synth.make_tokens(41, nf, G, D)
     return rgb, depth, poses, tokens
 
 
@@ -39,7 +39,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, nf=F):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -47,16 +47,17 @@ def _worker(rank, world, port, mode, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bsc_nav_amd as B
     from bsc_nav_amd import dist as bd
-    rgb, depth, poses, tokens = _inputs()
-    mem = B.VoxelTokenMemory(_args(out_dir, "merged"), need_diffusion=False, feature_mode=mode, max_frames_per_call=F,
+    rgb, depth, poses, tokens = _inputs(nf)
+    mem = B.VoxelTokenMemory(_args(out_dir, "merged"), need_diffusion=False, feature_mode=mode, max_frames_per_call=nf,
                              voxel_capacity=100_000)
     mem.set_map_origin(poses[0])                                   # every rank writes into the scene's map frame
-    a, b = bd.shard_frames(F)
+    a, b = bd.shard_frames(nf)
     dev = lambda x: torch.from_numpy(x[a:b]).cuda().contiguous()   # noqa: E731
     mem.ingest_frames(dev(rgb), dev(depth), poses[a:b], tokens=dev(tokens))
     mem.base_height.append(float(rank))
     mem.long_memory_dict.append({"label": "chair", "loc": [10 * rank, 5, 5], "confidence": 0.5 + 0.1 * rank})
     local_voxels = mem.max_id
+    lpos, lrgb, lwgt = mem.engine.export_rgb()                     # this rank's own colour state, before the merge
     info = bd.merge_dense_maps(mem.engine)                         # rows now distributed: slice `rank` of the global order
     q = torch.from_numpy(np.random.RandomState(5).standard_normal((2, D)).astype(np.float32)).cuda()
     sp, ss = bd.localize_sharded(mem.engine, q, K=50)              # every rank scans its slice, K-way merge
@@ -68,7 +69,7 @@ def _worker(rank, world, port, mode, out_dir):
         mh, cv = mem.engine.export_heightmap()
         np.savez(f"{out_dir}/root.npz", path=np.array(mem.memory_save_path), mh=mh, cv=cv, n_union=info["n_union"])
     np.savez(f"{out_dir}/r{rank}.npz", local_voxels=local_voxels, n_local=info["n_local"], per=info["per_rank"],
-             sp0=sp[0], ss0=ss[0], sp1=sp[1], ss1=ss[1])
+             sp0=sp[0], ss0=ss[0], sp1=sp[1], ss1=ss[1], frames=b - a, lpos=lpos, lrgb=lrgb, lwgt=lwgt)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -112,6 +113,22 @@ def test_two_process_sharded_build_equals_single_process(tmp_path, mode):
     # truncating chain; voxels seen by one rank only are bit-exact, the others stay close
     drgb = np.abs(got.grid_rgb.astype(np.int32) - one.grid_rgb.astype(np.int32))
     assert (drgb == 0).mean() > 0.5 and drgb.mean() < 2.0 and np.percentile(drgb, 99) <= 16
+    # the analytic bound of the rule: every merge step is the chain's own update — a truncated convex combination of
+    # integer colours whose product c*w is rounded in f32, which can land an ulp under c and truncate to c - 1 — so the merged
+    # colour lies between (the smallest of the ranks' own colours of that voxel) - (merge steps) and the largest, channel by
+    # channel; it equals the rank's colour where only one rank saw the voxel; the weights are the sum of the ranks' weights
+    code = lambda p: (p[:, 0].astype(np.int64) << 42) | (p[:, 1].astype(np.int64) << 21) | p[:, 2].astype(np.int64)   # noqa: E731
+    gcode = code(got.grid_rgb_pos)
+    order = np.argsort(gcode)
+    lo = np.full((n, 3), 255, np.int32); hi = np.zeros((n, 3), np.int32); seen = np.zeros(n, np.int32); wsum = np.zeros(n, np.float64)
+    for r in ranks:
+        at = order[np.searchsorted(gcode[order], code(r["lpos"]))]
+        assert np.array_equal(gcode[at], code(r["lpos"]))
+        lo[at] = np.minimum(lo[at], r["lrgb"]); hi[at] = np.maximum(hi[at], r["lrgb"]); seen[at] += 1; wsum[at] += r["lwgt"]
+    g = got.grid_rgb.astype(np.int32)
+    assert (seen >= 1).all() and ((g >= lo - (seen[:, None] - 1)) & (g <= hi)).all()
+    assert (seen == 1).any() and np.array_equal(g[seen == 1], one.grid_rgb[seen == 1].astype(np.int32))
+    np.testing.assert_allclose(got.weight, wsum, rtol=2e-6)
     assert np.load(str(root["path"]) + "/base_height.npy").tolist() == [0.0, 1.0]       # rank order
     assert sorted(o["loc"][0] for o in got.long_memory_dict) == [0, 10]
     # ---- identical top-K: sharded scan (before the gather), the loaded merged memory, the single-process memory ----
@@ -122,6 +139,54 @@ def test_two_process_sharded_build_equals_single_process(tmp_path, mode):
         assert n1[qi] == n2[qi] == 50
         gu.assert_topk_near(p2[qi], s2[qi], p1[qi], s1[qi], tol=5e-6)
         for r in ranks:                                             # both ranks hold the same merged answer
+            gu.assert_topk_near(r[f"sp{qi}"], r[f"ss{qi}"], p1[qi], s1[qi], tol=5e-6)
+
+
+def test_eight_process_sharded_build_with_uneven_shards(tmp_path):
+    """The target world size: EIGHT ranks (gloo stand-in, all on the test box's one GPU) with 11 frames — shards of 2 and 1
+    frames — and a voxel union that is not a multiple of 8 (sentinel rows in the reduce-scatter layout): merge_dense_maps +
+    gather_merged_to_root + localize_sharded give the single-process memory (ids, positions, counts, top-down map bit-exact,
+    features 1e-3, the same top-K on every rank)."""
+    import torch
+    import torch.multiprocessing as mp
+    import bsc_nav_amd as B
+    world, mode = 8, "mean"
+    for nf in (11, 13, 10, 12, 14):        # a frame count whose voxel union is not a multiple of 8 (11 frames: 11 952 = 8 x 1 494)
+        rgb, depth, poses, tokens = _inputs(nf)
+        one = B.VoxelTokenMemory(_args(tmp_path, f"single8_{nf}"), need_diffusion=False, feature_mode=mode, max_frames_per_call=nf,
+                                 voxel_capacity=100_000)
+        one.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
+        n = one.max_id
+        if n % world != 0 and nf % world != 0:
+            break
+        one.engine.close()
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), nf), nprocs=world, join=True)
+    root = np.load(f"{tmp_path}/root.npz")
+    ranks = [np.load(f"{tmp_path}/r{r}.npz") for r in range(world)]
+    assert sorted(int(r["frames"]) for r in ranks) == sorted(nf // world + (1 if r < nf % world else 0) for r in range(world))
+    assert len({int(r["frames"]) for r in ranks}) == 2, "uneven shards"
+    per = int(ranks[0]["per"])
+    assert int(root["n_union"]) == n and sum(int(r["n_local"]) for r in ranks) == n
+    assert n % world != 0 and per * world > n, "the case must exercise the sentinel rows of the last slice"
+    assert all(int(r["per"]) == per for r in ranks) and [int(r["n_local"]) for r in ranks][:-1] == [per] * (world - 1)
+    args = _args(tmp_path, "loaded8")
+    args.load_memory_path = str(root["path"])
+    got = B.VoxelTokenMemory(args, need_diffusion=False, feature_mode=mode, voxel_capacity=100_000)
+    got.load_memory()
+    assert got.max_id == n
+    assert np.array_equal(got.grid_rgb_pos, one.grid_rgb_pos) and np.array_equal(got.occupied_ids, one.occupied_ids)
+    (gacc, gcnt), (oacc, ocnt) = got.engine.export_dense(), one.engine.export_dense()
+    assert np.array_equal(gcnt, ocnt)
+    c = np.maximum(ocnt, 1)[:, None].astype(np.float64)
+    np.testing.assert_allclose(gacc / c, oacc / c, rtol=1e-3, atol=1e-3)
+    omh, ocv = one.engine.export_heightmap()
+    assert np.array_equal(root["mh"], omh) and np.array_equal(root["cv"], ocv)
+    np.testing.assert_allclose(got.weight, one.weight, rtol=4e-6)
+    q = torch.from_numpy(np.random.RandomState(5).standard_normal((2, D)).astype(np.float32)).cuda()
+    p1, s1, n1 = one.engine.localize(q, K=50)
+    for qi in range(2):
+        assert n1[qi] == 50
+        for r in ranks:                                             # all eight ranks hold the same merged answer
             gu.assert_topk_near(r[f"sp{qi}"], r[f"ss{qi}"], p1[qi], s1[qi], tol=5e-6)
 
 
