@@ -92,6 +92,7 @@ struct bsc_ctx {
     int32_t *log_cell;
     PointRec *log_rec;
     int64_t log_cap, log_n;
+    bool log_stale;            // the colour state was imported / replaced while the log was on: the log no longer describes it
     // ---- per-batch scratch (max_points) ----
     int32_t *p_cell;
     uint32_t *p_patf;

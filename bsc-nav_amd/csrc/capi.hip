@@ -96,6 +96,7 @@ static bsc_status reset_state(bsc_ctx *x)
     x->order_base = 0;
     x->names_dirty = true;
     x->log_n = 0;
+    x->log_stale = false;
     return BSC_OK;
 }
 
@@ -685,6 +686,7 @@ extern "C" bsc_status bsc_import_rgb(bsc_ctx *x, int64_t max_id, const int32_t *
     if (!x || max_id < 0 || max_id > x->c.voxel_capacity) { bsc_set_error("bsc_import_rgb: max_id vs capacity"); return BSC_E_CAPACITY; }
     BSC_HIP(hipSetDevice(x->device));
     BSC_TRY(reset_state(x));
+    if (x->log_cap && max_id > 0) x->log_stale = true;     // a replayed point log would rebuild colours that ignore the imported state
     if (max_id == 0) return BSC_OK;
     hipStream_t s = x->stream;
     BSC_HIP(hipMemcpyAsync(x->rgb_pos, pos, sizeof(int32_t) * 3 * max_id, hipMemcpyHostToDevice, s));
@@ -768,6 +770,7 @@ extern "C" bsc_status bsc_point_log_enable(bsc_ctx *x, int64_t capacity)
     if (x->log_rec) { (void)hipFree(x->log_rec); x->log_rec = nullptr; }
     x->log_cap = 0;
     x->log_n = 0;
+    x->log_stale = false;
     if (capacity == 0) return BSC_OK;
     BSC_HIP(hipMalloc((void **)&x->log_cell, sizeof(int32_t) * (size_t)capacity));
     BSC_HIP(hipMalloc((void **)&x->log_rec, sizeof(PointRec) * (size_t)capacity));
@@ -780,6 +783,11 @@ extern "C" bsc_status bsc_point_log_read(bsc_ctx *x, int32_t *cells_out_dev, uin
 {
     if (!x || !n_points || capacity < 0) return BSC_E_INVALID;
     if (!x->log_cap) { bsc_set_error("bsc_point_log_read: the log is not enabled"); return BSC_E_STATE; }
+    if (x->log_stale) {
+        bsc_set_error("bsc_point_log_read: colour state was imported / replaced after the log was enabled (a map that was loaded "
+                      "or merged and then extended): the log does not describe it; bsc_reset or bsc_point_log_enable starts a new one");
+        return BSC_E_STATE;
+    }
     BSC_HIP(hipSetDevice(x->device));
     *n_points = x->log_n;
     const int64_t n = x->log_n < capacity ? x->log_n : capacity;
@@ -933,6 +941,7 @@ extern "C" bsc_status bsc_dense_replace_full(bsc_ctx *x, int64_t n, const int32_
                                              const int32_t *cnt_dev, const uint8_t *rgb_dev, const float *weight_dev)
 {
     if (!x || x->c.mode == BSC_MODE_EXACT) { bsc_set_error("bsc_dense_replace: dense modes only"); return BSC_E_STATE; }
+    if (x->log_cap && n > 0) x->log_stale = true;          // a replayed point log would rebuild colours that ignore this state
     if (n < 0 || (n > 0 && (!keys_dev || !acc_dev || !cnt_dev)) || ((rgb_dev == nullptr) != (weight_dev == nullptr))) {
         bsc_set_error("bsc_dense_replace: invalid argument");
         return BSC_E_INVALID;

@@ -198,7 +198,14 @@ def merge_colour_replay(engine, union, per, group=None):
     rc, h = cells // nh, cells % nh
     codes = ((rc // gs) << 42) | ((rc % gs) << 21) | h
     su, order = torch.sort(union)                                   # union is in first-touch order: sorted view for the lookup
-    upos = order[torch.searchsorted(su, codes)] if codes.numel() else codes
+    if codes.numel():
+        at = torch.searchsorted(su, codes).clamp_(max=su.numel() - 1)
+        if not bool((su[at] == codes).all()):
+            raise RuntimeError("merge_colour_replay: the point log holds voxels that are not in the merged union (a log that "
+                               "belongs to another map state)")
+        upos = order[at]
+    else:
+        upos = codes
     dest = upos // max(per, 1)
     rows = torch.stack([upos, (recs[:, 0].to(torch.int64) & 0xffffffff) | (recs[:, 1].to(torch.int64) << 32),
                         recs[:, 2].to(torch.int64)], dim=1) if codes.numel() else torch.zeros((0, 3), dtype=torch.int64, device=union.device)

@@ -511,6 +511,13 @@ def test_point_log_capacity_and_empty_replay():
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
     cells, recs = eng.point_log()
     assert cells.numel() == H * W and recs.shape == (H * W, 3)
+    # colour state imported over a logging engine: the log no longer describes the map and says so instead of replaying wrong colours
+    pos0, rgb0, w0 = eng.export_rgb()
+    eng.import_rgb(pos0, rgb0, w0)
+    with pytest.raises(B._lib.BscError, match="does not describe"):
+        eng.point_log()
+    eng.point_log_enable(H * W + 10)                                     # a new log starts clean
+    assert eng.point_log()[0].numel() == 0
     vox = torch.tensor([1, 1, 3], dtype=torch.int32, device="cuda")      # voxels 0, 2, 4 have no record
     r = torch.tensor([[0, 0x3ff00000, 0x0a0b0c], [0, 0x3fe00000, 0x010203], [0, 0x3fd00000, 0x040506]], dtype=torch.int32, device="cuda")
     out_rgb, out_w = eng.replay_colour(vox, r, 5)
