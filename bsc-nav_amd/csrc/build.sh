@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../libbscnav.so"
 OBJ="$HERE/_obj"
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+FLAGS="${BSC_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 pids=()
 for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_gemm host_rng capi; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"

@@ -544,6 +544,11 @@ template <int NV, bool PAIRED> __device__ __forceinline__ int acc_slot(int t, in
     return 2 * (lane + 64 * (t >> 1)) + (t & 1);
 }
 
+// token rows in flight per wavefront: 8 row gathers outstanding cover the L2-miss latency of the one-voxel-per-point regime (a 58 MB
+// token tile against 4 MB of L2 per XCD: 45 GB per call past the L2 by PMC) — reduce 11.2 -> 8.9 ms there, neutral where rows hit
+#ifndef BSC_REDUCE_RF
+#define BSC_REDUCE_RF 8
+#endif
 template <int NV, int MODE, typename TOK, bool PAIRED = false>
 __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__restrict__ code_sorted,
                                                              const uint32_t *__restrict__ idx_sorted,
@@ -553,6 +558,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                                                              float *__restrict__ acc_g, int32_t *__restrict__ acnt,
                                                              CellCode cc, const int32_t *__restrict__ occ)
 {
+    constexpr int RF = BSC_REDUCE_RF;          // token rows in flight per wavefront
     const int lane = threadIdx.x & 63;
     const int64_t nseg = dscal[DS_B_NPSEG];
     const int64_t max_id_prev = dscal[DS_MAX_ID_PREV];
@@ -580,16 +586,16 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
             const u64 rec = in ? pair_rec[idx_sorted[k]] : 0ull;
             const int n = __popcll(__ballot(in));
             const uint32_t row_l = (uint32_t)(rec >> 32), cnt_l = (uint32_t)rec & 0xffffffu;
-            for (int j = 0; j < n; j += 4) {
+            for (int j = 0; j < n; j += RF) {
                 if constexpr (sizeof(TOK) == 2 && MODE != BSC_MODE_MAX) {
                     // bf16 rows, sum: v_dot2c_f32_bf16 with (m, 0) / (0, m) as the second operand adds m x one element of the
                     // pair to the f32 accumulator — widening and multiply-add in one instruction (the row loads are 8 bytes
                     // per lane; a separate shift / mask per element made this path slower than f32 rows).  m is exact in bf16
                     // up to 256; a larger multiplicity (a pair holds at most a tile's ~3300 points) goes byte by byte, each part exact.
-                    uint2 xr[4][NV];
-                    uint32_t mi[4];
+                    uint2 xr[RF][NV];
+                    uint32_t mi[RF];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < RF; ++q) {
                         const int jj = j + q < n ? j + q : j;
                         const TOK *row = tokens + (int64_t)__builtin_amdgcn_readlane((int)row_l, jj) * D;
                         mi[q] = j + q < n ? (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, jj) : 0u;
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < RF; ++q) {
                         // one exact bf16 factor per byte of the multiplicity (wave-uniform; one pass in the usual case)
                         for (uint32_t rem = mi[q], sh = 0; rem; rem >>= 8, sh += 8) {
                             const uint32_t part = (rem & 255u) << sh;
@@ -627,10 +633,10 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                     }
                     continue;
                 }
-                float4 xv[4][NV];
-                float m[4];
+                float4 xv[RF][NV];
+                float m[RF];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < RF; ++q) {
                     const int jj = j + q < n ? j + q : j;                  // padding repeats pair j with multiplicity 0
                     const TOK *row = tokens + (int64_t)__builtin_amdgcn_readlane((int)row_l, jj) * D;
                     m[q] = j + q < n ? (float)(uint32_t)__builtin_amdgcn_readlane((int)cnt_l, jj) : 0.f;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < RF; ++q)
 #pragma unroll
                     for (int t = 0; t < NV; ++t) {
                         if (MODE == BSC_MODE_MAX) {         // padding repeats a real row: max is idempotent

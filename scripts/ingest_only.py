@@ -1,6 +1,6 @@
 """Ingest-only loop of the bench workload (no encoder): isolated kernel durations for rocprofv3.
-usage: ingest_only.py [calls] [sync|nosync] [frames per call] [kind] [arch dims: g D gs]"""
-import sys, time, numpy as np, torch
+usage: ingest_only.py [calls] [sync|nosync] [frames per call] [kind] [arch dims: g D gs]   (BSC_TOKENS=bf16: bf16 token rows)"""
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import bsc_nav_amd as B
 from bsc_nav_amd import synthetic
@@ -17,6 +17,8 @@ half = gs * 0.05
 vcap = 400000 if kind == "room" else 4_000_000
 eng = B.VoxelEngine(H, W, gs, 0.1, -half, half, g, D, mode="mean", voxel_capacity=vcap, max_points=F * H * W)
 tok = torch.randn((F, g, g, D), device="cuda")
+if os.environ.get("BSC_TOKENS") == "bf16":
+    tok = tok.bfloat16()
 frames = [synthetic.make_frames(17 + s, F, H, W, kind, poses=poses[s * F:(s + 1) * F]) for s in range(calls)]
 torch.cuda.synchronize()
 for rep in range(2):

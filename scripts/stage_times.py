@@ -1,6 +1,6 @@
 """Per-stage HIP-event times of bsc_ingest running alone with a synchronize per call (library stage timers).
 usage: stage_times.py [kind] [frames per call] [calls]"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import bsc_nav_amd as B
 from bsc_nav_amd import synthetic
@@ -13,6 +13,8 @@ chain = B.PoseChain()
 Ts = np.stack([chain.pc_transform(p) for p in poses])
 eng = B.VoxelEngine(H, W, gs, 0.1, -12.8, 12.8, g, D, mode="mean", voxel_capacity=4_000_000, max_points=F * H * W)
 tok = torch.randn((F, g, g, D), device="cuda")
+if os.environ.get("BSC_TOKENS") == "bf16":
+    tok = tok.bfloat16()
 frames = [synthetic.make_frames(17 + s, F, H, W, kind, poses=poses[s * F:(s + 1) * F]) for s in range(calls)]
 names = {2: "points", 3: "pairs", 4: "order", 5: "pairsort", 0: "reduce", 6: "ingest", 7: "chain"}
 for rep in range(2):
