@@ -27,7 +27,7 @@ for name, cs in agg.items():
                  "ingest": not any(name.startswith(p) or p in name[:40] for p in ENCODER)}
 tot = sum((v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_call"] for v in out.values() if v["ingest"])
 json.dump({"command": "rocprofv3 --pmc <TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B | TCC_EA0_WRREQ TCC_EA0_WRREQ_64B> "
-                      "--kernel-trace -- python bench.py --no-cpu-baseline --no-localize --no-workloads --no-f32 --repeats 1 (two separate passes; "
+                      "--kernel-trace -- python bench.py --no-cpu-baseline --no-localize --no-workloads --no-f32 --no-exact --repeats 1 (two separate passes; "
                       "8 steps x 384 frames, room depth)",
            "commit": commit,
            "units": "bytes per launch (mean over all launches of the pass), by request size: read = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B, "
