@@ -715,6 +715,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
 // instructions instead of 2e5 dependent steps of ~28 (6 ms -> 0.5 ms), and the loads of a round are 64 independent
 // gathers instead of 4.
 #define LONG_WAVES 16384
+#define HOT_RPT 8                                // rounds of 64 points per wavefront and tile of a hot segment (records held in registers)
 __device__ __forceinline__ float wave_incl_sum_f32(float x)
 {
 #define BSC_SCAN_STEP(ctrl, rows) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rows, 0xf, false));
@@ -731,6 +732,57 @@ __device__ __forceinline__ float wave_incl_sum_f32(float x)
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 struct ChainState { float w; uint32_t c0, c1, c2; };
+
+// rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
+// after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
+// One round: 64 consecutive points of a voxel (lane l = point l of the round; invalid lanes carry alpha 0 and do not count),
+// state (w, c0, c1, c2) wave-uniform in, the state after the round out.
+__device__ __forceinline__ void chain_round_step(const PointRec rec, const bool valid, float &w, uint32_t &c0, uint32_t &c1,
+                                                 uint32_t &c2, const int lane)
+{
+    const double a = valid ? __hiloint2double((int)rec.ahi, (int)rec.alo) : 0.0;      // alpha 0 leaves w as it is
+    // ---- weights: predict, check with the recurrence, redo from the first lane that fails ----------------------------
+    float wbase = w, wp = w, wn;
+    int start = 0;
+    for (;;) {
+        const float inc = lane >= start ? (float)((double)wbase + a) - wbase : 0.f;
+        const float incl = wave_incl_sum_f32(inc);
+        if (lane >= start) wp = wbase + (incl - inc);
+        wn = (float)((double)wp + a);                                  // :896,:899 the weight this point leaves
+        const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wn), 0x138, 0xf, 0xf, false));   // wave_shr:1
+        const u64 bad = __ballot(lane > start && left != wp);
+        if (!bad) break;
+        start = __ffsll((unsigned long long)bad) - 1;
+        wbase = readlane_f32(wn, start - 1);
+    }
+    w = readlane_f32(wn, 63);
+    const double den = (double)wp + a;
+    double rd = __builtin_amdgcn_rcp(den);
+    double e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
+    e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
+    // ---- colours: every lane steps from the round's entry colour; the first lane that disagrees sets the new one -------
+    const u64 vmask = __ballot(valid);
+#define BSC_LONG_CHANNEL(cc, shift)                                                                     \
+    {                                                                                                   \
+        const double ra = (double)((rec.rgbv >> shift) & 0xffu) * a;                                    \
+        u64 pend = vmask;                                                                               \
+        for (;;) {                                                                                      \
+            const double num = (double)((float)cc * wp) + ra;                                           \
+            const double q0 = num * rd;                                                                 \
+            const double rr = fma(-den, q0, num);                                                       \
+            const uint32_t t = (uint32_t)fma(rr, rd, q0);                                               \
+            const u64 diff = __ballot(t != cc) & pend;                                                  \
+            if (!diff) break;                                                                           \
+            const int f = __ffsll((unsigned long long)diff) - 1;                                        \
+            cc = (uint32_t)__builtin_amdgcn_readlane((int)t, f);                                        \
+            pend &= ~((2ull << f) - 1ull);                                                              \
+        }                                                                                               \
+    }
+    BSC_LONG_CHANNEL(c0, 0)
+    BSC_LONG_CHANNEL(c1, 8)
+    BSC_LONG_CHANNEL(c2, 16)
+#undef BSC_LONG_CHANNEL
+}
 
 // rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
 // after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
@@ -755,83 +807,10 @@ __device__ __forceinline__ void chain_rounds(const uint32_t *__restrict__ sj, co
             const int64_t kc = k + 128 + lane;
             j_nxt = sj[kc < kend ? kc : klast];
         }
-        const bool valid = k + lane < k1;
-        const double a = valid ? __hiloint2double((int)rec.ahi, (int)rec.alo) : 0.0;      // alpha 0 leaves w as it is
-        // ---- weights: predict, check with the recurrence, redo from the first lane that fails ----------------------------
-        float wbase = w, wp = w, wn;
-        int start = 0;
-        for (;;) {
-            const float inc = lane >= start ? (float)((double)wbase + a) - wbase : 0.f;
-            const float incl = wave_incl_sum_f32(inc);
-            if (lane >= start) wp = wbase + (incl - inc);
-            wn = (float)((double)wp + a);                                  // :896,:899 the weight this point leaves
-            const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wn), 0x138, 0xf, 0xf, false));   // wave_shr:1
-            const u64 bad = __ballot(lane > start && left != wp);
-            if (!bad) break;
-            start = __ffsll((unsigned long long)bad) - 1;
-            wbase = readlane_f32(wn, start - 1);
-        }
-        w = readlane_f32(wn, 63);
-        const double den = (double)wp + a;
-        double rd = __builtin_amdgcn_rcp(den);
-        double e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
-        e = fma(-den, rd, 1.0); rd = fma(rd, e, rd);
-        // ---- colours: every lane steps from the round's entry colour; the first lane that disagrees sets the new one -------
-        const u64 vmask = __ballot(valid);
-#define BSC_LONG_CHANNEL(cc, shift)                                                                     \
-        {                                                                                               \
-            const double ra = (double)((rec.rgbv >> shift) & 0xffu) * a;                                \
-            u64 pend = vmask;                                                                           \
-            for (;;) {                                                                                  \
-                const double num = (double)((float)cc * wp) + ra;                                       \
-                const double q0 = num * rd;                                                             \
-                const double rr = fma(-den, q0, num);                                                   \
-                const uint32_t t = (uint32_t)fma(rr, rd, q0);                                           \
-                const u64 diff = __ballot(t != cc) & pend;                                              \
-                if (!diff) break;                                                                       \
-                const int f = __ffsll((unsigned long long)diff) - 1;                                    \
-                cc = (uint32_t)__builtin_amdgcn_readlane((int)t, f);                                    \
-                pend &= ~((2ull << f) - 1ull);                                                          \
-            }                                                                                           \
-        }
-        BSC_LONG_CHANNEL(c0, 0)
-        BSC_LONG_CHANNEL(c1, 8)
-        BSC_LONG_CHANNEL(c2, 16)
-#undef BSC_LONG_CHANNEL
+        chain_round_step(rec, k + lane < k1, w, c0, c1, c2, lane);
         rec = rec_nxt;
     }
     st.w = w; st.c0 = c0; st.c1 = c1; st.c2 = c2;
-}
-
-// sum over the positions [k, k1) of what each point would add to a weight of wbase's binade: f32(f64(wbase) + alpha) - wbase
-// (whole ulps, so the float sums are exact while the weight stays in the binade).  Wave-uniform result.
-__device__ __forceinline__ float chain_inc_sum(const uint32_t *__restrict__ sj, const PointRec *__restrict__ p_rec, int64_t k,
-                                               const int64_t k1, const float wbase, const int lane)
-{
-    constexpr int UN = 16;                      // 1024 points per step: 16 gathers in flight, the next step's indices behind them
-    float acc = 0.f;
-    if (k >= k1) return acc;
-    const double wb = (double)wbase;
-    const int64_t klast = k1 - 1;
-    uint32_t j[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) { const int64_t kk = k + 64 * u + lane; j[u] = sj[kk < k1 ? kk : klast]; }
-    for (; k < k1; k += 64 * UN) {
-        uint32_t alo[UN], ahi[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { const PointRec r = p_rec[j[u]]; alo[u] = r.alo; ahi[u] = r.ahi; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) { const int64_t kk = k + 64 * (UN + u) + lane; j[u] = sj[kk < k1 ? kk : klast]; }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const bool valid = k + 64 * u + lane < k1;
-            const double a = __hiloint2double((int)ahi[u], (int)alo[u]);
-            acc += valid ? (float)(wb + a) - wbase : 0.f;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return readlane_f32(acc, 0);
 }
 
 __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_t vid, const int32_t s, const int64_t klast,
@@ -868,7 +847,10 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nlong = bscal[4], nhot = bscal[6];
     const int64_t max_id_prev = bscal[1];
-    // ---- hot segments: one workgroup each ---------------------------------------------------------------------------------
+    // ---- hot segments: one workgroup each, in TILES of NWV x HOT_RPT x 64 points whose records every wavefront loads ONCE into
+    // registers: (A) the increments of its slice summed from registers, (B) its rounds stepped from registers from the predicted
+    // entry state, (C) the slices' entry / exit states compared; a slice whose entry was wrong runs (A, B) again from registers.
+    // (Until round 4 the chunks spanned the whole segment and pass A re-read every record of it: +12 B per hot point.)
     for (int64_t turn = blockIdx.x; turn < nhot; turn += gridDim.x) {
         const int32_t s = seg_info[turn].w;
         const int4 info = seg_info[s];
@@ -881,32 +863,58 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
         st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
         st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
         st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
-        const int64_t chunk = (((k1 - k) + NWV - 1) / NWV + 63) & ~63ll;
-        const int64_t ka = k + wv * chunk < k1 ? k + wv * chunk : k1, kb = ka + chunk < k1 ? ka + chunk : k1;
-        // chunks < first are final; `st` is the true state at the start of chunk `first`
-        for (int first = 0;;) {
-            const float mine = wv >= first ? chain_inc_sum(sj, p_rec, ka, kb, st.w, lane) : 0.f;
-            __syncthreads();                                // the shared arrays are free (previous pass / previous segment)
-            if (lane == 0) s_sum[wv] = mine;
-            __syncthreads();
-            if (wv >= first) {
-                ChainState me = st;
-                for (int i = first; i < wv; ++i) me.w += s_sum[i];
-                if (lane == 0) s_entry[wv] = me;
-                chain_rounds(sj, p_rec, ka, kb, k1, me, lane);
-                if (lane == 0) s_exit[wv] = me;
+        const int64_t klast = k1 - 1;
+        for (int64_t tile = k; tile < k1; tile += (int64_t)NWV * HOT_RPT * 64) {
+            const int64_t ka = tile + (int64_t)wv * HOT_RPT * 64;          // this wavefront's slice [ka, ka + HOT_RPT * 64) of the tile
+            PointRec rec[HOT_RPT];
+#pragma unroll
+            for (int r = 0; r < HOT_RPT; ++r) {
+                const int64_t kk = ka + r * 64 + lane;
+                rec[r] = p_rec[sj[kk < k1 ? kk : klast]];
             }
-            __syncthreads();
-            int bad = NWV;
-            for (int c = NWV - 1; c > first; --c) {
-                const ChainState have = s_entry[c], real = s_exit[c - 1];
-                if (!(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2)) bad = c;
+            // chunks < first are final; `st` is the true state at the start of chunk `first`
+            for (int first = 0;;) {
+                float mine = 0.f;
+                if (wv >= first) {
+                    const double wb = (double)st.w;
+#pragma unroll
+                    for (int r = 0; r < HOT_RPT; ++r) {
+                        const bool valid = ka + r * 64 + lane < k1;
+                        const double a = __hiloint2double((int)rec[r].ahi, (int)rec[r].alo);
+                        mine += valid ? (float)(wb + a) - st.w : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+                    mine = readlane_f32(mine, 0);
+                }
+                __syncthreads();                                // the shared arrays are free (previous pass / tile / segment)
+                if (lane == 0) s_sum[wv] = mine;
+                __syncthreads();
+                if (wv >= first) {
+                    ChainState me = st;
+                    for (int i = first; i < wv; ++i) me.w += s_sum[i];
+                    if (lane == 0) s_entry[wv] = me;
+#pragma unroll
+                    for (int r = 0; r < HOT_RPT; ++r) {
+                        if (ka + r * 64 >= k1) break;           // (uniform) past the segment's end
+                        chain_round_step(rec[r], ka + r * 64 + lane < k1, me.w, me.c0, me.c1, me.c2, lane);
+                    }
+                    if (lane == 0) s_exit[wv] = me;
+                }
+                __syncthreads();
+                int bad = NWV;
+                for (int c = NWV - 1; c > first; --c) {
+                    const ChainState have = s_entry[c], real = s_exit[c - 1];
+                    if (!(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2)) bad = c;
+                }
+                if (bad == NWV) break;
+                st = s_exit[bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
+                first = bad;
             }
-            if (bad == NWV) break;
-            st = s_exit[bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
-            first = bad;
+            st = s_exit[NWV - 1];                               // the state after the tile (every thread reads the same entry)
+            __syncthreads();                                    // before the next tile's pass overwrites the shared arrays
         }
-        if (threadIdx.x == 0) chain_finish(s_exit[NWV - 1], vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
+        if (threadIdx.x == 0) chain_finish(st, vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
     // ---- the other long segments: one wavefront each, static schedule over the length-ordered list, back and forth (wave g
     // takes g, 2n-1-g, 2n+g, ...): no queue — an `if (lane == 0) atomicAdd` at the head of a loop that ends in another
