@@ -303,6 +303,14 @@ def test_full_size_dense_against_oracle():
     assert n_vox > 5000
 
 
+def test_groups_longer_than_the_run_length_field_are_cut_into_runs():
+    """A voxel capacity of 2^26 leaves 6 bits for a run's length beside the voxel id in the sort key: k_points has to cut every
+    block-local group of more than 64 points into several runs (1 m cells: groups of up to 2048 points), and the chain must still
+    see every voxel's points in order j — rgb bytes, weights, ids bit-exact against the sequential oracle."""
+    longest, n_vox = _dense_vs_oracle(240, 320, 16, 4, 32, 1.0, -16.0, 16.0, F=4, per_call=2, seed=21, vcap=(1 << 26) - 2)
+    assert longest > 20_000 and n_vox < 2000
+
+
 def test_very_long_voxel_chains_against_oracle():
     """1 m cells: single voxels collect > 10^5 points of a call, so the rgb chain walks thousands of 64-point chunks per
     segment (prefetch pipeline, longest-first queue, segments far longer than the wavefront count) — bit-exact rgb."""
