@@ -663,14 +663,12 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
             const int idx = tid + NTHR * r;
             const int t = idx >> 3, ch = idx & 7;
             if (idx < TP * 8) {
-                const bool in = t < T;
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                const uint4 kr = make_uint4(k8[4 * r], k8[4 * r + 1], k8[4 * r + 2], k8[4 * r + 3]);
-                const uint4 vr = make_uint4(v8[4 * r], v8[4 * r + 1], v8[4 * r + 2], v8[4 * r + 3]);
-                *(uint4 *)&sK[t * KP + ch * 8] = in ? kr : z;
+                // padded keys: zero rows, by a mask (a select between two uint4 values is compiled through scratch memory:
+                // 16 scratch stores + loads per staged row until round 4)
+                const uint32_t keep = t < T ? 0xffffffffu : 0u;
+                *(uint4 *)&sK[t * KP + ch * 8] = make_uint4(k8[4 * r] & keep, k8[4 * r + 1] & keep, k8[4 * r + 2] & keep, k8[4 * r + 3] & keep);
                 *(uint4 *)&sQ[t * KP + ch * 8] = make_uint4(q8[4 * r], q8[4 * r + 1], q8[4 * r + 2], q8[4 * r + 3]);
-                const uint4 v = in ? vr : z;
-                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t vv[4] = {v8[4 * r] & keep, v8[4 * r + 1] & keep, v8[4 * r + 2] & keep, v8[4 * r + 3] & keep};
                 // V^T[d][t] lives at granule (t >> 2) ^ (d >> 3) of row d: the 8 rows a lane writes per element pair
                 // and the 8 lanes that share a token then fall into different banks
                 const int col = 4 * ((t >> 2) ^ ch) + (t & 3);
@@ -702,6 +700,9 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
                     const bf16x8_t a = *(const bf16x8_t *)&sK[(t * 16 + n) * KP + kk * 32 + g * 8];
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[kk], acc[t], 0, 0, 0);
                 }
+                // keep the K fragment loads of later key tiles behind these MFMAs: left alone the scheduler hoists them all to the
+                // top of the strip (register pressure; T = 261: 146 -> 109 us per launch together with the masked staging)
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             // padded keys leave the softmax with -inf; for the usual lengths only the last two tiles have any.  The lane's key
             // limit is made opaque per strip: left loop-invariant, the compiler evaluates all 4 NT comparisons once per kernel
@@ -765,6 +766,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
                     uint4 vb = make_uint4(v0.x, v0.y, v1.x, v1.y);
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *(bf16x8_t *)&vb, o[dt], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // o[dt][i] = O[query q0 + 4g + i][d = 16 dt + n]; the row sums sit with the lanes whose n is that query
             const float inv = 1.f / sum;
