@@ -35,6 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GS_KC 32                 // K chunk
 #define GS_PITCH 40              // fp16 elements per staged weight row (80 bytes)
 #define GS_TPB 256
+#ifndef BSC_GEMM_NARROW_TILE
+#define BSC_GEMM_NARROW_TILE 1           // tile variant for N <= 1024 (see bsc_enc_gemm_split)
+#endif
 
 enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
 
@@ -588,14 +591,17 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
         bsc_set_error("bsc_enc_gemm_split: invalid argument (K must be a multiple of 32; piece output needs N %% 32 == 0)");
         return BSC_E_INVALID;
     }
-    static const bool wide = !(getenv("BSC_GEMM_TILE") && atoi(getenv("BSC_GEMM_TILE")) == 2);   // 32 x 256 per wavefront (A/B: 2 = 64 x 128)
-    constexpr int TROWS = 256, TCOLS = 256;                        // workgroup tile of every variant
+    // tile shape: 256 x 256 (8 wavefronts x 32 rows x 256 columns), or — for the narrow outputs (N <= 1024: 888 tiles of 256 x 256 on
+    // 256 CUs is 3.47 rounds, 13 % of the last one idle) — a smaller tile that balances better; BSC_GEMM_TILE = 1 / 3 / 4 forces one
+    static const int tile_env = getenv("BSC_GEMM_TILE") ? atoi(getenv("BSC_GEMM_TILE")) : 0;
+    const int tile = tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
+    const int TROWS = tile == 3 ? 128 : 256, TCOLS = tile == 1 ? 256 : 128, NTHR = tile == 3 ? 256 : 512;
     const int64_t n_pad = ((int64_t)N + 255) / 256 * 256;
     const int n_tiles_n = (int)(n_pad / TCOLS);
     const int64_t n_tiles_m = (M + TROWS - 1) / TROWS;
     const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
     const int64_t n_wg = groups * n_tiles_n * 8;
-    const size_t lds = 2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
     hipStream_t s = (hipStream_t)hip_stream;
     const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
 #define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
@@ -606,14 +612,15 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                      \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(512), lds, s, a_dev, M, K, \
+        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, M, K,\
                            (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
                            c_pieces_scale, n_tiles_n, (int)n_tiles_m);                                                               \
     } while (0)
 #define BSC_GEMM_LAUNCH(EPIV, APV, CPV)                                                                                              \
     do {                                                                                                                             \
-        if (wide) BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, APV, CPV);                                                                      \
-        else BSC_GEMM_LAUNCH2(2, 4, 4, 2, EPIV, APV, CPV);                                                                           \
+        if (tile == 3) BSC_GEMM_LAUNCH2(1, 4, 4, 1, EPIV, APV, CPV);                                                                 \
+        else if (tile == 4) BSC_GEMM_LAUNCH2(1, 4, 8, 1, EPIV, APV, CPV);                                                            \
+        else BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, APV, CPV);                                                                           \
     } while (0)
     if (epilogue == GS_EPI_GELU) {
         if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, true, true);
