@@ -532,21 +532,57 @@ __global__ __launch_bounds__(TPB) void k_gather_topk(int K, int n_cand, int max_
 // Rounds of this kernel shrink n candidates to K without a device-wide sort: n -> ceil(n/1024)*K -> ... -> K.
 #define TK_N 1024
 #define SEL_CNT_PAD 32          // int32 slots between the survivor counters of consecutive queries (one 128-byte line each)
-__device__ __forceinline__ void bitonic_1024(u64 *sk, uint32_t *sv)
+// Ascending bitonic sort of 1024 (key, value) pairs held 4 per thread (element e = 256 r + tid in slot r).  A compare-exchange
+// distance j >= 256 pairs two slots of one thread, j < 64 two lanes of one wavefront (shuffles), only j = 64 and 128 cross
+// wavefronts and go through LDS: 7 of the 55 steps, one barrier each (two buffers alternate), instead of a barrier after every
+// step of an all-LDS network (round 3: ~40 us per block sort, most of it barriers).
+__device__ __forceinline__ void kv_cx(u64 &k, uint32_t &v, const u64 pk, const uint32_t pv, const bool take_min)
 {
+    const bool swap = take_min ? (pk < k) : (pk > k);
+    k = swap ? pk : k;
+    v = swap ? pv : v;
+}
+
+__device__ __forceinline__ void bitonic_1024_regs(u64 (&key)[4], uint32_t (&val)[4], u64 (*bk)[TK_N], uint32_t (*bv)[TK_N])
+{
+    const int tid = threadIdx.x;
+    int buf = 0;
+#pragma unroll
     for (int k = 2; k <= TK_N; k <<= 1) {
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < TK_N / 2; t += TPB) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // lower index of the pair
-                const int l = i | j;
-                const bool up = (i & k) == 0;
-                const u64 a = sk[i], b = sk[l];
-                if ((a > b) == up) {
-                    sk[i] = b; sk[l] = a;
-                    const uint32_t va = sv[i]; sv[i] = sv[l]; sv[l] = va;
+            if (j >= 256) {                             // partner slot r ^ (j / 256) of the same thread
+                const int dr = j >> 8;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r & dr) continue;
+                    const int e = r * 256 + tid;
+                    const bool up = (e & k) == 0;       // the lower element of the pair keeps the minimum when the run ascends
+                    const bool sw = (key[r] > key[r | dr]) == up;
+                    const u64 ka = key[r], kb = key[r | dr];
+                    const uint32_t va = val[r], vb = val[r | dr];
+                    key[r] = sw ? kb : ka; key[r | dr] = sw ? ka : kb;
+                    val[r] = sw ? vb : va; val[r | dr] = sw ? va : vb;
                 }
+            } else if (j < 64) {                        // partner lane tid ^ j of the same wavefront
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = r * 256 + tid;
+                    const u64 pk = __shfl_xor((unsigned long long)key[r], j);
+                    const uint32_t pv = __shfl_xor(val[r], j);
+                    kv_cx(key[r], val[r], pk, pv, ((e & j) == 0) == ((e & k) == 0));
+                }
+            } else {                                    // j = 64, 128: another wavefront, through LDS
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bk[buf][r * 256 + tid] = key[r]; bv[buf][r * 256 + tid] = val[r]; }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = r * 256 + tid;
+                    kv_cx(key[r], val[r], bk[buf][e ^ j], bv[buf][e ^ j], ((e & j) == 0) == ((e & k) == 0));
+                }
+                buf ^= 1;                               // the next cross-wavefront step writes the other buffer: one barrier per step
             }
-            __syncthreads();
         }
     }
 }
@@ -556,23 +592,29 @@ __global__ __launch_bounds__(TPB) void k_cand_topk(CandArgs a, const float *__re
                                                    u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
                                                    int64_t out_stride, int nb, int nq, int bstride)
 {
-    __shared__ u64 sk[TK_N];
-    __shared__ uint32_t sv[TK_N];
+    __shared__ u64 bk[2][TK_N];
+    __shared__ uint32_t bv[2][TK_N];
     for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
         const int q = wi / nb, bx = wi - q * nb;
         const float *qs = sims + (int64_t)q * sims_stride;
-        for (int i = threadIdx.x; i < TK_N; i += TPB) {
-            const int c = bx * bstride * TK_N + i;            // bstride > 1: a sample of blocks spread over the whole map
-            sk[i] = cand_key(a, c, qs);
-            sv[i] = (uint32_t)c;
+        u64 key[4];
+        uint32_t val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = bx * bstride * TK_N + r * 256 + (int)threadIdx.x;     // bstride > 1: a sample of blocks spread over the whole map
+            key[r] = cand_key(a, c, qs);
+            val[r] = (uint32_t)c;
         }
-        __syncthreads();
-        bitonic_1024(sk, sv);
-        for (int i = threadIdx.x; i < K; i += TPB) {
-            out_keys[(int64_t)q * out_stride + (int64_t)bx * K + i] = sk[i];
-            out_vals[(int64_t)q * out_stride + (int64_t)bx * K + i] = sv[i];
+        __syncthreads();                                            // the previous item's partner reads are done
+        bitonic_1024_regs(key, val, bk, bv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = r * 256 + (int)threadIdx.x;
+            if (e < K) {
+                out_keys[(int64_t)q * out_stride + (int64_t)bx * K + e] = key[r];
+                out_vals[(int64_t)q * out_stride + (int64_t)bx * K + e] = val[r];
+            }
         }
-        __syncthreads();
     }
 }
 
@@ -581,24 +623,30 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
                                                     u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
                                                     int64_t out_stride, int nb, int nq)
 {
-    __shared__ u64 sk[TK_N];
-    __shared__ uint32_t sv[TK_N];
+    __shared__ u64 bk[2][TK_N];
+    __shared__ uint32_t bv[2][TK_N];
     for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
         const int q = wi / nb, bx = wi - q * nb;
         const int64_t nn = n_per_q ? min((int64_t)n_per_q[q * SEL_CNT_PAD], n) : n;
         const int64_t base = (int64_t)bx * TK_N;
-        for (int i = threadIdx.x; i < TK_N; i += TPB) {
-            const int64_t g = base + i;
-            sk[i] = g < nn ? in_keys[(int64_t)q * in_stride + g] : ~0ull;
-            sv[i] = g < nn ? in_vals[(int64_t)q * in_stride + g] : 0u;
+        u64 key[4];
+        uint32_t val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t g = base + r * 256 + (int)threadIdx.x;
+            key[r] = g < nn ? in_keys[(int64_t)q * in_stride + g] : ~0ull;
+            val[r] = g < nn ? in_vals[(int64_t)q * in_stride + g] : 0u;
         }
         __syncthreads();
-        bitonic_1024(sk, sv);
-        for (int i = threadIdx.x; i < K; i += TPB) {
-            out_keys[(int64_t)q * out_stride + (int64_t)bx * K + i] = sk[i];
-            out_vals[(int64_t)q * out_stride + (int64_t)bx * K + i] = sv[i];
+        bitonic_1024_regs(key, val, bk, bv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = r * 256 + (int)threadIdx.x;
+            if (e < K) {
+                out_keys[(int64_t)q * out_stride + (int64_t)bx * K + e] = key[r];
+                out_vals[(int64_t)q * out_stride + (int64_t)bx * K + e] = val[r];
+            }
         }
-        __syncthreads();
     }
 }
 
