@@ -21,6 +21,7 @@
 #include "bsc_internal.h"
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 #include <math.h>
 
@@ -683,6 +684,217 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
     }
 }
 
+// ---- column-sliced per-voxel reduce: the regime where the token rows do not stay in the L2 ---------------------------------
+// With one voxel per handful of points (no spatial coherence between a frame's pixels) the voxels running at one time on an XCD
+// reference more distinct token rows than its 4 MB of L2 hold (the 1024 voxels of 32 CUs x 32 wavefronts: ~6 k rows of 1.5 KB), and
+// two thirds of the row gathers go out to the Infinity Cache / HBM.  Here every XCD reduces only ONE column slice of the rows — 384 B
+// of a 1536 B bf16 row (a whole number of 128 B lines) — for every voxel of its share: the same voxels in flight now keep a quarter
+// of the bytes live in each L2 and the reuse between neighbouring voxels (a patch's frustum crosses them all) is served from it.
+// A wavefront holds RPI = 64 / (slice bytes / 16) rows per load instruction (lane group `sub` takes the pairs sub, sub + RPI, ...),
+// RF instructions in flight; the groups' partial sums are combined in lane-group order at the end: a fixed order, so the result
+// does not depend on the schedule.  The pair records arrive gathered into sorted order (k_pairs_gather) — read once per slice.
+__global__ __launch_bounds__(TPB) void k_pairs_gather(const uint32_t *__restrict__ idx_sorted, const u64 *__restrict__ pair_rec,
+                                                      int64_t n, u64 *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) out[i] = pair_rec[idx_sorted[i]];
+}
+
+// voxel id of every segment of the sorted pair list
+__global__ __launch_bounds__(TPB) void k_seg_vid(const uint32_t *__restrict__ code_sorted, const uint32_t *__restrict__ seg_start,
+                                                 const int64_t *dscal, CellCode cc, const int32_t *__restrict__ occ,
+                                                 int32_t *__restrict__ seg_vid)
+{
+    const int64_t nseg = dscal[DS_B_NPSEG];
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * TPB)
+        seg_vid[i] = occ[code_to_cell(cc, (u64)code_sorted[seg_start[i]])];
+}
+
+// What bounds this kernel is instruction issue — one vector and one scalar instruction per cycle and CU — and, per visit of a
+// voxel, a chain of dependent memory round trips (segment -> pair records -> token rows -> old accumulator).  So:
+//  * one row slice per load instruction, 8 bytes per lane (a 384-byte slice = 48 lanes): a row's byte offset and multiplicity are
+//    wave-uniform — computed once per 64-pair chunk in the lanes, fetched with v_readlane at a CONSTANT lane index (the chunk is
+//    walked by fully unrolled batches of RF pairs) and used as the scalar offset of a buffer_load / the scalar operand of
+//    v_dot2c_f32_bf16: per row slice two or three v_readlane, one load, one dot2 per element, and no address arithmetic at all;
+//  * lanes past the end of a segment repeat its last row with multiplicity 0 (max: idempotent), so batches need no tail handling;
+//  * the segment bounds and voxel id of the visit after the next arrive by scalar loads, the pair records of the next visit are
+//    fetched under the row gathers of the current one, the old accumulator slice is the initial value of the sums;
+//  * bf16 multiplicities go byte by byte (each part exact in bf16), the upper bytes only for a chunk that has them.
+template <int MODE, typename TOK, int RF = 8, int WPE = 8>
+__global__ __launch_bounds__(TPB, WPE) void k_dense_reduce_sliced(const u64 *__restrict__ rec_sorted, int64_t n_pairs,
+                                                                  const uint32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_vid,
+                                                                  const int64_t *dscal, const TOK *__restrict__ tokens, int D,
+                                                                  float *__restrict__ acc_g, int32_t *__restrict__ acnt, int nslice,
+                                                                  uint32_t tok_bytes)
+{
+    constexpr int E = 8 / (int)sizeof(TOK);                 // columns per 8-byte load
+    constexpr bool DOT2 = sizeof(TOK) == 2 && MODE != BSC_MODE_MAX;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nseg = (int)dscal[DS_B_NPSEG];
+    const int max_id_prev = (int)dscal[DS_MAX_ID_PREV];
+    const int SC = D / nslice;                              // columns of a slice; lanes 0 .. SC / E - 1 hold them
+    const bool active = lane * E < SC;
+    const int xcd = blockIdx.x & 7, slice = xcd % nslice, part = xcd / nslice, nparts = 8 / nslice;
+    const int col = slice * SC + (active ? lane : 0) * E;
+    const uint32_t colb = (uint32_t)col * (uint32_t)sizeof(TOK);
+    const uint32_t rowb = (uint32_t)D * (uint32_t)sizeof(TOK);
+    // the token tile as a raw buffer: a gather is buffer_load_dwordx2 with the lane's column offset in a VGPR and the row's byte
+    // offset in an SGPR
+    const __amdgpu_buffer_rsrc_t tok_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tokens, 0, tok_bytes, 0x00020000);
+    const int w_local = (int)(blockIdx.x >> 3) * (TPB / 64) + wave;
+    const int w_per_xcd = (int)(gridDim.x >> 3) * (TPB / 64);
+    const int chunk = (nseg + 63) / 64;                     // the XCD part walks the super-chunks part, part + nparts, ...
+    const int n_super = 64 / nparts;
+    // cursor of the segment fetch: visit number = cq * chunk + cr (advanced without divisions)
+    int cq = w_local / (chunk > 0 ? chunk : 1), cr = w_local - cq * chunk;
+    const int step_q = w_per_xcd / (chunk > 0 ? chunk : 1), step_r = w_per_xcd - step_q * chunk;
+
+    // the next visit of this wavefront: first pair, pair count, voxel id (wave-uniform: scalar loads); n = 0 past the end
+#define SL_META(i0_, n_, vid_)                                                                             \
+    do {                                                                                                   \
+        i0_ = 0; n_ = 0; vid_ = -1;                                                                        \
+        if (cq < n_super) {                                                                                \
+            const int sg_ = (part + nparts * cq) * chunk + cr;                                             \
+            if (sg_ < nseg) {                                                                              \
+                i0_ = (int)seg_start[sg_];                                                                 \
+                n_ = (sg_ + 1 < nseg ? (int)seg_start[sg_ + 1] : (int)n_pairs) - i0_;                      \
+                vid_ = seg_vid[sg_];                                                                       \
+            }                                                                                              \
+        }                                                                                                  \
+        cq += step_q; cr += step_r;                                                                        \
+        if (cr >= chunk) { cr -= chunk; ++cq; }                                                            \
+    } while (0)
+    // per chunk of up to 64 pair records: the lane's row offset and multiplicity operands
+#define SL_CHUNK(nn_)                                                                                      \
+    do {                                                                                                   \
+        const uint32_t row_ = (uint32_t)(rec >> 32);                                                       \
+        cnt_l = (int)((uint32_t)rec & 0xffffffu);                                                          \
+        const uint32_t last_ = (uint32_t)__builtin_amdgcn_readlane((int)row_, (nn_) - 1);                  \
+        roff_l = (int)((lane < (nn_) ? row_ : last_) * rowb);                                              \
+        if constexpr (DOT2) {                                                                              \
+            m0_l = (int)(__float_as_uint((float)(cnt_l & 0xff)) >> 16);                                    \
+            big = __ballot(cnt_l > 255) != 0ull;                                                           \
+        } else m0_l = (int)__float_as_uint((float)cnt_l);                                                  \
+    } while (0)
+#define SL_ISSUE(B_)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < RF; ++q) {                                                       \
+        const uint32_t off_ = (uint32_t)__builtin_amdgcn_readlane(roff_l, (B_) * RF + q);                  \
+        x[q] = __builtin_amdgcn_raw_buffer_load_b64(tok_rsrc, colb, off_, 0);                              \
+    }
+#define SL_DOT2(B_, mb_)                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < RF; ++q) {                                                       \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane(mb_, (B_) * RF + q), hi_ = lo_ << 16;     \
+        const bf16x2_t blo_ = __builtin_bit_cast(bf16x2_t, lo_), bhi_ = __builtin_bit_cast(bf16x2_t, hi_); \
+        const uint32_t w0_ = x[q].x, w1_ = x[q].y;      /* (bit_cast of a vector ELEMENT reads element 0 whatever the index) */ \
+        const bf16x2_t e01_ = __builtin_bit_cast(bf16x2_t, w0_), e23_ = __builtin_bit_cast(bf16x2_t, w1_); \
+        a[0] = __builtin_amdgcn_fdot2_f32_bf16(e01_, blo_, a[0], false);                                   \
+        a[1 % E] = __builtin_amdgcn_fdot2_f32_bf16(e01_, bhi_, a[1 % E], false);                           \
+        a[2 % E] = __builtin_amdgcn_fdot2_f32_bf16(e23_, blo_, a[2 % E], false);                           \
+        a[3 % E] = __builtin_amdgcn_fdot2_f32_bf16(e23_, bhi_, a[3 % E], false);                           \
+    }
+#define SL_ACCUM(B_)                                                                                       \
+    if constexpr (DOT2) {                                                                                  \
+        SL_DOT2(B_, m0_l)                                                                                  \
+        if (big) {                                                                                         \
+            const int m1_l = (int)(__float_as_uint((float)(cnt_l & 0xff00)) >> 16);                        \
+            const int m2_l = (int)(__float_as_uint((float)(cnt_l & 0xff0000)) >> 16);                      \
+            SL_DOT2(B_, m1_l)                                                                              \
+            SL_DOT2(B_, m2_l)                                                                              \
+        }                                                                                                  \
+    } else {                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < RF; ++q) {                                                   \
+            const float m_ = __uint_as_float((uint32_t)__builtin_amdgcn_readlane(m0_l, (B_) * RF + q));    \
+            float v_[4];                                                                                   \
+            if constexpr (sizeof(TOK) == 2) {                                                              \
+                v_[0] = __uint_as_float(x[q].x << 16); v_[1] = __uint_as_float(x[q].x & 0xffff0000u);      \
+                v_[2] = __uint_as_float(x[q].y << 16); v_[3] = __uint_as_float(x[q].y & 0xffff0000u);      \
+            } else {                                                                                       \
+                v_[0] = __uint_as_float(x[q].x); v_[1] = __uint_as_float(x[q].y); v_[2] = 0.f; v_[3] = 0.f; \
+            }                                                                                              \
+            _Pragma("unroll") for (int e = 0; e < E; ++e)                                                  \
+                a[e] = (MODE == BSC_MODE_MAX) ? fmaxf(a[e], v_[e]) : fmaf(m_, v_[e], a[e]);                \
+        }                                                                                                  \
+    }
+
+    int i0_1, vid_1, i0_2, vid_2, n_1, n_2;
+    SL_META(i0_1, n_1, vid_1);
+    SL_META(i0_2, n_2, vid_2);
+    u64 r1 = lane < n_1 ? rec_sorted[i0_1 + lane] : 0ull;
+    while (n_1 > 0 || n_2 > 0 || cq < n_super) {
+        const int i0 = i0_1, vid = vid_1, n = n_1;
+        u64 rec = r1;
+        i0_1 = i0_2; n_1 = n_2; vid_1 = vid_2;
+        if (n <= 0) {                                       // a hole of the walk: keep the pipeline moving
+            r1 = lane < n_1 ? rec_sorted[i0_1 + lane] : 0ull;
+            SL_META(i0_2, n_2, vid_2);
+            continue;
+        }
+        const bool is_new = vid >= max_id_prev;
+        float *dst = acc_g + (int64_t)vid * D + col;
+        float a[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = (MODE == BSC_MODE_MAX) ? -INFINITY : 0.f;
+        if (!is_new && active) {
+            if constexpr (E == 4) { const float4 o = *(const float4 *)dst; a[0] = o.x; a[1 % E] = o.y; a[2 % E] = o.z; a[3 % E] = o.w; }
+            else { const float2 o = *(const float2 *)dst; a[0] = o.x; a[1 % E] = o.y; }
+        }
+        u32x2_t x[RF];
+        int roff_l, cnt_l, m0_l;
+        bool big = false;
+        int nn = n < 64 ? n : 64;
+        SL_CHUNK(nn);
+        uint32_t cs = (uint32_t)cnt_l;              // lanes past the segment hold 0
+        SL_ISSUE(0)
+        // under the first row gathers: the next visit's pair records, the segment of the visit after that
+        r1 = lane < n_1 ? rec_sorted[i0_1 + lane] : 0ull;
+        SL_META(i0_2, n_2, vid_2);
+        SL_ACCUM(0)
+#pragma unroll
+        for (int B = 1; B < 64 / RF; ++B) {
+            if (nn > B * RF) {
+                SL_ISSUE(B)
+                SL_ACCUM(B)
+            }
+        }
+        for (int base = 64; base < n; base += 64) {
+            rec = base + lane < n ? rec_sorted[i0 + base + lane] : 0ull;
+            nn = n - base < 64 ? n - base : 64;
+            SL_CHUNK(nn);
+            cs += (uint32_t)cnt_l;
+#pragma unroll
+            for (int B = 0; B < 64 / RF; ++B) {
+                if (nn > B * RF) {
+                    SL_ISSUE(B)
+                    SL_ACCUM(B)
+                }
+            }
+        }
+        if (active) {
+            if constexpr (E == 4) *(float4 *)dst = make_float4(a[0], a[1 % E], a[2 % E], a[3 % E]);
+            else *(float2 *)dst = make_float2(a[0], a[1 % E]);
+        }
+        if (slice == 0) {
+            for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
+            if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)cs;
+        }
+    }
+#undef SL_META
+#undef SL_ISSUE
+#undef SL_ACCUM
+#undef SL_DOT2
+#undef SL_CHUNK
+}
+
+// column slices of the sliced reduce: the fewest of 1 / 2 / 4 / 8 for which a slice is a whole number of 128-byte lines and one
+// load instruction of 8 bytes per lane covers it (<= 512 bytes); 0: no such split (the per-voxel kernel stays)
+static int reduce_slices(int D, int tok_bytes)
+{
+    const int64_t rowb = (int64_t)D * tok_bytes;
+    for (int ns = 1; ns <= 8; ns <<= 1)
+        if (rowb % (128 * ns) == 0 && rowb / ns <= 512) return ns;
+    return 0;
+}
+
 __global__ void k_dense_counters(int64_t *dscal)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -788,6 +1000,32 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         stat_end(x, BSC_STAT_PAIRSORT, 0.0);
         stat_begin(x, BSC_STAT_DENSE);
         const dim3 grid(256 * 8), block(TPB);
+        {
+            // BSC_SLICED_MIN_PAIRS=<n>: pair lists of n or more take the column-sliced kernel.  Off by default: on the one-voxel-per-
+            // point workload it halves the bytes fetched past the L2 (38 -> 19 GB per call) and still runs 9.1 ms against 8.5 ms for
+            // the per-voxel kernel — four visits per voxel, each bound by instruction issue (profiles/r04_iid_reduce.txt)
+            const int64_t sliced_min = getenv("BSC_SLICED_MIN_PAIRS") ? atoll(getenv("BSC_SLICED_MIN_PAIRS")) : INT64_MAX;
+            const int ns = reduce_slices(D, token_dtype == BSC_TOK_BF16 ? 2 : 4);
+            const int64_t tile_bytes = (int64_t)n_frames * x->g2 * D * (token_dtype == BSC_TOK_BF16 ? 2 : 4);     // < 4 GB: 32-bit row offsets
+            if (ns && n_pairs >= sliced_min && tile_bytes < ((int64_t)1 << 32)) {
+                u64 *rec_sorted = x->pstage_key;           // free since k_patch_compact
+                int32_t *seg_vid = (int32_t *)x->pair_cnt_a;    // the unsorted codes: free since the sort
+                hipLaunchKernelGGL(k_pairs_gather, dim3(256 * 8), block, 0, s, idx_sorted, x->pair_key_a, n_pairs, rec_sorted);
+                hipLaunchKernelGGL(k_seg_vid, dim3(256 * 4), block, 0, s, x->pair_cnt_b, (const uint32_t *)x->pseg_start, x->dscal, cc,
+                                   x->occ, seg_vid);
+#define LS(MODEV, TOKT)                                                                                                         \
+    hipLaunchKernelGGL((k_dense_reduce_sliced<MODEV, TOKT>), grid, block, 0, s, rec_sorted, n_pairs,                            \
+                       (const uint32_t *)x->pseg_start, seg_vid, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, ns, \
+                       (uint32_t)tile_bytes)
+                if (token_dtype == BSC_TOK_BF16) { if (x->c.mode == BSC_MODE_MEAN) LS(BSC_MODE_MEAN, bf16_t); else LS(BSC_MODE_MAX, bf16_t); }
+                else { if (x->c.mode == BSC_MODE_MEAN) LS(BSC_MODE_MEAN, float); else LS(BSC_MODE_MAX, float); }
+#undef LS
+                stat_end(x, BSC_STAT_DENSE, 0.0);
+                hipLaunchKernelGGL(k_dense_counters, dim3(1), dim3(64), 0, s, x->dscal);
+                BSC_HIP(hipGetLastError());
+                return BSC_OK;
+            }
+        }
 #define LVP(NVV, MODEV, TOKT, PAIR)                                                                                            \
     hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT, PAIR>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
                        n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ)

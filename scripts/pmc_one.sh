@@ -17,6 +17,8 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     if sys.argv[2] in r["Kernel_Name"]:
         agg[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if "End_Timestamp" in r:
+            agg[(r["Kernel_Name"].split("(")[0][-60:], "duration_us (serialized)")].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 for (k, c), v in sorted(agg.items()):
     print(f"{k:60s} {c:28s} mean {sum(v) / len(v):16.1f}  n={len(v)}")
 PY

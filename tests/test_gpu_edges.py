@@ -303,6 +303,42 @@ def test_full_size_dense_against_oracle():
     assert n_vox > 5000
 
 
+@pytest.mark.parametrize("D,bf16,mode,kind", [(768, True, "mean", "iid"), (768, True, "max", "room"), (1024, False, "mean", "room"),
+                                               (128, False, "max", "iid"), (1024, True, "mean", "room"), (384, True, "mean", "iid")])
+def test_column_sliced_reduce_against_oracle(monkeypatch, D, bf16, mode, kind):
+    """k_dense_reduce_sliced (one column slice of the token rows per XCD; taken for very long pair lists, forced here): 4 slices
+    of 24 lanes (768-D bf16), 8 of 32 / 16 (1024-D f32 / bf16), 4 of 8 lanes (128-D f32), 2 of 24 (384-D bf16) — counts exact,
+    max rows bit-exact, means within 1e-3 of the sequential oracle, over two calls (old voxels take the read-modify-write)."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    monkeypatch.setenv("BSC_SLICED_MIN_PAIRS", "1")
+    H, W, g, gs, F = 240, 320, 14, 128, 4
+    rgb, depth, poses = synth.make_frames(51, F, H, W, kind)
+    tokens = synth.make_tokens(51, F, g, D)
+    d_tok = torch.from_numpy(tokens).cuda()
+    if bf16:
+        d_tok = d_tok.bfloat16()
+        tokens = d_tok.float().cpu().numpy()
+    eng = B.VoxelEngine(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=mode, voxel_capacity=400_000, max_points=2 * H * W)
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=1 if mode == "mean" else 2), voxel_capacity=400_000)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f])
+    for a in range(0, F, 2):
+        eng.ingest(torch.from_numpy(depth[a:a + 2]).cuda(), torch.from_numpy(rgb[a:a + 2]).cuda(), d_tok[a:a + 2].contiguous(), Ts[a:a + 2])
+    (acc, cnt), (oacc, ocnt) = eng.export_dense(), om.export_dense()
+    assert np.array_equal(eng.export_rgb()[0], om.export_rgb()[0]) and np.array_equal(cnt, ocnt) and len(cnt) > 2000
+    if mode == "max":
+        assert np.array_equal(acc, oacc)
+    else:
+        c = np.maximum(cnt, 1)[:, None].astype(np.float64)
+        np.testing.assert_allclose(acc / c, oacc / c, rtol=1e-3, atol=1e-3)
+    eng.close()
+
+
 def test_groups_longer_than_the_run_length_field_are_cut_into_runs():
     """A voxel capacity of 2^26 leaves 6 bits for a run's length beside the voxel id in the sort key: k_points has to cut every
     block-local group of more than 64 points into several runs (1 m cells: groups of up to 2048 points), and the chain must still
