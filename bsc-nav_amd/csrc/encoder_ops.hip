@@ -793,6 +793,242 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
     }
 }
 
+// ---- the same attention on 32 x 32 x 16 MFMA tiles (sequences up to 224 tokens) ----------------------------------------------
+// k_attention reads every K and V^T fragment from LDS once per 16 queries: 56 KB of LDS reads per strip, ~730 KB per (image, head)
+// item, and the LDS pipe — with the exp2 of the softmax on the vector unit — is what the kernel waits for (MFMA busy 11 %).  With
+// v_mfma_f32_32x32x16_bf16 a wavefront takes 32 queries: every fragment read feeds twice the matrix work (half the LDS bytes per
+// item), seven strips of 32 cover 197 tokens with one strip per wavefront (13 strips of 16 over 7 wavefronts left one in seven idle
+// half the time), and the two halves of a wavefront hold a query's keys, so max and sum need ONE cross-lane step instead of two.
+//   S^T tile t (32 keys x 32 queries) = K_t . Q^T     A = K rows (lane & 31 = key, 8 features at 8 (lane >> 5) of the 16-wide k step)
+//                                                     B = Q rows (lane & 31 = query), four k steps
+//        -> acc[t][r] = S^T[key 32 t + 8 (r >> 2) + 4 hh + (r & 3)][query lane & 31],  hh = lane >> 5
+//   O^T (64 x 32 queries) = V^T . P^T                  the accumulators ARE the B operand if a 16-key step takes its contraction
+//        index in accumulator order: step (t, jp) = registers 8 jp .. 8 jp + 7 = keys 32 t + 16 jp + {0..3, 8..11} + 4 hh;
+//        V^T is read in that order (two 8-byte reads per lane and step)
+// Staging: a thread owns PAIRS of consecutive tokens, so V^T (row = feature, column = key) is written two keys at a time (4-byte
+// stores); its row pitch is 4 x odd elements: the 32 feature rows a fragment read touches fall into 32 different bank pairs.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int NLP, int NTHR>
+__device__ __forceinline__ void att32_issue_loads(typename u32vec<8 * NLP>::type &k8, typename u32vec<8 * NLP>::type &v8,
+                                                  typename u32vec<8 * NLP>::type &q8, const uint16_t *__restrict__ qkv,
+                                                  int item, int T, int H, int tid)
+{
+    const int64_t tok_stride = (int64_t)3 * H * 64;
+    const int b = item / H, h = item % H;
+    const uint16_t *Qp = qkv + (int64_t)b * T * tok_stride + (int64_t)h * 64;
+    const uint16_t *Kp = Qp + (int64_t)H * 64, *Vp = Qp + (int64_t)2 * H * 64;
+#pragma unroll
+    for (int r = 0; r < NLP; ++r) {
+        const int idx = tid + NTHR * r;
+        const int tp = idx >> 3, ch = idx & 7;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = 2 * tp + u, tc = t < T ? t : T - 1;
+            const uint4 k = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + ch * 8);
+            const uint4 v = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + ch * 8);
+            const uint4 q = *(const uint4 *)(Qp + (int64_t)tc * tok_stride + ch * 8);
+            const int o = 8 * r + 4 * u;
+            k8[o] = k.x; k8[o + 1] = k.y; k8[o + 2] = k.z; k8[o + 3] = k.w;
+            v8[o] = v.x; v8[o + 1] = v.y; v8[o + 2] = v.z; v8[o + 3] = v.w;
+            q8[o] = q.x; q8[o + 1] = q.y; q8[o + 2] = q.z; q8[o + 3] = q.w;
+        }
+    }
+}
+
+template <int NT2, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention32(const uint16_t *__restrict__ qkv, int T, int H, int items,
+                                                         uint16_t *__restrict__ out, int *work)
+{
+    __shared__ int s_ticket;
+    constexpr int NTHR = 64 * NW;
+    constexpr int TP = NT2 * 32;
+    constexpr int KP = 64 + 8;                              // K / Q row pitch (bf16 elements)
+    constexpr int VP = TP + 4;                              // V^T row pitch: 4 x odd
+    constexpr int NLP = (TP * 4 + NTHR - 1) / NTHR;         // (token pair, 16-byte piece) items per thread
+    __shared__ __attribute__((aligned(16))) uint16_t sK[TP * KP];
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[TP * KP];
+    __shared__ __attribute__((aligned(16))) uint16_t sVt[64 * VP + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 31, hh = lane >> 5;
+    const float c = 0.125f * 1.44269504088896340736f;               // 1/sqrt(64) * log2(e)
+    typename u32vec<8 * NLP>::type k8, v8, q8;
+
+    int item = blockIdx.x;
+    if (work) {
+        if (tid == 0) s_ticket = atomicAdd(&work[0], 1);
+        __syncthreads();
+        item = s_ticket;
+    }
+    att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, item < items ? item : items - 1, T, H, tid);
+    int nxt = item;
+#ifdef BSC_ATT_PROFILE
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+#define ATT_T(k) { const long long now_ = clock64(); tph[k] += now_ - tq; tq = now_; }
+    tq = clock64();
+#else
+#define ATT_T(k)
+#endif
+    for (; item < items; item = nxt) {
+        const int b = item / H, h = item % H;
+        __syncthreads();                                            // the previous item's strips are done with LDS
+        ATT_T(0)
+#pragma unroll
+        for (int r = 0; r < NLP; ++r) {
+            const int idx = tid + NTHR * r;
+            const int tp = idx >> 3, ch = idx & 7;
+            if (idx < TP * 4) {
+                const int t0 = 2 * tp;
+                const uint32_t keep0 = t0 < T ? 0xffffffffu : 0u, keep1 = t0 + 1 < T ? 0xffffffffu : 0u;    // padded keys: zero rows
+                *(uint4 *)&sK[t0 * KP + ch * 8] = make_uint4(k8[8 * r] & keep0, k8[8 * r + 1] & keep0, k8[8 * r + 2] & keep0, k8[8 * r + 3] & keep0);
+                *(uint4 *)&sK[(t0 + 1) * KP + ch * 8] = make_uint4(k8[8 * r + 4] & keep1, k8[8 * r + 5] & keep1, k8[8 * r + 6] & keep1, k8[8 * r + 7] & keep1);
+                *(uint4 *)&sQ[t0 * KP + ch * 8] = make_uint4(q8[8 * r], q8[8 * r + 1], q8[8 * r + 2], q8[8 * r + 3]);
+                *(uint4 *)&sQ[(t0 + 1) * KP + ch * 8] = make_uint4(q8[8 * r + 4], q8[8 * r + 5], q8[8 * r + 6], q8[8 * r + 7]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t w0 = v8[8 * r + e] & keep0, w1 = v8[8 * r + 4 + e] & keep1;     // features 2e, 2e+1 of the piece, tokens t0 / t0+1
+                    *(uint32_t *)&sVt[(ch * 8 + 2 * e) * VP + t0] = (w0 & 0xffffu) | (w1 << 16);
+                    *(uint32_t *)&sVt[(ch * 8 + 2 * e + 1) * VP + t0] = (w0 >> 16) | (w1 & 0xffff0000u);
+                }
+            }
+        }
+        if (work && tid == 0) s_ticket = atomicAdd(&work[0], 1);    // everyone has read the previous ticket (barrier above)
+        __syncthreads();
+        nxt = work ? s_ticket : item + (int)gridDim.x;
+        ATT_T(1)
+        const int q0 = wave * 32;
+        if (q0 >= T) {
+            att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
+            continue;
+        }
+        bf16x8_t bq[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bq[kk] = *(const bf16x8_t *)&sQ[(q0 + nl) * KP + kk * 16 + hh * 8];
+        f32x16_t acc[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t a = *(const bf16x8_t *)&sK[(t * 32 + nl) * KP + kk * 16 + hh * 8];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kk], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                      // keep the K fragment loads of later tiles behind these MFMAs
+        }
+        // padded keys leave the softmax with -inf: only the last two tiles can hold any (the lane's limit is made opaque: left
+        // loop-invariant the comparisons turn into scalar mask pairs that do not fit the SGPR file)
+        ATT_T(3)
+        // the next item's K, V, Q rows: requested here, behind the wavefront's own Q.K^T (the wavefronts then reach the texture
+        // path at different times instead of queueing 84 load instructions at the barrier), in flight during softmax and P.V
+        att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
+        ATT_T(2)
+        int lim = T - hh * 4;
+        asm volatile("" : "+v"(lim));
+        if (T > 32 * (NT2 - 2)) {
+#pragma unroll
+            for (int t = (NT2 > 2 ? NT2 - 2 : 0); t < NT2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 32 + 8 * (r >> 2) + (r & 3) >= lim) acc[t][r] = -INFINITY;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 32 + 8 * (r >> 2) + (r & 3) >= lim) acc[t][r] = -INFINITY;
+        }
+        // row maximum: v_max3_f32 trees over the lane's 16 NT2 scores, then the other half of the wavefront
+        float m;
+        {
+            float mt[NT2];
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const float a0 = fmaxf(fmaxf(acc[t][0], acc[t][1]), acc[t][2]), a1 = fmaxf(fmaxf(acc[t][3], acc[t][4]), acc[t][5]);
+                const float a2 = fmaxf(fmaxf(acc[t][6], acc[t][7]), acc[t][8]), a3 = fmaxf(fmaxf(acc[t][9], acc[t][10]), acc[t][11]);
+                const float a4 = fmaxf(fmaxf(acc[t][12], acc[t][13]), acc[t][14]);
+                mt[t] = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), acc[t][15]));
+            }
+            m = mt[0];
+#pragma unroll
+            for (int t = 1; t < NT2; ++t) m = fmaxf(m, mt[t]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float nmc = -m * c;
+        ATT_T(4)
+        // exp2 and P.V tile by tile: the V^T fragments of a tile are requested first, its 16 scores go through exp2 / sum / bf16
+        // packing on the vector unit while the previous tile's four MFMAs run, then its own MFMAs are issued
+        f32x16_t o[2];
+        const uint16_t *vp[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+            vp[dt] = &sVt[(dt * 32 + nl) * VP + 4 * hh];
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+            uint4 vb[2][2];
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const uint2 v0 = *(const uint2 *)(vp[dt] + t * 32 + 16 * jp), v1 = *(const uint2 *)(vp[dt] + t * 32 + 16 * jp + 8);
+                    vb[jp][dt] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                }
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c, nmc));       // exp2((s - m) * c)
+            sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7])) + (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                uint4 pa;
+                pa.x = pack_bf16(e[8 * jp], e[8 * jp + 1]);
+                pa.y = pack_bf16(e[8 * jp + 2], e[8 * jp + 3]);
+                pa.z = pack_bf16(e[8 * jp + 4], e[8 * jp + 5]);
+                pa.w = pack_bf16(e[8 * jp + 6], e[8 * jp + 7]);
+                const bf16x8_t a = *(bf16x8_t *)&pa;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t *)&vb[jp][dt], a, o[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 32);
+        ATT_T(5)
+        // V^T is the FIRST operand: o[dt][r] = O^T[feature 32 dt + 8 (r >> 2) + 4 hh + (r & 3)][query q0 + nl] — the lane that holds a
+        // query's row sum also holds its outputs, four consecutive features per register quad: 8-byte stores, no shuffles
+        const float inv = 1.f / sum;
+        const int q = q0 + nl;
+        if (q < T) {
+            uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + 4 * hh;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(uint2 *)(dst + 32 * dt + 8 * j) = make_uint2(pack_bf16(o[dt][4 * j] * inv, o[dt][4 * j + 1] * inv),
+                                                                   pack_bf16(o[dt][4 * j + 2] * inv, o[dt][4 * j + 3] * inv));
+        }
+        ATT_T(6)
+    }
+#ifdef BSC_ATT_PROFILE
+    if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 6))
+        printf("att32 wave %d: wait-barrier %lld stage %lld issue %lld qk %lld softmax %lld pv %lld store %lld (clock64 ticks)\n", wave,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
+#endif
+#undef ATT_T
+    // the last workgroup to leave re-arms the counters for the next launch on this stream
+    if (work && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&work[1], 1) == (int)gridDim.x - 1) {
+            work[0] = 0;
+            work[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
 extern "C" bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                                             void *out_dev, int32_t *work2_dev, void *hip_stream)
 {
@@ -810,7 +1046,11 @@ extern "C" bsc_status bsc_enc_attention_dyn(const void *qkv_dev, int32_t B, int3
     }
     const int64_t items = (int64_t)B * heads;
     const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
-    if (T <= 224)
+    static const bool tiles32 = !(getenv("BSC_ATT_TILE") && atoi(getenv("BSC_ATT_TILE")) == 16);
+    if (T <= 224 && tiles32)
+        hipLaunchKernelGGL((k_attention32<7, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
+                           (uint16_t *)out_dev, (int *)work2_dev);
+    else if (T <= 224)
         hipLaunchKernelGGL((k_attention<14, 7>), grid, dim3(64 * 7), 0, s, (const uint16_t *)qkv_dev, T, heads, (int)items,
                            (uint16_t *)out_dev, (int *)work2_dev);
     else
