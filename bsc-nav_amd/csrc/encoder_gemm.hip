@@ -495,29 +495,27 @@ __global__ __launch_bounds__(64 * NW) void k_attention_split(const uint16_t *__r
                     const uint2 l0 = *(const uint2 *)(v0p[dt] + 64 * VP + 32 * ks), l1 = *(const uint2 *)(v1p[dt] + 64 * VP + 32 * ks);
                     const half8_t vh = __builtin_bit_cast(half8_t, (u32x4_t){h0.x, h0.y, h1.x, h1.y});
                     const half8_t vl = __builtin_bit_cast(half8_t, (u32x4_t){l0.x, l0.y, l1.x, l1.y});
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vl, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vh, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vh, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ah, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, al, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ah, o[dt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // o[dt][i] = 2^8 sum O[query q0 + 4g + i][d = 16 dt + n]; the row sums (x 2^8 as well) sit with the lanes whose n is that query
+            // V^T is the FIRST operand: o[dt][i] = 2^8 sum O^T[d = 16 dt + 4 g + i][query q0 + n] — the lane that holds a query's row sum
+            // (x 2^8 as well) holds its outputs, four consecutive features per accumulator: 8-byte stores of the h and the l pieces,
+            // no shuffles (with the queries along the registers this epilogue was 32 two-byte stores and 4 shuffles per lane and strip)
             const float inv = out_scale / sum;
+            const int q = q0 + n;
+            if (q < T) {
+                uint16_t *dst = out + ((int64_t)b * T + q) * 2 * H * 64 + (int64_t)2 * h * 64 + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = __shfl(inv, g * 4 + i);
-                const int q = q0 + g * 4 + i;
-                if (q < T) {
-                    uint16_t *dst = out + ((int64_t)b * T + q) * 2 * H * 64 + (int64_t)2 * h * 64 + n;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const float v = o[dt][i] * r;
-                        const _Float16 hh = (_Float16)v;
-                        const _Float16 ll = (_Float16)(v - (float)hh);
-                        uint16_t *d2 = dst + (dt >> 1) * 64 + (dt & 1) * 16;          // chunk 2 h + (dt >> 1): [h 32 | l 32]
-                        d2[0] = *(const uint16_t *)&hh;
-                        d2[32] = *(const uint16_t *)&ll;
-                    }
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint32_t ph0, pl0, ph1, pl1;
+                    split2(o[dt][0] * inv, o[dt][1] * inv, ph0, pl0);
+                    split2(o[dt][2] * inv, o[dt][3] * inv, ph1, pl1);
+                    uint16_t *d2 = dst + (dt >> 1) * 64 + (dt & 1) * 16;          // chunk 2 h + (dt >> 1): [h 32 | l 32]
+                    *(uint2 *)d2 = make_uint2(ph0, ph1);
+                    *(uint2 *)(d2 + 32) = make_uint2(pl0, pl1);
                 }
             }
         }

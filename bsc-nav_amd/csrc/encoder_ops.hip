@@ -764,21 +764,20 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
                 for (int dt = 0; dt < 4; ++dt) {
                     const uint2 v0 = *(const uint2 *)(v0p[dt] + 32 * ks), v1 = *(const uint2 *)(v1p[dt] + 32 * ks);
                     uint4 vb = make_uint4(v0.x, v0.y, v1.x, v1.y);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *(bf16x8_t *)&vb, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8_t *)&vb, a, o[dt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // o[dt][i] = O[query q0 + 4g + i][d = 16 dt + n]; the row sums sit with the lanes whose n is that query
+            // V^T is the FIRST operand: o[dt][i] = O^T[d = 16 dt + 4 g + i][query q0 + n] — the lane that holds a query's row sum holds
+            // its outputs, four consecutive features per accumulator: 8-byte stores, no shuffles (with the queries along the
+            // registers the epilogue was 16 two-byte stores + 4 shuffles per lane and strip: 40 % of the kernel's time)
             const float inv = 1.f / sum;
+            const int q = q0 + n;
+            if (q < T) {
+                uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = __shfl(inv, g * 4 + i);
-                const int q = q0 + g * 4 + i;
-                if (q < T) {
-                    uint16_t *dst = out + ((int64_t)b * T + q) * H * 64 + (int64_t)h * 64 + n;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (uint16_t)(pack_bf16(o[dt][i] * r, 0.f) & 0xffffu);
-                }
+                for (int dt = 0; dt < 4; ++dt)
+                    *(uint2 *)(dst + dt * 16) = make_uint2(pack_bf16(o[dt][0] * inv, o[dt][1] * inv), pack_bf16(o[dt][2] * inv, o[dt][3] * inv));
             }
         }
     }
