@@ -155,7 +155,8 @@ struct bsc_ctx {
     uint32_t *l_sel_val[2];
     u64 *l_sel_thr;      // per-query threshold keys of the sample selection
     int32_t *l_sel_cnt;  // per-query survivor counts
-    int64_t l_sel_cap[6];
+    uint32_t *l_valid;   // one bit per dense row: the row holds points (what the filter needs of acnt)
+    int64_t l_sel_cap[7];
     int32_t *l_out_pos;
     float *l_out_sim;
     bool names_dirty;

@@ -310,7 +310,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_qp, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
-                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
+                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->l_valid, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
                     x->fr_centers, x->fr_gains, x->log_cell, x->log_rec, x->stage_cell, x->stage_pos};
     for (void *p : ptrs)

@@ -629,6 +629,15 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
         const int q = wi / nb, bx = wi - q * nb;
         const int64_t nn = n_per_q ? min((int64_t)n_per_q[q * SEL_CNT_PAD], n) : n;
         const int64_t base = (int64_t)bx * TK_N;
+        if (base >= nn) {
+            // nothing in this slice (survivor lists are sized for the worst case: ~6 400 of 32 768 slots hold a candidate at K = 100,
+            // so 25 of a query's 32 first-round slices are empty): no sort, K empty winners
+            for (int e = (int)threadIdx.x; e < K; e += TPB) {
+                out_keys[(int64_t)q * out_stride + (int64_t)bx * K + e] = ~0ull;
+                out_vals[(int64_t)q * out_stride + (int64_t)bx * K + e] = 0u;
+            }
+            continue;
+        }
         u64 key[4];
         uint32_t val[4];
 #pragma unroll
@@ -656,10 +665,18 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
 // so only candidates at least that good can be in the answer; they are appended (unordered) to a short survivor list
 #define FILT_PER_BLOCK 4096
 #define FILT_G (FILT_PER_BLOCK / (4 * TPB))
+// bit c of the map: candidate c (a dense row) holds points.  The filter reads a query's similarities once and, per 16 of them, two
+// bytes of this map instead of 64 bytes of counts.
+__global__ __launch_bounds__(TPB) void k_valid_bits(const int32_t *__restrict__ cnt, int n, uint32_t *__restrict__ bits)
+{
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    const u64 b = __ballot(c < n && cnt[c < n ? c : 0] > 0);
+    if ((threadIdx.x & 63) == 0) *(u64 *)(bits + 2 * (c >> 6)) = b;
+}
 __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__restrict__ sims, int64_t sims_stride,
                                                      const u64 *__restrict__ thr_keys, int K, int cap,
                                                      u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
-                                                     int32_t *__restrict__ counts, int nbf, int nq)
+                                                     int32_t *__restrict__ counts, int nbf, int nq, const uint32_t *__restrict__ valid)
 {
   for (int wi = blockIdx.x; wi < nbf * nq; wi += gridDim.x) {
     const int q = wi / nbf, bx = wi - q * nbf;
@@ -676,11 +693,11 @@ __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__
         const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
         if (fast && c0 + 3 < a.max_id) {
             const float4 sv = *(const float4 *)(qs + c0);
-            const int4 cv = *(const int4 *)(a.cnt + c0);
-            sk[g][0] = cv.x > 0 ? float_desc_key(sv.x) : 0xffffffffu;
-            sk[g][1] = cv.y > 0 ? float_desc_key(sv.y) : 0xffffffffu;
-            sk[g][2] = cv.z > 0 ? float_desc_key(sv.z) : 0xffffffffu;
-            sk[g][3] = cv.w > 0 ? float_desc_key(sv.w) : 0xffffffffu;
+            const uint32_t vb = valid[c0 >> 5] >> (c0 & 31);            // c0 is a multiple of 4: its four bits sit in one word
+            sk[g][0] = (vb & 1u) ? float_desc_key(sv.x) : 0xffffffffu;
+            sk[g][1] = (vb & 2u) ? float_desc_key(sv.y) : 0xffffffffu;
+            sk[g][2] = (vb & 4u) ? float_desc_key(sv.z) : 0xffffffffu;
+            sk[g][3] = (vb & 8u) ? float_desc_key(sv.w) : 0xffffffffu;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) sk[g][k] = cand_simkey(a, c0 + k, qs);
@@ -815,9 +832,15 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
                            x->l_sel_thr, x->l_sel_cnt);
         cur = 0;
         const unsigned nbf = (unsigned)(((int64_t)ca.n_cand + FILT_PER_BLOCK - 1) / FILT_PER_BLOCK);
+        if (!ca.exact) {
+            const int64_t words = 2 * (((int64_t)ca.max_id + 63) / 64) + 2;
+            BSC_TRY(grow_dev((void **)&x->l_valid, &x->l_sel_cap[6], sizeof(uint32_t) * words));
+            if (ca.max_id > 0)
+                hipLaunchKernelGGL(k_valid_bits, dim3((unsigned)((ca.max_id + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, ca.cnt, ca.max_id, x->l_valid);
+        }
         hipLaunchKernelGGL(k_cand_filter, dim3(nbf * (unsigned)nq < 16384u ? nbf * (unsigned)nq : 16384u), dim3(TPB), 0, x->stream, ca, x->l_sims,
                            sims_stride, x->l_sel_thr, K, SEL_SURVIVOR_CAP, x->l_sel_key[0], x->l_sel_val[0],
-                           x->l_sel_cnt, (int)nbf, nq);
+                           x->l_sel_cnt, (int)nbf, nq, (const uint32_t *)x->l_valid);
         // survivors of query q sit at [q * CAP, q * CAP + count); the rounds use stride CAP for them
         BSC_TRY(bitonic_rounds(x, nq, SEL_SURVIVOR_CAP, x->l_sel_cnt, K, SEL_SURVIVOR_CAP, &cur));
         stride = SEL_SURVIVOR_CAP;
