@@ -379,6 +379,16 @@ __device__ __forceinline__ void aa_taps(int o, float scale, int in_size, int &lo
     for (int i = 0; i < PP_TAPS; ++i) w[i] *= inv;
 }
 
+// first tap and tap count of output index o alone (the same arithmetic as aa_taps)
+__device__ __forceinline__ void aa_bounds(int o, float scale, int in_size, int &lo, int &n)
+{
+    const float support = scale >= 1.f ? scale : 1.f;
+    const float center = scale * ((float)o + 0.5f);
+    lo = max((int)(center - support + 0.5f), 0);
+    const int hi = min((int)(center + support + 0.5f), in_size);
+    n = min(hi - lo, PP_TAPS);
+}
+
 // one element of the unfolded patch matrix (row, k of K): mode 0 bf16, 1 f32, 2 fp16 pieces in the chunk-interleaved layout of the
 // split-operand GEMM (encoder_gemm.hip: row = K / 32 chunks of [32 h | 32 l]; K % 32 == 0)
 __device__ __forceinline__ void pp_store(void *out, int mode, int64_t row, int K, int k, float v)
@@ -474,34 +484,89 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches_tiled(const uint32_t
     const int g = S / p;
     const int patch = blockIdx.x % (g * g), b = blockIdx.x / (g * g);
     const int gy = patch / g, gx = patch % g;
-    // window = union of the taps of the patch's first and last output row / column (taps are monotone in the output index)
-    const int y_lo = ty[gy * p].lo, x_lo = tx[gx * p].lo;
-    const int win_h = ty[gy * p + p - 1].lo + ty[gy * p + p - 1].n - y_lo;
-    const int win_w = tx[gx * p + p - 1].lo + tx[gx * p + p - 1].n - x_lo;
+    // window = union of the taps of the patch's first and last output row / column (taps are monotone in the output index);
+    // its bounds are computed, not read from the tap table: the window loads and the thread's tap weights then leave in ONE round
+    // trip (read from the table first, the bounds cost a dependent trip of their own ahead of the window's)
+    int y_lo, x_lo, lo_l, n_l;
+    aa_bounds(gy * p, (float)H / (float)S, H, y_lo, n_l);
+    aa_bounds(gy * p + p - 1, (float)H / (float)S, H, lo_l, n_l);
+    const int win_h = lo_l + n_l - y_lo;
+    aa_bounds(gx * p, (float)W / (float)S, W, x_lo, n_l);
+    aa_bounds(gx * p + p - 1, (float)W / (float)S, W, lo_l, n_l);
+    const int win_w = lo_l + n_l - x_lo;
     const uint32_t *img = rgba + (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < win_h * win_w; i += TPB) {
-        const int r = i / win_w, c = i - r * win_w;
-        tile[r][c] = img[(int64_t)(y_lo + r) * W + x_lo + c];
+    // TPB % p == 0: all (window row, output column) items of a thread share the output column, i.e. one set of column weights
+    const PpTap wx_mine = tx[gx * p + (int)threadIdx.x % p];
+    const PpTap wy_mine = ty[gy * p + ((int)threadIdx.x < p * p ? (int)threadIdx.x / p : 0)];
+    {
+        // one wavefront per window row, the lane is the column (PPT_MAXW = 64): every load of the window is issued before the first
+        // LDS store (as a loop of load -> store the window cost one memory round trip per 256 pixels, 8-9 in a row: the kernel's time)
+        const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+        uint32_t v[PPT_MAXH / (TPB / 64)];
+#pragma unroll
+        for (int j = 0; j < PPT_MAXH / (TPB / 64); ++j) {
+            const int r = r0 + (TPB / 64) * j;
+            const bool in = r < win_h && c < win_w;
+            v[j] = in ? img[(int64_t)(y_lo + r) * W + x_lo + c] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT_MAXH / (TPB / 64); ++j) {
+            const int r = r0 + (TPB / 64) * j;
+            if (r < win_h && c < win_w) tile[r][c] = v[j];
+        }
     }
     __syncthreads();
+    // The row sums r(input row, output column) = sum_k wx[k] * pixel do not depend on the output ROW: every (window row, output
+    // column) pair is evaluated once (win_h * p of them, ~3 per thread) and shared through LDS by the p output rows that weigh it —
+    // the same products and the same summation order as one thread per output pixel doing all its yn x TXN taps (bit-identical
+    // results), at 40 % of the vector instructions: the kernel was bound by them (0.365 ms for 0.6 GB of traffic).
+    __shared__ float hs[PPT_MAXH][3][16 + 1];
+    const bool shared_rows = p <= 16 && TPB % p == 0;
+    if (shared_rows) {
+        for (int i = threadIdx.x; i < win_h * p; i += TPB) {
+            const int r = i / p, px = i - r * p;
+            const uint32_t *row = &tile[r][wx_mine.lo - x_lo];
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < TXN; ++k) {                 // weights beyond n are zero
+                const uint32_t v = row[k < wx_mine.n ? k : 0];
+                r0 += wx_mine.w[k] * (float)(v & 0xffu);
+                r1 += wx_mine.w[k] * (float)((v >> 8) & 0xffu);
+                r2 += wx_mine.w[k] * (float)((v >> 16) & 0xffu);
+            }
+            hs[r][0][px] = r0; hs[r][1][px] = r1; hs[r][2][px] = r2;
+        }
+        __syncthreads();
+    }
     if ((int)threadIdx.x >= p * p) return;
     const int py = threadIdx.x / p, px = threadIdx.x - py * p;
-    const PpTap *wyp = &ty[gy * p + py];            // its weights are read in the row loop (dynamic index)
-    const PpTap wx = tx[gx * p + px];
-    const int yn = wyp->n, ylo = wyp->lo;
+    const PpTap *wyp = &ty[gy * p + py];            // the generic path reads its weights in the row loop (dynamic index)
+    const int yn = wy_mine.n, ylo = wy_mine.lo;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int i = 0; i < yn; ++i) {
-        const uint32_t *row = &tile[ylo - y_lo + i][wx.lo - x_lo];
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (shared_rows) {
 #pragma unroll
-        for (int k = 0; k < TXN; ++k) {                 // weights beyond n are zero
-            const uint32_t v = row[k < wx.n ? k : 0];
-            r0 += wx.w[k] * (float)(v & 0xffu);
-            r1 += wx.w[k] * (float)((v >> 8) & 0xffu);
-            r2 += wx.w[k] * (float)((v >> 16) & 0xffu);
+        for (int i = 0; i < PP_TAPS; ++i) {
+            if (i < yn) {
+                const float wyi = wy_mine.w[i];
+                const int r = ylo - y_lo + i;
+                a0 += wyi * hs[r][0][px]; a1 += wyi * hs[r][1][px]; a2 += wyi * hs[r][2][px];
+            }
         }
-        const float wyi = wyp->w[i];
-        a0 += wyi * r0; a1 += wyi * r1; a2 += wyi * r2;
+    } else {
+        const PpTap wx = tx[gx * p + px];
+        for (int i = 0; i < yn; ++i) {
+            const uint32_t *row = &tile[ylo - y_lo + i][wx.lo - x_lo];
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < TXN; ++k) {                 // weights beyond n are zero
+                const uint32_t v = row[k < wx.n ? k : 0];
+                r0 += wx.w[k] * (float)(v & 0xffu);
+                r1 += wx.w[k] * (float)((v >> 8) & 0xffu);
+                r2 += wx.w[k] * (float)((v >> 16) & 0xffu);
+            }
+            const float wyi = wyp->w[i];
+            a0 += wyi * r0; a1 += wyi * r1; a2 += wyi * r2;
+        }
     }
     const int64_t row = (int64_t)b * g * g + patch;
     pp_store(out, mode, row, 3 * p * p, py * p + px, (a0 * (1.f / 255.f) - m0) / s0);
