@@ -869,34 +869,41 @@ __global__ __launch_bounds__(64 * NW) void k_attention(const uint16_t *__restric
 //   O^T (64 x 32 queries) = V^T . P^T                  the accumulators ARE the B operand if a 16-key step takes its contraction
 //        index in accumulator order: step (t, jp) = registers 8 jp .. 8 jp + 7 = keys 32 t + 16 jp + {0..3, 8..11} + 4 hh;
 //        V^T is read in that order (two 8-byte reads per lane and step)
-// Staging: a thread owns PAIRS of consecutive tokens, so V^T (row = feature, column = key) is written two keys at a time (4-byte
-// stores); its row pitch is 4 x odd elements: the 32 feature rows a fragment read touches fall into 32 different bank pairs.
+// Staging: a thread owns FOUR consecutive tokens of one 16-byte piece, so V^T (row = feature, column = key) is written four keys at
+// a time (8-byte stores); its row pitch is 4 x odd elements: the 32 feature rows a fragment read touches fall into 32 different
+// bank pairs.  Q goes from global memory straight into the B-operand registers of its wavefront (no LDS copy).
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-template <int NLP, int NTHR>
-__device__ __forceinline__ void att32_issue_loads(typename u32vec<8 * NLP>::type &k8, typename u32vec<8 * NLP>::type &v8,
-                                                  typename u32vec<8 * NLP>::type &q8, const uint16_t *__restrict__ qkv,
-                                                  int item, int T, int H, int tid)
+// One of the 12 global loads of a thread for an (image, head) item: J = 0..3 the K rows of its token group (4 consecutive tokens,
+// one 16-byte piece each), 4..7 the V rows, 8..11 the four k-steps of its wavefront's Q fragment (straight in MFMA operand layout:
+// Q never visits LDS).  Separate calls so that they can be placed between the MFMAs of Q.K^T.
+template <int J>
+__device__ __forceinline__ void att32_load_one(u32vec<16>::type &k8, u32vec<16>::type &v8, u32vec<16>::type &bqn,
+                                               const uint16_t *__restrict__ qkv, int item, int T, int H, int tid)
 {
     const int64_t tok_stride = (int64_t)3 * H * 64;
     const int b = item / H, h = item % H;
     const uint16_t *Qp = qkv + (int64_t)b * T * tok_stride + (int64_t)h * 64;
-    const uint16_t *Kp = Qp + (int64_t)H * 64, *Vp = Qp + (int64_t)2 * H * 64;
-#pragma unroll
-    for (int r = 0; r < NLP; ++r) {
-        const int idx = tid + NTHR * r;
-        const int tp = idx >> 3, ch = idx & 7;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = 2 * tp + u, tc = t < T ? t : T - 1;
-            const uint4 k = *(const uint4 *)(Kp + (int64_t)tc * tok_stride + ch * 8);
-            const uint4 v = *(const uint4 *)(Vp + (int64_t)tc * tok_stride + ch * 8);
-            const uint4 q = *(const uint4 *)(Qp + (int64_t)tc * tok_stride + ch * 8);
-            const int o = 8 * r + 4 * u;
-            k8[o] = k.x; k8[o + 1] = k.y; k8[o + 2] = k.z; k8[o + 3] = k.w;
-            v8[o] = v.x; v8[o + 1] = v.y; v8[o + 2] = v.z; v8[o + 3] = v.w;
-            q8[o] = q.x; q8[o + 1] = q.y; q8[o + 2] = q.z; q8[o + 3] = q.w;
-        }
+    if (J < 8) {
+        const int tg = tid >> 3, ch = tid & 7, t = 4 * tg + (J & 3), tc = t < T ? t : T - 1;
+        const uint16_t *src = Qp + (int64_t)(J < 4 ? 1 : 2) * H * 64 + (int64_t)tc * tok_stride + ch * 8;
+        const uint4 v = *(const uint4 *)src;
+        const int o = 4 * (J & 3);
+        if (J < 4) { k8[o] = v.x; k8[o + 1] = v.y; k8[o + 2] = v.z; k8[o + 3] = v.w; }
+        else { v8[o] = v.x; v8[o + 1] = v.y; v8[o + 2] = v.z; v8[o + 3] = v.w; }
+    } else {
+        const int lane = tid & 63, q = (tid >> 6) * 32 + (lane & 31), qc = q < T ? q : T - 1, kk = J - 8;
+        const uint4 v = *(const uint4 *)(Qp + (int64_t)qc * tok_stride + kk * 16 + (lane >> 5) * 8);
+        bqn[4 * kk] = v.x; bqn[4 * kk + 1] = v.y; bqn[4 * kk + 2] = v.z; bqn[4 * kk + 3] = v.w;
+    }
+}
+template <int J0, int J1>
+__device__ __forceinline__ void att32_load_range(u32vec<16>::type &k8, u32vec<16>::type &v8, u32vec<16>::type &bqn,
+                                                 const uint16_t *__restrict__ qkv, int item, int T, int H, int tid)
+{
+    if constexpr (J0 < J1) {
+        att32_load_one<J0>(k8, v8, bqn, qkv, item, T, H, tid);
+        att32_load_range<J0 + 1, J1>(k8, v8, bqn, qkv, item, T, H, tid);
     }
 }
 
@@ -907,16 +914,15 @@ __global__ __launch_bounds__(64 * NW) void k_attention32(const uint16_t *__restr
     __shared__ int s_ticket;
     constexpr int NTHR = 64 * NW;
     constexpr int TP = NT2 * 32;
-    constexpr int KP = 64 + 8;                              // K / Q row pitch (bf16 elements)
+    static_assert(TP * 2 == NTHR && NT2 >= 6, "one (4-token group, 16-byte piece) item per thread; six key tiles carry the next item's loads");
+    constexpr int KP = 64 + 8;                              // K row pitch (bf16 elements)
     constexpr int VP = TP + 4;                              // V^T row pitch: 4 x odd
-    constexpr int NLP = (TP * 4 + NTHR - 1) / NTHR;         // (token pair, 16-byte piece) items per thread
     __shared__ __attribute__((aligned(16))) uint16_t sK[TP * KP];
-    __shared__ __attribute__((aligned(16))) uint16_t sQ[TP * KP];
     __shared__ __attribute__((aligned(16))) uint16_t sVt[64 * VP + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 31, hh = lane >> 5;
     const float c = 0.125f * 1.44269504088896340736f;               // 1/sqrt(64) * log2(e)
-    typename u32vec<8 * NLP>::type k8, v8, q8;
+    u32vec<16>::type k8, v8, bqn;
 
     int item = blockIdx.x;
     if (work) {
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention32(const uint16_t *__restr
         __syncthreads();
         item = s_ticket;
     }
-    att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, item < items ? item : items - 1, T, H, tid);
+    att32_load_range<0, 12>(k8, v8, bqn, qkv, item < items ? item : items - 1, T, H, tid);
     int nxt = item;
 #ifdef BSC_ATT_PROFILE
     long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
@@ -937,37 +943,40 @@ __global__ __launch_bounds__(64 * NW) void k_attention32(const uint16_t *__restr
         const int b = item / H, h = item % H;
         __syncthreads();                                            // the previous item's strips are done with LDS
         ATT_T(0)
+        {
+            // the thread's token group: K rows as they are, V transposed four tokens at a time (8-byte stores)
+            const int tg = tid >> 3, ch = tid & 7, t0 = 4 * tg;
+            uint32_t keep[4];
 #pragma unroll
-        for (int r = 0; r < NLP; ++r) {
-            const int idx = tid + NTHR * r;
-            const int tp = idx >> 3, ch = idx & 7;
-            if (idx < TP * 4) {
-                const int t0 = 2 * tp;
-                const uint32_t keep0 = t0 < T ? 0xffffffffu : 0u, keep1 = t0 + 1 < T ? 0xffffffffu : 0u;    // padded keys: zero rows
-                *(uint4 *)&sK[t0 * KP + ch * 8] = make_uint4(k8[8 * r] & keep0, k8[8 * r + 1] & keep0, k8[8 * r + 2] & keep0, k8[8 * r + 3] & keep0);
-                *(uint4 *)&sK[(t0 + 1) * KP + ch * 8] = make_uint4(k8[8 * r + 4] & keep1, k8[8 * r + 5] & keep1, k8[8 * r + 6] & keep1, k8[8 * r + 7] & keep1);
-                *(uint4 *)&sQ[t0 * KP + ch * 8] = make_uint4(q8[8 * r], q8[8 * r + 1], q8[8 * r + 2], q8[8 * r + 3]);
-                *(uint4 *)&sQ[(t0 + 1) * KP + ch * 8] = make_uint4(q8[8 * r + 4], q8[8 * r + 5], q8[8 * r + 6], q8[8 * r + 7]);
+            for (int u = 0; u < 4; ++u) keep[u] = t0 + u < T ? 0xffffffffu : 0u;          // padded keys: zero rows
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t w0 = v8[8 * r + e] & keep0, w1 = v8[8 * r + 4 + e] & keep1;     // features 2e, 2e+1 of the piece, tokens t0 / t0+1
-                    *(uint32_t *)&sVt[(ch * 8 + 2 * e) * VP + t0] = (w0 & 0xffffu) | (w1 << 16);
-                    *(uint32_t *)&sVt[(ch * 8 + 2 * e + 1) * VP + t0] = (w0 >> 16) | (w1 & 0xffff0000u);
-                }
+            for (int u = 0; u < 4; ++u)
+                *(uint4 *)&sK[(t0 + u) * KP + ch * 8] = make_uint4(k8[4 * u] & keep[u], k8[4 * u + 1] & keep[u], k8[4 * u + 2] & keep[u], k8[4 * u + 3] & keep[u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                           // features 2e, 2e+1 of the piece
+                const uint32_t w0 = v8[e] & keep[0], w1 = v8[4 + e] & keep[1], w2 = v8[8 + e] & keep[2], w3 = v8[12 + e] & keep[3];
+                *(uint2 *)&sVt[(ch * 8 + 2 * e) * VP + t0] = make_uint2((w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16));
+                *(uint2 *)&sVt[(ch * 8 + 2 * e + 1) * VP + t0] = make_uint2((w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u));
             }
         }
         if (work && tid == 0) s_ticket = atomicAdd(&work[0], 1);    // everyone has read the previous ticket (barrier above)
         __syncthreads();
         nxt = work ? s_ticket : item + (int)gridDim.x;
+        const int nxc = nxt < items ? nxt : items - 1;
         ATT_T(1)
         const int q0 = wave * 32;
-        if (q0 >= T) {
-            att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
-            continue;
-        }
         bf16x8_t bq[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) bq[kk] = *(const bf16x8_t *)&sQ[(q0 + nl) * KP + kk * 16 + hh * 8];
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 v = make_uint4(bqn[4 * kk], bqn[4 * kk + 1], bqn[4 * kk + 2], bqn[4 * kk + 3]);
+            bq[kk] = *(const bf16x8_t *)&v;
+        }
+        if (q0 >= T) {
+            att32_load_range<0, 12>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            continue;
+        }
+        // Q.K^T with the next item's 12 loads spread between its MFMAs (requested in one burst by all wavefronts they queued at the
+        // texture path: ~2 k clocks per item on the slowest wavefront)
         f32x16_t acc[NT2];
 #pragma unroll
         for (int t = 0; t < NT2; ++t) {
@@ -978,15 +987,18 @@ __global__ __launch_bounds__(64 * NW) void k_attention32(const uint16_t *__restr
                 const bf16x8_t a = *(const bf16x8_t *)&sK[(t * 32 + nl) * KP + kk * 16 + hh * 8];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[kk], acc[t], 0, 0, 0);
             }
+            if (t == 0) att32_load_range<0, 2>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            if (t == 1) att32_load_range<2, 4>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            if (t == 2) att32_load_range<4, 6>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            if (t == 3) att32_load_range<6, 8>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            if (t == 4) att32_load_range<8, 10>(k8, v8, bqn, qkv, nxc, T, H, tid);
+            if (t == 5) att32_load_range<10, 12>(k8, v8, bqn, qkv, nxc, T, H, tid);
             __builtin_amdgcn_sched_barrier(0);                      // keep the K fragment loads of later tiles behind these MFMAs
         }
+        ATT_T(3)
+        ATT_T(2)
         // padded keys leave the softmax with -inf: only the last two tiles can hold any (the lane's limit is made opaque: left
         // loop-invariant the comparisons turn into scalar mask pairs that do not fit the SGPR file)
-        ATT_T(3)
-        // the next item's K, V, Q rows: requested here, behind the wavefront's own Q.K^T (the wavefronts then reach the texture
-        // path at different times instead of queueing 84 load instructions at the barrier), in flight during softmax and P.V
-        att32_issue_loads<NLP, NTHR>(k8, v8, q8, qkv, nxt < items ? nxt : items - 1, T, H, tid);
-        ATT_T(2)
         int lim = T - hh * 4;
         asm volatile("" : "+v"(lim));
         if (T > 32 * (NT2 - 2)) {
