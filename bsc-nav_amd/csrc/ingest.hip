@@ -246,7 +246,9 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 if (alpha_in) alpha = alpha_in[j];
                 ralo[r] = (uint32_t)__double2loint(alpha);
                 rahi[r] = (uint32_t)__double2hiint(alpha);
-                rrgb[r] = (uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16);
+                // RGBA frames: the pixel's three colour bytes come with one aligned 32-bit gather instead of three byte gathers
+                rrgb[r] = rgb_ch == 4 ? (*(const uint32_t *)pv & 0xffffffu)
+                                      : ((uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16));
             }
         }
         cells[r] = cell;
