@@ -160,6 +160,33 @@ def test_fused_preprocess_matches_torch_interpolate(hw):
     assert err.mean().item() < 0.004
 
 
+@pytest.mark.parametrize("hw,S,p", [((480, 640), 224, 16), ((240, 320), 224, 16), ((480, 640), 224, 14), ((300, 300), 224, 16)])
+def test_tiled_preprocess_equals_generic_kernel_bit_for_bit(hw, S, p):
+    """k_preprocess_patches_tiled (RGBA frames: window in LDS, row sums shared by the output rows, window bounds computed inline)
+    against the generic one-thread-per-output-pixel kernel (RGB frames): the same taps, weights and summation order — f32 outputs
+    must be identical bit for bit, for patch sizes that divide the workgroup (16: shared row sums) and that do not (14)."""
+    import ctypes as C
+    import torch
+    from bsc_nav_amd import _lib, encoder
+    H, W = hw
+    g = S // p
+    torch.manual_seed(H + W + p)
+    rgb3 = torch.randint(0, 256, (2, H, W, 3), dtype=torch.uint8, device="cuda")
+    rgba = torch.cat([rgb3, torch.full((2, H, W, 1), 255, dtype=torch.uint8, device="cuda")], dim=-1).contiguous()
+    mean = (C.c_float * 3)(*encoder.IMAGENET_MEAN)
+    std = (C.c_float * 3)(*encoder.IMAGENET_STD)
+    outs = []
+    for img, ch in ((rgb3, 3), (rgba, 4)):
+        out = torch.empty((2, g * g, 3 * p * p), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.load().bsc_enc_preprocess_patches_typed(C.c_void_p(img.data_ptr()), 2, H, W, ch, S, p,
+                                                                C.c_void_p(out.data_ptr()), 1, mean, std,
+                                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max().item() > 1.0
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_long_memory_matches_reference(tmp_path):
     """long_memory + long_memory_integration (memory_2.py:905-945, 993-1025) with seeded detector boxes: same objects,
     same voxel locations, same confidences, frame by frame."""
