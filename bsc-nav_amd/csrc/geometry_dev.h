@@ -125,14 +125,15 @@ __device__ __forceinline__ double div_by_const(double x, double c, double rc)
     return __fma_rn(__fma_rn(-c, q, x), rc, q);
 }
 
-__device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
-                                                GeomFastOut &o, bool want_alpha)
+// tx, ty: the patch column / row of the pixel (c.pat_x[x], c.pat_y[y]; 255 = outside), fetched by the caller — k_points reads
+// them for all its rounds ahead of the geometry so that no round waits for a table lookup
+__device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
+                                                  GeomFastOut &o, bool want_alpha, uint32_t tx, uint32_t ty)
 {
     o.cell = -1;
     const double px = (double)x + 0.5, py = (double)y + 0.5;
     const double z = (double)zf;
     if (!((z > c.min_depth) && (z < c.max_depth))) return;
-    const uint32_t tx = c.pat_x[x], ty = c.pat_y[y];
     if (tx == 255u || ty == 255u) return;                       // memory_2.py:878 patch range
     o.patch = ty * (uint32_t)c.g + tx;
     const double p0 = __dmul_rn(__dadd_rn(__dmul_rn(c.Kinv[0], px), c.Kinv[2]), z);
@@ -161,4 +162,10 @@ __device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, i
     o.r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(z, z));
     o.alpha = want_alpha ? exp(div_by_const(-o.r2, 1.2, 1.0 / 1.2)) : 0.0;
     o.cell = (row * c.gs + col) * c.nh + (h - c.min_h);
+}
+
+__device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
+                                                GeomFastOut &o, bool want_alpha)
+{
+    geom_point_fast_t(c, x, y, zf, T, o, want_alpha, c.pat_x[x], c.pat_y[y]);
 }

@@ -92,10 +92,12 @@ __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
     return v;
 }
 
-// LDS accesses of ONE wavefront execute in program order; this keeps the compiler from reordering them
+// LDS accesses of ONE wavefront execute in program order; this keeps the compiler from reordering them.  The fence names the LDS
+// address space: as a fence over ALL memory it was lowered to s_waitcnt vmcnt(0) — three times per round of 64 points k_points
+// then sat out the round trips of its depth load, colour gather and cell store (4.7 k clocks per round for ~1 k of issue).
 __device__ __forceinline__ void wave_lds_order()
 {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -175,14 +177,25 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         for (int k = 0; k < 12; ++k) T[k] = Tv[k];
     }
     int32_t cells[RPW];
-    uint32_t sr[RPW], ralo[RPW], rahi[RPW], rrgb[RPW];
+    uint32_t sr[RPW], ralo[RPW], rahi[RPW];
     int ovf_cnt = 0;
+#ifdef BSC_POINTS_PROFILE
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tq = clock64();
+#define PT_T(k) { const long long now_ = clock64(); tph[k] += now_ - tq; tq = now_; }
+#else
+#define PT_T(k)
+#endif
+    // Frame, pixel and depth of the lane's point of EVERY round first: the rounds below then start from registers.  (Loaded round
+    // by round, each round sat out three memory round trips in a row — its depth, the completion of its cell store ahead of the
+    // colour gather, the gather itself: 4.7 k clocks per round for ~1 k clocks of instruction issue.)
+    int fr[RPW];
+    int32_t ir[RPW];
+    float zr[RPW];
+    uint32_t xy[RPW], tp[RPW];                      // fast geometry: pixel (x | y << 16), patch column | row << 8 of the pixel
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const int p_local = wv * RPW * 64 + r * 64 + lane;
-        const int64_t j = blk_base + p_local;
-        int32_t cell = -2;
-        ralo[r] = rahi[r] = rrgb[r] = 0u;
+        const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
+        fr[r] = 0; ir[r] = 0; zr[r] = 0.f; xy[r] = 0u; tp[r] = 0xffffu;
         if (j < P) {
             int f;
             int32_t i;
@@ -203,24 +216,47 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 f = fb;
                 i = ib;
             }
-            const float z = depth[(int64_t)f * N + i];
-            if (f != fT) {
-                const double *Tv = transforms + 16 * (int64_t)f;
+            fr[r] = f; ir[r] = i;
+            zr[r] = depth[(int64_t)f * N + i];
+            if (FAST) {
+                // y = i / W without an integer division: float estimate (exact operands below 2^24), corrected by one
+                int32_t y = (int32_t)((float)i * inv_w);
+                int32_t x = i - y * gc.W;
+                if (x < 0) { --y; x += gc.W; } else if (x >= gc.W) { ++y; x -= gc.W; }
+                xy[r] = (uint32_t)x | ((uint32_t)y << 16);
+                tp[r] = (uint32_t)gc.pat_x[x] | ((uint32_t)gc.pat_y[y] << 8);
+            }
+        }
+    }
+    uint32_t raw0[RPW], raw1[RPW];                  // colour gathers, consumed after the rounds
+    const bool rgb4 = rgb_ch == 4;
+    PT_T(0)
 #pragma unroll
-                for (int k = 0; k < 12; ++k) T[k] = Tv[k];
-                fT = f;
+    for (int r = 0; r < RPW; ++r) {
+        const int p_local = wv * RPW * 64 + r * 64 + lane;
+        const int64_t j = blk_base + p_local;
+        int32_t cell = -2;
+        ralo[r] = rahi[r] = 0u;
+        int64_t pix_off = 0;                        // byte offset of the colour the point samples (0: none — a harmless read)
+        if (j < P) {
+            const int f = fr[r];
+            const int32_t i = ir[r];
+            const float z = zr[r];
+            if (__ballot(f != fT)) {                // wave-uniform: the transform is re-read only by a wavefront that crosses a frame
+                if (f != fT) {
+                    const double *Tv = transforms + 16 * (int64_t)f;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) T[k] = Tv[k];
+                    fT = f;
+                }
             }
             int32_t sx = 0, sy = 0;
             uint32_t patch = 0;
             double r2 = 0.0, alpha = 0.0;
             cell = -1;
             if (FAST) {
-                // y = i / W without an integer division: float estimate (exact operands below 2^24), corrected by one
-                int32_t y = (int32_t)((float)i * inv_w);
-                int32_t x = i - y * gc.W;
-                if (x < 0) { --y; x += gc.W; } else if (x >= gc.W) { ++y; x -= gc.W; }
                 GeomFastOut o;
-                geom_point_fast(gc, x, y, z, T, o, alpha_in == nullptr);
+                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, tp[r] & 0xffu, tp[r] >> 8);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
             } else {
@@ -240,18 +276,20 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             }
             p_cell[j] = cell;
             if (cell >= 0) {
-                const uint8_t *pv = rgb + ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
+                pix_off = ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
                 if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
                 if (p_r2f) p_r2f[j] = (float)r2;      // memory_2.py:885 grid_feat_dis is float32 (token cache only)
                 if (alpha_in) alpha = alpha_in[j];
                 ralo[r] = (uint32_t)__double2loint(alpha);
                 rahi[r] = (uint32_t)__double2hiint(alpha);
-                // RGBA frames: the pixel's three colour bytes come with one aligned 32-bit gather instead of three byte gathers
-                rrgb[r] = rgb_ch == 4 ? (*(const uint32_t *)pv & 0xffffffu)
-                                      : ((uint32_t)pv[0] | ((uint32_t)pv[1] << 8) | ((uint32_t)pv[2] << 16));
             }
         }
+        // the colour gather of every lane, unconditionally and unprocessed: nothing below needs it before the records are written,
+        // so its round trip runs under the following rounds (RGBA frames: one aligned 32-bit gather; RGB: 16 + 8 bits)
+        if (rgb4) { raw0[r] = *(const uint32_t *)(rgb + pix_off); raw1[r] = 0u; }
+        else { raw0[r] = (uint32_t)rgb[pix_off] | ((uint32_t)rgb[pix_off + 1] << 8); raw1[r] = (uint32_t)rgb[pix_off + 2]; }
         cells[r] = cell;
+        PT_T(1)
         // ---- slot of the cell, rank of the point among the wavefront's points of that cell --------------------------------
         uint32_t e = GROUP_OVF;
         if (cell >= 0) {
@@ -286,8 +324,10 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         if (!grouped) lr = (uint32_t)ovf_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
         ovf_cnt += __popcll(om);
         sr[r] = cell >= 0 ? (e | (lr << 16)) : 0xffffffffu;
+        PT_T(2)
     }
     __syncthreads();
+    PT_T(3)
     // ---- group sizes -> positions: exclusive prefix over the slots (points | runs << 16), then over the wavefronts ----------
     if (lane == 0) s_ovf[wv] = ovf_cnt;
     uint32_t v[EPT], tv = 0;
@@ -342,6 +382,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         n_ovf += c;
     }
     const uint32_t n_valid = n_grouped + n_ovf;
+    PT_T(4)
     // ---- records into the block's slice, group by group (through LDS: the global stores are whole lines) -------------------
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -358,7 +399,8 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             claim_cells(ovf, cells[r], blk_base + wv * RPW * 64 + r * 64 + lane, occ, new_cells, dscal, lane);
         }
         if (valid) {
-            s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rrgb[r];
+            const uint32_t rgbv = rgb4 ? (raw0[r] & 0xffffffu) : (raw0[r] | (raw1[r] << 16));
+            s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rgbv;
             if (g_cell) g_cell[blk_base + pos] = cells[r];
         }
     }
@@ -374,6 +416,13 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         }
     }
     if (tid == 0) { blk_runs[blockIdx.x] = (int32_t)(n_gruns + n_ovf); blk_pass[blockIdx.x] = (int32_t)n_valid; }
+    PT_T(5)
+#ifdef BSC_POINTS_PROFILE
+    if (blockIdx.x == 1000 && lane == 0 && (wv == 0 || wv == 3))
+        printf("k_points wave %d: init %lld geometry %lld slot/rank %lld barrier %lld prefix/claims %lld records %lld (clocks, %d rounds)\n", wv,
+               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], RPW);
+#endif
+#undef PT_T
 }
 
 // scalars of the batch, on the device: run / passing-point totals from the block scans, the new voxels' id range
