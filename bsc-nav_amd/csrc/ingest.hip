@@ -191,11 +191,12 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     int fr[RPW];
     int32_t ir[RPW];
     float zr[RPW];
-    uint32_t xy[RPW], tp[RPW];                      // fast geometry: pixel (x | y << 16), patch column | row << 8 of the pixel
+    uint32_t xy[RPW];                               // fast geometry: pixel (x | y << 16)
+    uint8_t tpx[RPW], tpy[RPW];                     // patch column / row of the pixel (raw table bytes: combining them here would wait for the loads)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
-        fr[r] = 0; ir[r] = 0; zr[r] = 0.f; xy[r] = 0u; tp[r] = 0xffffu;
+        fr[r] = 0; ir[r] = 0; zr[r] = 0.f; xy[r] = 0u; tpx[r] = 255; tpy[r] = 255;
         if (j < P) {
             int f;
             int32_t i;
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                 int32_t x = i - y * gc.W;
                 if (x < 0) { --y; x += gc.W; } else if (x >= gc.W) { ++y; x -= gc.W; }
                 xy[r] = (uint32_t)x | ((uint32_t)y << 16);
-                tp[r] = (uint32_t)gc.pat_x[x] | ((uint32_t)gc.pat_y[y] << 8);
+                tpx[r] = gc.pat_x[x];
+                tpy[r] = gc.pat_y[y];
             }
         }
     }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             cell = -1;
             if (FAST) {
                 GeomFastOut o;
-                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, tp[r] & 0xffu, tp[r] >> 8);
+                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r]);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
             } else {
