@@ -192,7 +192,8 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     int32_t ir[RPW];
     float zr[RPW];
     uint32_t xy[RPW];                               // fast geometry: pixel (x | y << 16)
-    uint8_t tpx[RPW], tpy[RPW];                     // patch column / row of the pixel (raw table bytes: combining them here would wait for the loads)
+    uint32_t tpx[RPW], tpy[RPW];                    // patch column / row of the pixel (raw table bytes, one register each: combining or
+                                                    // packing them here would wait for the loads)
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
@@ -276,7 +277,6 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                     r2 = o.r2; alpha = o.alpha;
                 }
             }
-            p_cell[j] = cell;
             if (cell >= 0) {
                 pix_off = ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
                 if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         }
         // the colour gather of every lane, unconditionally and unprocessed: nothing below needs it before the records are written,
         // so its round trip runs under the following rounds (RGBA frames: one aligned 32-bit gather; RGB: 16 + 8 bits)
-        if (rgb4) { raw0[r] = *(const uint32_t *)(rgb + pix_off); raw1[r] = 0u; }
+        // (raw1 stays unwritten for RGBA frames and is not read for them: a `= 0` here overwrites a register the hardware may still
+        //  owe an earlier load, and the wait for that also sat out the cell store just issued — a memory round trip per round)
+        if (rgb4) raw0[r] = *(const uint32_t *)(rgb + pix_off);
         else { raw0[r] = (uint32_t)rgb[pix_off] | ((uint32_t)rgb[pix_off + 1] << 8); raw1[r] = (uint32_t)rgb[pix_off + 2]; }
         cells[r] = cell;
         PT_T(1)
@@ -327,6 +329,14 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         ovf_cnt += __popcll(om);
         sr[r] = cell >= 0 ? (e | (lr << 16)) : 0xffffffffu;
         PT_T(2)
+    }
+    // the cells of all rounds leave together: a store inside the rounds shares the vmcnt counter with the loads still in flight
+    // (returns are ordered among loads, not between loads and stores), and every counted wait of a later round degraded to
+    // "wait for everything", the store's own round trip included
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
+        if (j < P) p_cell[j] = cells[r] == -2 ? -1 : cells[r];
     }
     __syncthreads();
     PT_T(3)
