@@ -570,12 +570,22 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
     const int64_t w_local = (int64_t)(blockIdx.x >> 3) * (TPB / 64) + (threadIdx.x >> 6);
     const int64_t w_per_xcd = (int64_t)(gridDim.x >> 3) * (TPB / 64);
     const int64_t chunk = (nseg + 63) / 64;
+#ifdef BSC_REDUCE_PROFILE
+    const long long t_begin = clock64();
+    int n_vox = 0, n_rows_p = 0, n_max = 0;
+#endif
     for (int64_t it = w_local; it < 8 * chunk; it += w_per_xcd) {
         const int64_t s = (xcd + 8 * (it / chunk)) * chunk + (it % chunk);
         if (s >= nseg) continue;
         const int64_t i0 = seg_start[s];
         const uint32_t code = code_sorted[i0];
         const int64_t vid = occ[code_to_cell(cc, (u64)code)];
+#ifdef BSC_REDUCE_PROFILE
+        {
+            const int64_t i1 = s + 1 < nseg ? (int64_t)seg_start[s + 1] : n_pairs;
+            ++n_vox; n_rows_p += (int)(i1 - i0); n_max = max(n_max, (int)(i1 - i0));
+        }
+#endif
         float4 a[NV];
 #pragma unroll
         for (int t = 0; t < NV; ++t)
@@ -682,6 +692,10 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
         }
         if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)total;
     }
+#ifdef BSC_REDUCE_PROFILE
+    if ((blockIdx.x % 128) == 5 && threadIdx.x == 0)
+        printf("reduce block %d wave 0: %lld clocks, %d voxels, %d pairs, longest %d\n", (int)blockIdx.x, clock64() - t_begin, n_vox, n_rows_p, n_max);
+#endif
 }
 
 // ---- column-sliced per-voxel reduce: the regime where the token rows do not stay in the L2 ---------------------------------
