@@ -130,11 +130,14 @@ __device__ __forceinline__ double div_by_const(double x, double c, double rc)
 __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
                                                   GeomFastOut &o, bool want_alpha, uint32_t tx, uint32_t ty)
 {
-    o.cell = -1;
+    // Straight-line on purpose: every lane evaluates the whole chain and the checks only gate the result.  With early returns the
+    // wavefront still issued every instruction (some lane is always valid) and paid ~40 register moves per point on top for the
+    // defaults and joins of the divergent branches.  Lanes that fail a check compute on whatever their depth gives; conversions
+    // saturate, nothing traps, and their outputs are discarded.
     const double px = (double)x + 0.5, py = (double)y + 0.5;
     const double z = (double)zf;
-    if (!((z > c.min_depth) && (z < c.max_depth))) return;
-    if (tx == 255u || ty == 255u) return;                       // memory_2.py:878 patch range
+    bool ok = (z > c.min_depth) && (z < c.max_depth);           // (false for NaN)
+    ok = ok && tx != 255u && ty != 255u;                        // memory_2.py:878 patch range
     o.patch = ty * (uint32_t)c.g + tx;
     const double p0 = __dmul_rn(__dadd_rn(__dmul_rn(c.Kinv[0], px), c.Kinv[2]), z);
     const double p1 = __dmul_rn(__dadd_rn(__dmul_rn(c.Kinv[4], py), c.Kinv[5]), z);
@@ -144,7 +147,7 @@ __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x,
     const int32_t row = (int32_t)(c.half_gs - (double)(int32_t)div_by_const(g0, c.cs, c.rcs));
     const int32_t col = (int32_t)(c.half_gs - (double)(int32_t)div_by_const(g1, c.cs, c.rcs));
     const int32_t h = (int32_t)div_by_const(g2, c.cs, c.rcs);
-    if (col >= c.gs || row >= c.gs || h >= c.max_h || col < 0 || row < 0 || h < c.min_h) return;
+    ok = ok && !(col >= c.gs || row >= c.gs || h >= c.max_h || col < 0 || row < 0 || h < c.min_h);
     // project_point(calib_mat): q0 / p2 - 0.5, q1 / p2 - 0.5 (mathematically integers: knife edge, evaluated exactly)
     const double q0 = __fma_rn(c.K[2], z, __dmul_rn(c.K[0], p0));
     const double q1 = __fma_rn(c.K[5], z, __dmul_rn(c.K[4], p1));
@@ -155,13 +158,13 @@ __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x,
     const double u = __fma_rn(__fma_rn(-z, u0, q0), rz, u0);
     const double v = __fma_rn(__fma_rn(-z, u1, q1), rz, u1);
     int sx = (int32_t)__dsub_rn(u, 0.5), sy = (int32_t)__dsub_rn(v, 0.5);
-    if (sx < 0) sx += c.W;
-    if (sy < 0) sy += c.H;
+    sx += sx < 0 ? c.W : 0;
+    sy += sy < 0 ? c.H : 0;
     o.sx = min(max(sx, 0), c.W - 1);
     o.sy = min(max(sy, 0), c.H - 1);
     o.r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(z, z));
     o.alpha = want_alpha ? exp(div_by_const(-o.r2, 1.2, 1.0 / 1.2)) : 0.0;
-    o.cell = (row * c.gs + col) * c.nh + (h - c.min_h);
+    o.cell = ok ? (row * c.gs + col) * c.nh + (h - c.min_h) : -1;
 }
 
 __device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,

@@ -277,14 +277,17 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
                     r2 = o.r2; alpha = o.alpha;
                 }
             }
-            if (cell >= 0) {
-                pix_off = ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch;
-                if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
-                if (p_r2f) p_r2f[j] = (float)r2;      // memory_2.py:885 grid_feat_dis is float32 (token cache only)
-                if (alpha_in) alpha = alpha_in[j];
-                ralo[r] = (uint32_t)__double2loint(alpha);
-                rahi[r] = (uint32_t)__double2hiint(alpha);
+            if (p_patf || p_r2f || alpha_in) {
+                if (cell >= 0) {
+                    if (p_patf) p_patf[j] = ((uint32_t)f << 16) | patch;
+                    if (p_r2f) p_r2f[j] = (float)r2;      // memory_2.py:885 grid_feat_dis is float32 (token cache only)
+                    if (alpha_in) alpha = alpha_in[j];
+                }
             }
+            // selects, not a branch: the record of a point outside the grid is never written, so its alpha bits may be anything
+            pix_off = cell >= 0 ? ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch : 0;
+            ralo[r] = (uint32_t)__double2loint(alpha);
+            rahi[r] = (uint32_t)__double2hiint(alpha);
         }
         // the colour gather of every lane, unconditionally and unprocessed: nothing below needs it before the records are written,
         // so its round trip runs under the following rounds (RGBA frames: one aligned 32-bit gather; RGB: 16 + 8 bits)
