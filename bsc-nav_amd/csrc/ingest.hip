@@ -1019,12 +1019,14 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
 // scanned over the ~R / 1024 block sums, and finished inside the block by k_expand — no R-sized scan array.
 #define EB 1024
 #define EXPAND_RUN_DRIVEN 16    // k_expand: wave-groups whose longest run has at most this many points are written run by run
-__device__ __forceinline__ int64_t run_item(const uint32_t *__restrict__ rkey, int64_t i, int64_t R, uint32_t vmask, int vb)
+// (length | head << 32) of sorted run i from its key and its predecessor's.  The two keys are loaded by the caller, unconditionally
+// (clamped indices) and for all its runs at once: read inside this function behind `if (i >= R)` and `if (v == vmask)`, every run
+// cost two dependent memory round trips, four runs per thread in a row.
+__device__ __forceinline__ int64_t run_item_of(uint32_t key, uint32_t prev, int64_t i, int64_t R, uint32_t vmask, int vb)
 {
-    if (i >= R) return 0;
-    const uint32_t key = rkey[i], v = key & vmask;
-    if (v == vmask) return 0;                   // no voxel: takes no room, starts no segment
-    const int64_t head = (i == 0 || (rkey[i - 1] & vmask) != v) ? 1 : 0;
+    const uint32_t v = key & vmask;
+    if (i >= R || v == vmask) return 0;         // no voxel: takes no room, starts no segment
+    const int64_t head = (i == 0 || (prev & vmask) != v) ? 1 : 0;
     return (int64_t)(key >> vb) + 1 + (head << 32);
 }
 
@@ -1034,8 +1036,15 @@ __global__ __launch_bounds__(TPB) void k_run_blocksum(int64_t R, int vb, const u
     __shared__ int64_t s_w[TPB / 64];
     const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
     int64_t v = 0;
+    uint32_t kc[EB / TPB], kp[EB / TPB];
 #pragma unroll
-    for (int r = 0; r < EB / TPB; ++r) v += run_item(rkey_sorted, (int64_t)blockIdx.x * EB + r * TPB + threadIdx.x, R, vmask, vb);
+    for (int r = 0; r < EB / TPB; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * EB + r * TPB + threadIdx.x, ic = i < R ? i : R - 1;
+        kc[r] = rkey_sorted[ic];
+        kp[r] = rkey_sorted[ic > 0 ? ic - 1 : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < EB / TPB; ++r) v += run_item_of(kc[r], kp[r], (int64_t)blockIdx.x * EB + r * TPB + threadIdx.x, R, vmask, vb);
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -1057,10 +1066,18 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
     // exclusive prefix of (length, head) inside the block, both in ONE 32-bit word — a block's 1024 runs hold at most 2^20
     // points (bits 0..20) and 1024 heads (bits 21..31) — scanned with DPP row shifts instead of 64-bit shuffles
     uint32_t item[EB / TPB], incl[EB / TPB];
+    uint32_t kc[EB / TPB], kp[EB / TPB], vc[EB / TPB];          // key, predecessor's key and value of the thread's four runs
+#pragma unroll
+    for (int r = 0; r < EB / TPB; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * EB + (r * (TPB / 64) + wid) * 64 + lane, ic = i < R ? i : R - 1;
+        kc[r] = rkey_sorted[ic];
+        kp[r] = rkey_sorted[ic > 0 ? ic - 1 : 0];
+        vc[r] = rval_sorted[ic];
+    }
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
         const int64_t i = (int64_t)blockIdx.x * EB + (r * (TPB / 64) + wid) * 64 + lane;      // group g = r * 4 + wid
-        const int64_t it = run_item(rkey_sorted, i, R, vmask, vb);
+        const int64_t it = run_item_of(kc[r], kp[r], i, R, vmask, vb);
         item[r] = (uint32_t)(it & 0x1fffff) | ((uint32_t)(it >> 32) << 21);
         uint32_t v = item[r];
 #define BSC_ISCAN_STEP(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false);
@@ -1086,9 +1103,9 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
         const int64_t i = (int64_t)blockIdx.x * EB + g * 64 + lane;
         int32_t off = INT_MAX, len = 0, j0 = 0;
         if (i < R) {
-            const uint32_t key = rkey_sorted[i];
+            const uint32_t key = kc[r];
             const uint32_t v = key & vmask;
-            j0 = (int32_t)rval_sorted[i];
+            j0 = (int32_t)vc[r];
             off = (int32_t)(sc & 0xffffffffll);
             if (v != vmask) {
                 len = (int32_t)(key >> vb) + 1;
