@@ -673,6 +673,7 @@ __global__ __launch_bounds__(TPB) void k_valid_bits(const int32_t *__restrict__ 
     const u64 b = __ballot(c < n && cnt[c < n ? c : 0] > 0);
     if ((threadIdx.x & 63) == 0) *(u64 *)(bits + 2 * (c >> 6)) = b;
 }
+template <bool FAST>      // FAST: dense map, no region / floor filter — candidate c is row c, validity from the bitmap (zero past max_id)
 __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__restrict__ sims, int64_t sims_stride,
                                                      const u64 *__restrict__ thr_keys, int K, int cap,
                                                      u64 *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
@@ -684,16 +685,17 @@ __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__
     const uint32_t thr_hi = (uint32_t)(thr >> 32);
     const float *qs = sims + (int64_t)q * sims_stride;
     const int lane = threadIdx.x & 63;
-    // dense maps without region / floor filter: candidate c is row c, so similarities and counts stream as 16-byte loads
-    const bool fast = !a.exact && !a.use_radius && !(a.floor_lo <= a.floor_hi) && (sims_stride % 4 == 0);
     uint32_t sk[FILT_G][4];
     // phase 1: every load of the block's 4096 candidates is in flight before anything is consumed
 #pragma unroll
     for (int g = 0; g < FILT_G; ++g) {
         const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
-        if (fast && c0 + 3 < a.max_id) {
-            const float4 sv = *(const float4 *)(qs + c0);
-            const uint32_t vb = valid[c0 >> 5] >> (c0 & 31);            // c0 is a multiple of 4: its four bits sit in one word
+        if constexpr (FAST) {
+            // (a group of four that reaches past max_id — the map's tail, max_id rounded up to 4 — reads nothing: its bits count as zero;
+            //  inside the last word the bits past max_id ARE zero)
+            const bool in = c0 < a.max_id;
+            const float4 sv = in ? *(const float4 *)(qs + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t vb = in ? valid[c0 >> 5] >> (c0 & 31) : 0u;  // c0 is a multiple of 4: its four bits sit in one word
             sk[g][0] = (vb & 1u) ? float_desc_key(sv.x) : 0xffffffffu;
             sk[g][1] = (vb & 2u) ? float_desc_key(sv.y) : 0xffffffffu;
             sk[g][2] = (vb & 4u) ? float_desc_key(sv.z) : 0xffffffffu;
@@ -725,10 +727,21 @@ __global__ __launch_bounds__(TPB) void k_cand_filter(CandArgs a, const float *__
         if (lane >= o) incl += t;
     }
     const int total = __shfl(incl, 63);
-    if (total == 0) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&counts[q * SEL_CNT_PAD], total);
-    base = __shfl(base, 0) + incl - mine;
+    // ONE atomic per work item (4096 candidates): the four wavefronts' totals meet in LDS.  Atomics on one address are served one
+    // at a time by the L2 (~0.4 us each with the returned value): with an atomic per wavefront a query's counter took 1024 of them in
+    // a row — that, not the 1.07 GB it reads, was this kernel's 0.46 ms
+    __shared__ int s_tot[TPB / 64], s_base;
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();                                    // the previous item's readers of s_tot / s_base are done
+    if (lane == 0) s_tot[wv] = total;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) { const int t = s_tot[w]; before += w < wv ? t : 0; all += t; }
+    if (all == 0) continue;                             // (uniform for the workgroup)
+    if (threadIdx.x == 0) s_base = atomicAdd(&counts[q * SEL_CNT_PAD], all);
+    __syncthreads();
+    int base = s_base + before + incl - mine;
 #pragma unroll
     for (int g = 0; g < FILT_G; ++g) {
         const int c0 = bx * FILT_PER_BLOCK + g * 4 * TPB + threadIdx.x * 4;
@@ -838,9 +851,15 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
             if (ca.max_id > 0)
                 hipLaunchKernelGGL(k_valid_bits, dim3((unsigned)((ca.max_id + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, ca.cnt, ca.max_id, x->l_valid);
         }
-        hipLaunchKernelGGL(k_cand_filter, dim3(nbf * (unsigned)nq < 16384u ? nbf * (unsigned)nq : 16384u), dim3(TPB), 0, x->stream, ca, x->l_sims,
-                           sims_stride, x->l_sel_thr, K, SEL_SURVIVOR_CAP, x->l_sel_key[0], x->l_sel_val[0],
-                           x->l_sel_cnt, (int)nbf, nq, (const uint32_t *)x->l_valid);
+        // dense maps without region / floor filter: candidate c is row c, similarities stream as 16-byte loads
+        const bool fast = !ca.exact && !ca.use_radius && !(ca.floor_lo <= ca.floor_hi) && (sims_stride % 4 == 0);
+        const dim3 fgrid(nbf * (unsigned)nq < 16384u ? nbf * (unsigned)nq : 16384u);
+        if (fast)
+            hipLaunchKernelGGL(k_cand_filter<true>, fgrid, dim3(TPB), 0, x->stream, ca, x->l_sims, sims_stride, x->l_sel_thr, K,
+                               SEL_SURVIVOR_CAP, x->l_sel_key[0], x->l_sel_val[0], x->l_sel_cnt, (int)nbf, nq, (const uint32_t *)x->l_valid);
+        else
+            hipLaunchKernelGGL(k_cand_filter<false>, fgrid, dim3(TPB), 0, x->stream, ca, x->l_sims, sims_stride, x->l_sel_thr, K,
+                               SEL_SURVIVOR_CAP, x->l_sel_key[0], x->l_sel_val[0], x->l_sel_cnt, (int)nbf, nq, (const uint32_t *)x->l_valid);
         // survivors of query q sit at [q * CAP, q * CAP + count); the rounds use stride CAP for them
         BSC_TRY(bitonic_rounds(x, nq, SEL_SURVIVOR_CAP, x->l_sel_cnt, K, SEL_SURVIVOR_CAP, &cur));
         stride = SEL_SURVIVOR_CAP;
