@@ -543,6 +543,29 @@ __device__ __forceinline__ void kv_cx(u64 &k, uint32_t &v, const u64 pk, const u
     v = swap ? pv : v;
 }
 
+// value of lane (lane ^ j), j < 64, without the LDS crossbar: DPP quad permutes / row mirrors below 16 (xor 4 = reverse of 8, then
+// of each quad; xor 8 = reverse of 16, then of each 8), v_permlane16_swap / v_permlane32_swap above.  As ds_bpermute a 1024-key sort
+// issued 2 160 wavefront-wide permutes at ~32 cycles of the CU's LDS pipe each: 33 us per sort and CU, whatever else ran beside it.
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int j, int lane)
+{
+    if (j == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);           // quad_perm [1,0,3,2]
+    if (j == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
+    if (j == 4) {
+        const int t = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);                     // row_half_mirror
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xf, 0xf, true);                        // quad_perm [3,2,1,0]
+    }
+    if (j == 8) {
+        const int t = __builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);                     // row_mirror
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x141, 0xf, 0xf, true);                       // row_half_mirror
+    }
+    if (j == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);                           // j == 32
+    return (lane & 32) ? r[0] : r[1];
+}
+
 __device__ __forceinline__ void bitonic_1024_regs(u64 (&key)[4], uint32_t (&val)[4], u64 (*bk)[TK_N], uint32_t (*bv)[TK_N])
 {
     const int tid = threadIdx.x;
@@ -568,8 +591,8 @@ __device__ __forceinline__ void bitonic_1024_regs(u64 (&key)[4], uint32_t (&val)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = r * 256 + tid;
-                    const u64 pk = __shfl_xor((unsigned long long)key[r], j);
-                    const uint32_t pv = __shfl_xor(val[r], j);
+                    const u64 pk = (u64)lane_xor((uint32_t)key[r], j, tid) | ((u64)lane_xor((uint32_t)(key[r] >> 32), j, tid) << 32);
+                    const uint32_t pv = lane_xor(val[r], j, tid);
                     kv_cx(key[r], val[r], pk, pv, ((e & j) == 0) == ((e & k) == 0));
                 }
             } else {                                    // j = 64, 128: another wavefront, through LDS
@@ -626,7 +649,10 @@ __global__ __launch_bounds__(TPB) void k_block_topk(const u64 *__restrict__ in_k
     __shared__ u64 bk[2][TK_N];
     __shared__ uint32_t bv[2][TK_N];
     for (int wi = blockIdx.x; wi < nb * nq; wi += gridDim.x) {      // persistent: (block, query) items
-        const int q = wi / nb, bx = wi - q * nb;
+        // the query is the FAST index: the non-empty slices of the survivor lists (the first ~7 of every query's 32) are then the
+        // first items and spread over all CUs — with the slice as the fast index they sat in every fourth workgroup of an XCD,
+        // i.e. on a quarter of its CUs, 16 sorts deep (first survivor round 258 us)
+        const int bx = wi / nq, q = wi - bx * nq;
         const int64_t nn = n_per_q ? min((int64_t)n_per_q[q * SEL_CNT_PAD], n) : n;
         const int64_t base = (int64_t)bx * TK_N;
         if (base >= nn) {
@@ -775,6 +801,9 @@ __global__ void k_sel_check(const u64 *__restrict__ thr, const int32_t *__restri
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     if (counts[q * SEL_CNT_PAD] > cap || thr[q] == ~0ull) *flag = 1;
+#ifdef BSC_SEL_DEBUG
+    if (q < 4 || q == nq - 1) printf("query %d: %d survivors (cap %d)\n", q, counts[q * SEL_CNT_PAD], cap);
+#endif
 }
 
 static bsc_status grow_dev(void **p, int64_t *cap, int64_t need_bytes)
