@@ -172,7 +172,9 @@ struct bsc_ctx {
     size_t prim_tmp_bytes;
     void *prim_tmp_side;       // second rocPRIM workspace: the order pipeline sorts on the side stream beside the pair sort
     bool order_on_side;        // per-voxel point order (k_runs .. k_seg_order) on the side stream (BSC_ORDER_MAIN=1 keeps it on the main stream)
-    hipEvent_t ev_ids, ev_runs;   // main: voxel ids assigned; side: k_runs has read the call's cells / block offsets
+    hipEvent_t ev_ids, ev_runs;   // voxel ids assigned; side: k_runs has read the call's cells / block offsets
+    hipEvent_t ev_tot;            // main: k_totals done (the call's run / new-voxel counts exist)
+    hipStream_t copy;             // early readback of those counts while the main stream goes on with the pair tiles
     bool ev_runs_valid;
     int last_order_set;        // scratch set of the last order stage enqueued on the side stream (-1: none): its ev_ready marks it complete
     // bookkeeping

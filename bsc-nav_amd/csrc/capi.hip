@@ -285,6 +285,8 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     x->order_on_side = getenv("BSC_ORDER_MAIN") == nullptr;
     BSC_HIP(hipEventCreateWithFlags(&x->ev_ids, hipEventDisableTiming));
     BSC_HIP(hipEventCreateWithFlags(&x->ev_runs, hipEventDisableTiming));
+    BSC_HIP(hipEventCreateWithFlags(&x->ev_tot, hipEventDisableTiming));
+    BSC_HIP(hipStreamCreateWithFlags(&x->copy, hipStreamNonBlocking));
     for (int w = 0; w < BSC_STAT_SLOTS; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i) BSC_HIP(hipEventCreate(&x->ev[w][i]));
     x->timing = true;
@@ -319,6 +321,8 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     if (x->side) hipStreamDestroy(x->side);
     if (x->ev_ids) hipEventDestroy(x->ev_ids);
     if (x->ev_runs) hipEventDestroy(x->ev_runs);
+    if (x->ev_tot) hipEventDestroy(x->ev_tot);
+    if (x->copy) hipStreamDestroy(x->copy);
     for (int k = 0; k < 2; ++k) {
         if (x->ev_ready[k]) hipEventDestroy(x->ev_ready[k]);
         if (x->ev_done[k]) hipEventDestroy(x->ev_done[k]);

@@ -1373,24 +1373,42 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
                        x->c.voxel_capacity, x->bscal_s[set]);
+    // early: (dense modes, order stage on the side stream) the counts k_totals wrote come back over a copy stream WHILE the main
+    // stream runs the pair tiles, and the new-voxel ids + order stage are enqueued on the side stream during that time; the pair
+    // count follows with a second, short readback.  With ONE readback after the pair tiles the host came back to an empty main
+    // stream and spent ~0.26 ms enqueueing before it had work again, and the order stage (hence the rgb chain) started 0.45 ms late.
+    const bool early = x->order_on_side && !exact;
+    if (early) BSC_HIP(hipEventRecord(x->ev_tot, s));
     stat_begin(x, BSC_STAT_PAIRS);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr, patf));
     stat_end(x, BSC_STAT_PAIRS, 0.0);
     // one small readback per call: new voxels, runs, pairs (dense modes), passing points (exact mode), capacity flag.
     // Everything enqueued so far is the call's front end; the back end is sized from these numbers.
-    BSC_TRY(read_scalars(x));
+    if (early) {
+        BSC_HIP(hipStreamWaitEvent(x->copy, x->ev_tot, 0));
+        BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->copy));
+        BSC_HIP(hipStreamSynchronize(x->copy));
+    } else {
+        BSC_TRY(read_scalars(x));
+    }
     const int64_t n_new_listed = x->hscal[DS_B_NNEW], n_new = x->hscal[DS_B_NFIRST];
-    // The buffers the back end shares with the order stage (run keys / values and their sort outputs) may still be in use by
-    // the previous call's order stage on the side stream when calls follow each other without an encoder pass in between
-    if (x->last_order_set >= 0) BSC_HIP(hipStreamWaitEvent(s, x->ev_ready[x->last_order_set], 0));
     // ids of the new voxels: rank of their winning point among the winners (memory_2.py:888-894)
-    if (n_new_listed > 0) {
-        const dim3 ngrid((unsigned)((n_new_listed + TPB - 1) / TPB));
-        hipLaunchKernelGGL(k_new_keys, ngrid, block, 0, s, n_new_listed, x->new_cells, x->occ, x->skey_a, x->sval_a);
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)n_new_listed, 0,
-                                    ceil_log2_u64((uint64_t)P + 1)));
-        hipLaunchKernelGGL(k_new_assign, ngrid, block, 0, s, n_new_listed, n_new, x->run_val_b, x->occ, x->dscal,
-                           x->c.grid_size, x->nh, x->rgb_pos);
+    auto assign_ids = [&](hipStream_t st) -> bsc_status {
+        if (n_new_listed > 0) {
+            const dim3 ngrid((unsigned)((n_new_listed + TPB - 1) / TPB));
+            hipLaunchKernelGGL(k_new_keys, ngrid, block, 0, st, n_new_listed, x->new_cells, x->occ, x->skey_a, x->sval_a);
+            BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)n_new_listed, 0,
+                                        ceil_log2_u64((uint64_t)P + 1)));
+            hipLaunchKernelGGL(k_new_assign, ngrid, block, 0, st, n_new_listed, n_new, x->run_val_b, x->occ, x->dscal,
+                               x->c.grid_size, x->nh, x->rgb_pos);
+        }
+        return BSC_OK;
+    };
+    if (!early) {
+        // The buffers the back end shares with the order stage (run keys / values and their sort outputs) may still be in use by
+        // the previous call's order stage on the side stream when calls follow each other without an encoder pass in between
+        if (x->last_order_set >= 0) BSC_HIP(hipStreamWaitEvent(s, x->ev_ready[x->last_order_set], 0));
+        BSC_TRY(assign_ids(s));
     }
     if (x->hscal[DS_ERROR]) {
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
@@ -1403,7 +1421,9 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // gaps (own rocPRIM workspace, disjoint buffers).  BSC_ORDER_MAIN=1: one stream, as in round 2.
     const bool side_order = x->order_on_side;
     hipStream_t so = side_order ? x->side : s;
-    if (side_order) {
+    if (early) {
+        BSC_HIP(hipStreamWaitEvent(so, x->ev_tot, 0));          // the side stream takes over from k_totals: ids, then the order stage
+    } else if (side_order) {
         BSC_HIP(hipEventRecord(x->ev_ids, s));
         BSC_HIP(hipStreamWaitEvent(so, x->ev_ids, 0));
     } else if (!exact) {
@@ -1413,6 +1433,10 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     void *const prim_main = x->prim_tmp;
     if (side_order) { x->stream = so; x->prim_tmp = x->prim_tmp_side; }
     const bsc_status order_st = [&]() -> bsc_status {
+    if (early) {
+        BSC_TRY(assign_ids(so));
+        BSC_HIP(hipEventRecord(x->ev_ids, so));
+    }
     stat_begin(x, BSC_STAT_ORDER, so);
     // stable radix sort of the RUNS on the voxel id alone: runs enter in order j, so each voxel's runs stay in order;
     // their expansion is the per-voxel point order
@@ -1459,7 +1483,14 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     x->stream = s;
     x->prim_tmp = prim_main;
     BSC_TRY(order_st);
-    if (side_order && !exact) BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    if (early) {
+        // second readback: the pair count (the main stream has only the pair tiles in flight), then the back end behind the ids
+        BSC_TRY(read_scalars(x));
+        BSC_HIP(hipStreamWaitEvent(s, x->ev_ids, 0));
+        BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    } else if (side_order && !exact) {
+        BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
+    }
     if (side_order && exact) BSC_HIP(hipStreamWaitEvent(s, x->ev_runs, 0));       // k_append reads the pass list k_runs wrote
     // rgb chain + top-down map: sequential-latency bound, on the library's side stream — and DEFERRED: the
     // call only marks its point order ready; the kernels are launched at the start of the next bsc_ingest (or by whatever

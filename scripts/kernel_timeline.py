@@ -1,0 +1,15 @@
+"""Timeline of the last <n> kernel launches of a rocprofv3 kernel_trace.csv: start offset, duration, queue, name.
+usage: kernel_timeline.py <kernel_trace.csv> [n] [name filter to anchor the window start, e.g. k_points]"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+if len(sys.argv) > 3:
+    idx = [i for i, r in enumerate(rows) if sys.argv[3] in r["Kernel_Name"]]
+    rows = rows[idx[-1]:idx[-1] + n] if idx else rows[-n:]
+else:
+    rows = rows[-n:]
+t0 = int(rows[0]["Start_Timestamp"])
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print(f"{(s - t0) / 1e3:9.1f} +{(e - s) / 1e3:8.1f} us  q={r.get('Queue_Id', '?'):>3s}  {r['Kernel_Name'][:90]}")
