@@ -162,7 +162,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->hmap, gs2);
     ALLOC(x->cv_map, 3 * gs2);
     ALLOC(x->dscal, DS_COUNT);
-    BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * DS_COUNT));
+    BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * (DS_COUNT + 1)));      // + a slot for the pair count read on its own
     ALLOC(x->pat_x, c.width);
     ALLOC(x->pat_y, c.height);
     {

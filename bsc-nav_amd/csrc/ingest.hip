@@ -1385,6 +1385,8 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // one small readback per call: new voxels, runs, pairs (dense modes), passing points (exact mode), capacity flag.
     // Everything enqueued so far is the call's front end; the back end is sized from these numbers.
     if (early) {
+        // the pair count: copied behind the pair tiles right away (its own pinned slot), waited for after the side stream's launches
+        BSC_HIP(hipMemcpyAsync(x->hscal + DS_COUNT, x->dscal + DS_B_NPAIR, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         BSC_HIP(hipStreamWaitEvent(x->copy, x->ev_tot, 0));
         BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->copy));
         BSC_HIP(hipStreamSynchronize(x->copy));
@@ -1484,8 +1486,9 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     x->prim_tmp = prim_main;
     BSC_TRY(order_st);
     if (early) {
-        // second readback: the pair count (the main stream has only the pair tiles in flight), then the back end behind the ids
-        BSC_TRY(read_scalars(x));
+        // the pair count (copied behind the pair tiles above), then the back end behind the ids
+        BSC_HIP(hipStreamSynchronize(s));
+        x->hscal[DS_B_NPAIR] = x->hscal[DS_COUNT];
         BSC_HIP(hipStreamWaitEvent(s, x->ev_ids, 0));
         BSC_TRY(dense_reduce_batch(x, tokens, token_dtype, n_frames));
     } else if (side_order && !exact) {
