@@ -20,9 +20,11 @@
 //              them in registers (v_cvt_pk_f16_f32);
 //   W operand  pieces precomputed once per weight matrix (bsc_enc_split_weights: planes h, l of (N,K) fp16), staged per 32-wide
 //              K chunk through LDS (80-byte row pitch: conflict-free 16-byte reads), double-buffered;
-//   MFMA       D[i][j] += A[i][k] W[j][k]: a lane of the accumulator tile holds ONE column n and 16 rows, so a store instruction
-//              writes 128 contiguous bytes of a row of C, and the bias is one register per tile;
+//   MFMA       the weights are the FIRST operand (D' = W X^T), so a lane of the accumulator tile holds ONE row of C and four
+//              consecutive columns per register quad;
 //   epilogue   bias, bias + GELU(tanh), bias + residual (C may alias the residual) — nothing elementwise is left between GEMMs.
+//              Each wavefront turns its 32 x 32 tiles round in 4 KB of LDS of its own and moves them as whole 128-byte lines
+//              (f32 rows or piece chunks), the residual rows requested three tiles ahead.
 // Workgroup ids map so that the workgroups of an XCD (id mod 8) walk the column tiles of ONE row tile back to back: the 786 KB
 // A tile is fetched into that XCD's L2 once.
 #include "bsc_internal.h"
@@ -31,6 +33,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 #define GS_KC 32                 // K chunk
 #define GS_PITCH 40              // fp16 elements per staged weight row (80 bytes)
@@ -41,11 +44,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
 
+#ifdef BSC_GEMM_PROFILE        // per-workgroup phase stamps (100 MHz wall clock) + the CU it ran on: -DBSC_GEMM_PROFILE, BSC_GEMM_PROFILE_DUMP=1
+#define GS_PROF_MAX 8192
+__device__ uint64_t g_gemm_prof[GS_PROF_MAX][6];
+#define GS_T(k)                                                                                                                   \
+    do {                                                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < GS_PROF_MAX) g_gemm_prof[blockIdx.x][k] = wall_clock64();                            \
+    } while (0)
+#else
+#define GS_T(k)
+#endif
+
 __device__ __forceinline__ uint32_t pack_f16_rne(float lo, float hi)        // v_cvt_pk_f16_f32
 {
     const f32x2_t v = {lo, hi};
     const half2_t r = __builtin_convertvector(v, half2_t);
     return *(const uint32_t *)&r;
+}
+
+// orders a wavefront's own LDS accesses (waits for its LDS operations only; no workgroup barrier)
+__device__ __forceinline__ void gs_wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // (a, b) -> packed fp16 pieces h, l of both
@@ -168,8 +189,26 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     const int tn = (int)(q % n_tiles_n);
     const int64_t tm = (q / n_tiles_n) * 8 + xcd;
     if (tm >= n_tiles_m) return;
+#ifdef BSC_GEMM_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x < GS_PROF_MAX) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_gemm_prof[blockIdx.x][0] = ((uint64_t)xcc << 32) | hw;
+    }
+    GS_T(1);
+#endif
     const int64_t row0 = tm * TROWS + wr * (MR * 32);
     const int n0 = tn * WROWS;
+    // the bias values of the wavefront's column strip, four per lane (they reach the epilogue through LDS)
+    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias && 4 * lane < NT * 32) {
+        const int nb = n0 + wc * NT * 32 + 4 * lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (nb + e < N) bias4[e] = bias[nb + e];
+    }
     // per-lane row base: f32 rows (16 floats of the chunk per lane) or P32 pieces (8 halfs of either piece per sub-step)
     const char *arow[MR];
 #pragma unroll
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     if (nchunks > 1) load_a(xg, 1);
     store_w(0);
     __syncthreads();
+    GS_T(2);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         // this chunk's rows as fp16 pieces (two sub-steps of 8 halfs), then the next chunk's loads go in flight
@@ -259,50 +299,128 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)ah[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // h l
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t], *(const half8_t *)ah[mr][sstep], acc[mr][t], 0, 0, 0);     // h l
 #pragma unroll
             for (int t = 0; t < NT; ++t) wf[t] = *(const half8_t *)(wb + (0 * WROWS + t * 32) * GS_PITCH + sstep * 8);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)al[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // l h
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t], *(const half8_t *)al[mr][sstep], acc[mr][t], 0, 0, 0);     // l h
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8_t *)ah[mr][sstep], wf[t], acc[mr][t], 0, 0, 0);     // h h
+                    acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t], *(const half8_t *)ah[mr][sstep], acc[mr][t], 0, 0, 0);     // h h
         }
         if (c + 1 < nchunks) store_w(buf ^ 1);
         __syncthreads();
     }
-    // accumulator tile (mr, t): lane (i, g) holds column n0 + 32 (wc NT + t) + i and the rows (r & 3) + 8 (r >> 2) + 4 g of fragment mr
+    GS_T(3);
+    // The weights are the MFMA's FIRST operand (D' = W X^T): lane (i, g) of accumulator tile (mr, t) holds ROW row0 + 32 mr + i of C
+    // and, in registers 4 q .. 4 q + 3, the four consecutive columns 32 t + 8 q + 4 g + (0..3) of the wavefront's strip.  A 32 x 32
+    // tile is 128 bytes per row either way (32 floats, or the P32 chunk [32 h | 32 l]): the wavefront turns it round in its own
+    // 4 KB of LDS (the weight buffers are free after the loop's last barrier; no workgroup barrier here) and moves it as WHOLE
+    // 128-byte lines — 8 lanes per row, 8 rows per 16-byte instruction.  How this epilogue got here (scripts/gemm_phase_profile.sh):
+    // one 4-byte access per element in accumulator order was 15 us per tile for piece output (VALU: ~25 instructions per element)
+    // and 65 us for the residual form (R may alias C, so every load stayed behind the store before it: a memory round trip per
+    // element) against 75 us of main loop at K = 768; 16-byte quads straight from the registers were 9 and 34 us (32 lines
+    // touched per instruction: the L1's line rate).  The residual rows are requested RD tiles ahead of their use.
     const bool full = row0 + MR * 32 <= M && n0 + WROWS <= N;               // (uniform) no bounds checks inside the tile
     float *C = (float *)Cv;
     uint16_t *Cp = (uint16_t *)Cv;
+    constexpr int EP = 136;                                                 // staged row pitch, bytes: conflict-free 8-byte writes
+    constexpr int WLB = 32 * EP + NT * 32 * 4;                              // per wavefront: one tile + the bias values of its strip
+    constexpr int RD = 3;
+    char *wl = (char *)Ws + w * WLB;
+    float *bs = (float *)(wl + 32 * EP);
+    if (4 * lane < NT * 32) *(f32x4_t *)&bs[4 * lane] = bias4;
+    gs_wave_lds_order();
+    const int rl = lane >> 3, seg = lane & 7;                               // line phase: row rl + 8 k of the tile, 16-byte segment seg
+    auto epilogue = [&](const bool chk) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + (wc * NT + t) * 32 + i;
-        const float b = (bias && n < N) ? bias[n] : 0.f;
+        for (int mr = 0; mr < MR; ++mr) {
+            const int64_t mbase = row0 + mr * 32;
+            if (CPIECES || (N & 3) == 0) {
+                f32x4_t rq[RD][4];
+                auto line_ok = [&](int t, int k) {
+                    const int n = n0 + (wc * NT + t) * 32 + (CPIECES ? 0 : 4 * seg);
+                    return !chk || (mbase + rl + 8 * k < M && n < N);
+                };
+                auto load_r = [&](int slot, int t) {
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                        rq[slot][k] = line_ok(t, k) ? *(const f32x4_t *)(R + (mbase + rl + 8 * k) * N + n0 + (wc * NT + t) * 32 + 4 * seg) : z;
+                    }
+                };
+                if (EPI == GS_EPI_RESID) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = row0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (!full && (m >= M || n >= N)) continue;
-                float v = fmaf(acc[mr][t][r], out_scale, b);
-                if (EPI == GS_EPI_GELU) v = gelu_tanh(v);
-                if (EPI == GS_EPI_RESID) v += R[m * N + n];
-                if (CPIECES) {
-                    v *= c_scale;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)(v - (float)h);
-                    uint16_t *o = Cp + p32_off(m, N, n);
-                    o[0] = *(const uint16_t *)&h;
-                    o[32] = *(const uint16_t *)&l;
-                } else C[m * N + n] = v;
+                    for (int t = 0; t < RD - 1 && t < NT; ++t) load_r(t, t);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (EPI == GS_EPI_RESID && t + RD - 1 < NT) load_r((t + RD - 1) % RD, t + RD - 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t b4 = *(const f32x4_t *)&bs[32 * t + 8 * q + 4 * g];
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaf(acc[mr][t][4 * q + e], out_scale, b4[e]);
+                            if (EPI == GS_EPI_GELU) v[e] = gelu_tanh(v[e]);
+                        }
+                        if (CPIECES) {
+                            uint32_t h0, l0, h1, l1;
+                            split2(v[0] * c_scale, v[1] * c_scale, h0, l0);
+                            split2(v[2] * c_scale, v[3] * c_scale, h1, l1);
+                            *(uint2 *)(wl + i * EP + 16 * q + 8 * g) = make_uint2(h0, h1);
+                            *(uint2 *)(wl + i * EP + 64 + 16 * q + 8 * g) = make_uint2(l0, l1);
+                        } else {
+                            *(float2 *)(wl + i * EP + 32 * q + 16 * g) = make_float2(v[0], v[1]);
+                            *(float2 *)(wl + i * EP + 32 * q + 16 * g + 8) = make_float2(v[2], v[3]);
+                        }
+                    }
+                    gs_wave_lds_order();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint2 lo = *(const uint2 *)(wl + (rl + 8 * k) * EP + 16 * seg);
+                        const uint2 hi = *(const uint2 *)(wl + (rl + 8 * k) * EP + 16 * seg + 8);
+                        if (!line_ok(t, k)) continue;
+                        const int64_t m = mbase + rl + 8 * k;
+                        if (CPIECES) {
+                            *(uint4 *)(Cp + m * 2 * N + (int64_t)((n0 >> 5) + wc * NT + t) * 64 + 8 * seg) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        } else {
+                            f32x4_t o = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+                            if (EPI == GS_EPI_RESID) o += rq[t % RD][k];
+                            *(f32x4_t *)(C + m * N + n0 + (wc * NT + t) * 32 + 4 * seg) = o;
+                        }
+                    }
+                    gs_wave_lds_order();
+                }
+            } else {                    // f32 output with N not a multiple of 4 (no encoder shape): element by element
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = mbase + i;
+                        const int nl = 32 * t + 8 * (r >> 2) + 4 * g + (r & 3), n = n0 + wc * NT * 32 + nl;
+                        if (m >= M || n >= N) continue;
+                        float v = fmaf(acc[mr][t][r], out_scale, bs[nl]);
+                        if (EPI == GS_EPI_GELU) v = gelu_tanh(v);
+                        if (EPI == GS_EPI_RESID) v += R[m * N + n];
+                        C[m * N + n] = v;
+                    }
             }
-    }
+        }
+    };
+    if (full) epilogue(false);
+    else epilogue(true);
+#ifdef BSC_GEMM_PROFILE
+    GS_T(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GS_T(5);
+#endif
 }
 
 // ---- attention at f32 accuracy on fp16 pieces ------------------------------------------------------------------------------------
@@ -314,7 +432,6 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
 // split (probabilities of 1/T would push their l piece into fp16's subnormals), the factor leaves with the row sum.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int N> struct gs_u32vec { typedef uint32_t type __attribute__((ext_vector_type(N))); };
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int NLD, int NTHR>
 __device__ __forceinline__ void atts_issue_loads(typename gs_u32vec<4 * NLD>::type &k8, typename gs_u32vec<4 * NLD>::type &v8,
@@ -599,7 +716,9 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const int64_t n_tiles_m = (M + TROWS - 1) / TROWS;
     const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
     const int64_t n_wg = groups * n_tiles_n * 8;
-    const size_t lds = (size_t)2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
+    const size_t lds_loop = (size_t)2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
+    const size_t lds_epi = (size_t)(NTHR / 64) * (32 * 136 + TCOLS * 4);          // the epilogue's per-wavefront tile + bias strip
+    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     hipStream_t s = (hipStream_t)hip_stream;
     const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
 #define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
@@ -638,6 +757,17 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
 #undef BSC_GEMM_LAUNCH
 #undef BSC_GEMM_LAUNCH2
     BSC_HIP(hipGetLastError());
+#ifdef BSC_GEMM_PROFILE
+    if (getenv("BSC_GEMM_PROFILE_DUMP")) {
+        static uint64_t host[GS_PROF_MAX][6];
+        BSC_HIP(hipStreamSynchronize(s));
+        BSC_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_prof), sizeof(host)));
+        const int64_t n = n_wg < GS_PROF_MAX ? n_wg : GS_PROF_MAX;
+        for (int64_t w = 0; w < n; ++w)
+            fprintf(stderr, "GP %lld %llx %llu %llu %llu %llu %llu\n", (long long)w, (unsigned long long)host[w][0], (unsigned long long)host[w][1],
+                    (unsigned long long)host[w][2], (unsigned long long)host[w][3], (unsigned long long)host[w][4], (unsigned long long)host[w][5]);
+    }
+#endif
     return BSC_OK;
 }
 
