@@ -168,13 +168,12 @@ __global__ __launch_bounds__(GS_TPB) void k_split_rows(const float *__restrict__
 // APIECES: A comes as P32 pieces (made by the producing kernel) — otherwise as f32 rows, split in registers.
 // CPIECES: C leaves as P32 pieces scaled by c_scale (the hidden tensor of the MLP: read by the next GEMM only).
 template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
-__global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restrict__ Av, int64_t M, int K,
-                                                             const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
-                                                             const float *__restrict__ bias, const float *R, void *Cv,
-                                                             float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m)
+__device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__restrict__ Av, int64_t M, int K,
+                                                const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
+                                                const float *__restrict__ bias, const float *R, void *Cv,
+                                                float a_scale, float out_scale, float c_scale, int64_t tm, int n0)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];           // [2][2][WC * NT * 32][GS_PITCH]
-    constexpr int WROWS = WC * NT * 32;
+    constexpr int WROWS = WC * NT * 32;                                       // Ws: [2][2][WROWS][GS_PITCH]
     constexpr int TROWS = WR * MR * 32;
     constexpr int BUF = 2 * WROWS * GS_PITCH;
     constexpr int NTHR = 64 * WR * WC;
@@ -182,13 +181,6 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WC, wc = w - wr * WC;
     const int i = lane & 31, g = lane >> 5;
-    // XCD k (= id mod 8) takes the row tiles k, k + 8, ... and walks all column tiles of one before the next
-    const int64_t wg = blockIdx.x;
-    const int xcd = (int)(wg & 7);
-    const int64_t q = wg >> 3;
-    const int tn = (int)(q % n_tiles_n);
-    const int64_t tm = (q / n_tiles_n) * 8 + xcd;
-    if (tm >= n_tiles_m) return;
 #ifdef BSC_GEMM_PROFILE
     if (threadIdx.x == 0 && blockIdx.x < GS_PROF_MAX) {
         uint32_t hw;
@@ -200,7 +192,6 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     GS_T(1);
 #endif
     const int64_t row0 = tm * TROWS + wr * (MR * 32);
-    const int n0 = tn * WROWS;
     // the bias values of the wavefront's column strip, four per lane (they reach the epilogue through LDS)
     f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
     if (bias && 4 * lane < NT * 32) {
@@ -421,6 +412,37 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GS_T(5);
 #endif
+}
+
+// XCD k (= workgroup id mod 8) takes the row tiles k, k + 8, ... and walks all column tiles of one before the next.  q_full: the
+// first q_full tiles of every XCD run whole; the rest — a last, partly filled round of workgroups (N = 768: 888 tiles on 256 CUs
+// are 3.47 rounds) — run as two half-width tiles each, so that round costs half a tile's time instead of a whole one.
+template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
+__global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restrict__ Av, int64_t M, int K,
+                                                             const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
+                                                             const float *__restrict__ bias, const float *R, void *Cv,
+                                                             float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m,
+                                                             int64_t q_full)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];
+    const int64_t wg = blockIdx.x;
+    const int xcd = (int)(wg & 7);
+    const int64_t q = wg >> 3;
+    if (NT % 2 || q < q_full) {
+        const int tn = (int)(q % n_tiles_n);
+        const int64_t tm = (q / n_tiles_n) * 8 + xcd;
+        if (tm >= n_tiles_m) return;
+        gemm_split_tile<MR, NT, WR, WC, EPI, APIECES, CPIECES>(Ws, Av, M, K, Wp, w_plane, N, bias, R, Cv, a_scale, out_scale, c_scale, tm,
+                                                               tn * (WC * NT * 32));
+    } else {
+        constexpr int NH = NT % 2 ? NT : NT / 2;
+        const int64_t qt = q_full + ((q - q_full) >> 1);
+        const int tn = (int)(qt % n_tiles_n);
+        const int64_t tm = (qt / n_tiles_n) * 8 + xcd;
+        if (tm >= n_tiles_m) return;
+        gemm_split_tile<MR, NH, WR, WC, EPI, APIECES, CPIECES>(Ws, Av, M, K, Wp, w_plane, N, bias, R, Cv, a_scale, out_scale, c_scale, tm,
+                                                               tn * (WC * NT * 32) + (int)((q - q_full) & 1) * (WC * NH * 32));
+    }
 }
 
 // ---- attention at f32 accuracy on fp16 pieces ------------------------------------------------------------------------------------
@@ -715,7 +737,18 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const int n_tiles_n = (int)(n_pad / TCOLS);
     const int64_t n_tiles_m = (M + TROWS - 1) / TROWS;
     const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
-    const int64_t n_wg = groups * n_tiles_n * 8;
+    // a last round that fills at most half of the CUs runs as half-width tiles (tile 1 only; BSC_GEMM_TAIL=0: whole tiles)
+    static const int tail_env = getenv("BSC_GEMM_TAIL") ? atoi(getenv("BSC_GEMM_TAIL")) : 1;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        BSC_HIP(hipGetDevice(&dev));
+        BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int64_t q_all = groups * n_tiles_n, per_round = n_cu / 8 > 0 ? n_cu / 8 : 1;
+    const int64_t q_rem = q_all % per_round;
+    const int64_t q_full = (tile == 1 && tail_env && q_rem > 0 && 2 * q_rem <= per_round && q_all > per_round) ? q_all - q_rem : q_all;
+    const int64_t n_wg = (q_full + 2 * (q_all - q_full)) * 8;
     const size_t lds_loop = (size_t)2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
     const size_t lds_epi = (size_t)(NTHR / 64) * (32 * 136 + TCOLS * 4);          // the epilogue's per-wavefront tile + bias strip
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
@@ -731,7 +764,7 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
         }                                                                                                                            \
         hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, M, K,\
                            (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
-                           c_pieces_scale, n_tiles_n, (int)n_tiles_m);                                                               \
+                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full);                                                       \
     } while (0)
 #define BSC_GEMM_LAUNCH(EPIV, APV, CPV)                                                                                              \
     do {                                                                                                                             \
