@@ -49,7 +49,7 @@ enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
 __device__ uint64_t g_gemm_prof[GS_PROF_MAX][6];
 #define GS_T(k)                                                                                                                   \
     do {                                                                                                                          \
-        if (threadIdx.x == 0 && blockIdx.x < GS_PROF_MAX) g_gemm_prof[blockIdx.x][k] = wall_clock64();                            \
+        if (threadIdx.x == 0 && prof_idx < GS_PROF_MAX) g_gemm_prof[prof_idx][k] = wall_clock64();                                \
     } while (0)
 #else
 #define GS_T(k)
@@ -167,11 +167,18 @@ __global__ __launch_bounds__(GS_TPB) void k_split_rows(const float *__restrict__
 // every weight fragment read from LDS feeds MR * 3 MFMAs, every activation fragment NT * 3.
 // APIECES: A comes as P32 pieces (made by the producing kernel) — otherwise as f32 rows, split in registers.
 // CPIECES: C leaves as P32 pieces scaled by c_scale (the hidden tensor of the MLP: read by the next GEMM only).
+// One tile of a persistent workgroup.  primed: the first two A chunks (xf, xg) and the first weight chunk (LDS buffer `par`) were
+// requested / staged by the tile before, under its last two K chunks; has_next: do the same for the tile (next_tm, next_n0) — of
+// the same shape — so that a workgroup's tiles form one continuous stream of chunks and only its first tile pays the latency of
+// a prologue.  par: parity of the LDS buffer that holds chunk 0 (advances by the chunk count per tile).
+template <int MR> struct gs_xf { typedef uint32_t type __attribute__((ext_vector_type(16 * MR))); };
 template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
-__device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__restrict__ Av, int64_t M, int K,
+__device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, const float *bias_lds, const void *__restrict__ Av, int64_t M, int K,
                                                 const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
-                                                const float *__restrict__ bias, const float *R, void *Cv,
-                                                float a_scale, float out_scale, float c_scale, int64_t tm, int n0)
+                                                const float *R, void *Cv,
+                                                float a_scale, float out_scale, float c_scale, int64_t tm, int n0, bool primed,
+                                                bool has_next, int64_t next_tm, int next_n0, int &par, typename gs_xf<MR>::type &xf,
+                                                typename gs_xf<MR>::type &xg, int prof_idx)
 {
     constexpr int WROWS = WC * NT * 32;                                       // Ws: [2][2][WROWS][GS_PITCH]
     constexpr int TROWS = WR * MR * 32;
@@ -182,34 +189,28 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
     const int wr = w / WC, wc = w - wr * WC;
     const int i = lane & 31, g = lane >> 5;
 #ifdef BSC_GEMM_PROFILE
-    if (threadIdx.x == 0 && blockIdx.x < GS_PROF_MAX) {
+    if (threadIdx.x == 0 && prof_idx < GS_PROF_MAX) {
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_gemm_prof[blockIdx.x][0] = ((uint64_t)xcc << 32) | hw;
+        g_gemm_prof[prof_idx][0] = ((uint64_t)xcc << 32) | hw;
     }
     GS_T(1);
 #endif
     const int64_t row0 = tm * TROWS + wr * (MR * 32);
-    // the bias values of the wavefront's column strip, four per lane (they reach the epilogue through LDS)
-    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias && 4 * lane < NT * 32) {
-        const int nb = n0 + wc * NT * 32 + 4 * lane;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (nb + e < N) bias4[e] = bias[nb + e];
-    }
     // per-lane row base: f32 rows (16 floats of the chunk per lane) or P32 pieces (8 halfs of either piece per sub-step)
-    const char *arow[MR];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-        const int64_t row = row0 + mr * 32 + i;
+    auto row_base = [&](int64_t first_row, int mr) {
+        const int64_t row = first_row + mr * 32 + i;
         const int64_t rc = row < M ? row : M - 1;                           // clamped: padded rows are not stored
         // lane group g contracts k = 16 g + 8 sstep + (0..7) of the chunk in sub-step sstep — the same split of the 32 on both operands
-        arow[mr] = APIECES ? (const char *)((const uint16_t *)Av + rc * 2 * K + g * 16) : (const char *)((const float *)Av + rc * K + g * 16);
-    }
+        return APIECES ? (const char *)((const uint16_t *)Av + rc * 2 * K + g * 16) : (const char *)((const float *)Av + rc * K + g * 16);
+    };
+    const char *arow[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) arow[mr] = row_base(row0, mr);
     const int nchunks = K / GS_KC;
+    has_next = has_next && nchunks >= 2;
     f32x16 acc[MR][NT];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
@@ -217,45 +218,55 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mr][t][r] = 0.f;
-    // prefetch registers as first-class vector values (an array that is live across the chunk loop would be left in scratch)
-    typedef uint32_t xf_t __attribute__((ext_vector_type(16 * MR)));
+    // prefetch registers as first-class vector values (an array that is live across the chunk loop would be left in scratch):
+    // xf = the A chunk about to be used, xg = the one after it (two chunks of load latency hidden)
+    typedef typename gs_xf<MR>::type xf_t;
     typedef uint32_t qr_t __attribute__((ext_vector_type(4 * NLD)));
-    xf_t xf, xg;             // A: the chunk about to be used, and the one after it (two chunks of load latency hidden)
     qr_t qr;
-    auto load_a = [&](xf_t &xf, int c) {
+    auto load_a = [&](xf_t &xf, const char *const (&ar)[MR], int c) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int v4 = 0; v4 < 4; ++v4) {
                 // f32: floats [4 v4, 4 v4 + 4) of the lane's 16; pieces: v4 = 2 piece + sub-step -> halfs [16 g + 8 sstep, + 8) of the piece
-                const uint4 v = APIECES ? *(const uint4 *)(arow[mr] + (int64_t)c * 128 + (v4 >> 1) * 64 + (v4 & 1) * 16)
-                                        : *(const uint4 *)(arow[mr] + (int64_t)c * 128 + 16 * v4);
+                const uint4 v = APIECES ? *(const uint4 *)(ar[mr] + (int64_t)c * 128 + (v4 >> 1) * 64 + (v4 & 1) * 16)
+                                        : *(const uint4 *)(ar[mr] + (int64_t)c * 128 + 16 * v4);
                 xf[16 * mr + 4 * v4] = v.x; xf[16 * mr + 4 * v4 + 1] = v.y; xf[16 * mr + 4 * v4 + 2] = v.z; xf[16 * mr + 4 * v4 + 3] = v.w;
             }
     };
-    auto load_w = [&](int c) {
+    // weight chunk: thread tid moves the 16-byte part tid & 3 of row (tid >> 2) + PR jj of piece plane p, j = p PPP + jj — ONE
+    // per-thread pointer and LDS offset; everything else in the addresses is uniform
+    constexpr int PR = NTHR / 4, PPP = WROWS / PR;
+    static_assert(WROWS % PR == 0 && NLD == 2 * PPP, "weight staging plan");
+    // (buffer loads: a 32-bit per-thread offset + a scalar offset.  With 64-bit pointers the compiler kept one loop-invariant
+    // pointer per j in registers — and, in the persistent form of this kernel, in scratch.)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)(4 * w_plane), 0x00020000);
+    const int wthr = ((tid >> 2) * K + (tid & 3) * 8) * 2;
+    const int lthr = (tid >> 2) * GS_PITCH + (tid & 3) * 8;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto load_w = [&](int nbase, int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int e = tid + NTHR * j, p = e / (WROWS * 4), rem = e - p * (WROWS * 4), n = rem >> 2, part = rem & 3;
-            const uint4 v = *(const uint4 *)(Wp + (int64_t)p * w_plane + (int64_t)(n0 + n) * K + c * GS_KC + part * 8);
-            qr[4 * j] = v.x; qr[4 * j + 1] = v.y; qr[4 * j + 2] = v.z; qr[4 * j + 3] = v.w;
+            const int uni = (int)(((int64_t)(j / PPP) * w_plane + (int64_t)(nbase + (j % PPP) * PR) * K + c * GS_KC) * 2);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wthr, uni, 0);
+            qr[4 * j] = v[0]; qr[4 * j + 1] = v[1]; qr[4 * j + 2] = v[2]; qr[4 * j + 3] = v[3];
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = tid + NTHR * j, p = e / (WROWS * 4), rem = e - p * (WROWS * 4), n = rem >> 2, part = rem & 3;
-            *(uint4 *)&Ws[buf * BUF + (p * WROWS + n) * GS_PITCH + part * 8] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
-        }
+        for (int j = 0; j < NLD; ++j)
+            *(uint4 *)&Ws[buf * BUF + lthr + ((j / PPP) * WROWS + (j % PPP) * PR) * GS_PITCH] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
     };
-    load_a(xf, 0);
-    load_w(0);
-    if (nchunks > 1) load_a(xg, 1);
-    store_w(0);
-    __syncthreads();
+    if (!primed) {
+        load_a(xf, arow, 0);
+        load_w(n0, 0);
+        if (nchunks > 1) load_a(xg, arow, 1);
+        store_w(par);
+        __syncthreads();
+    }
     GS_T(2);
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+        const int buf = (c + par) & 1;
         // this chunk's rows as fp16 pieces (two sub-steps of 8 halfs), then the next chunk's loads go in flight
         uint32_t ah[MR][2][4], al[MR][2][4];
 #pragma unroll
@@ -277,8 +288,16 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
             }
         }
         xf = xg;
-        if (c + 2 < nchunks) load_a(xg, c + 2);
-        if (c + 1 < nchunks) load_w(c + 1);
+        // ONE load site per operand: the last two chunks request the next tile's first two (a second load site under its own
+        // branch made the compiler merge the two results with register copies — and wait for the loads right there)
+        const bool a_next = c + 2 >= nchunks, w_next = c + 1 >= nchunks;
+        if (!a_next || has_next) {
+            const char *ap[MR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) ap[mr] = a_next ? row_base(next_tm * TROWS + wr * (MR * 32), mr) : arow[mr];
+            load_a(xg, ap, a_next ? c + 2 - nchunks : c + 2);
+        }
+        if (!w_next || has_next) load_w(w_next ? next_n0 : n0, w_next ? 0 : c + 1);
         const uint16_t *wb = &Ws[buf * BUF + (wc * NT * 32 + i) * GS_PITCH + g * 16];
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
@@ -304,9 +323,10 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
                 for (int t = 0; t < NT; ++t)
                     acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t], *(const half8_t *)ah[mr][sstep], acc[mr][t], 0, 0, 0);     // h h
         }
-        if (c + 1 < nchunks) store_w(buf ^ 1);
+        if (c + 1 < nchunks || has_next) store_w(buf ^ 1);
         __syncthreads();
     }
+    par = (par + nchunks) & 1;
     GS_T(3);
     // The weights are the MFMA's FIRST operand (D' = W X^T): lane (i, g) of accumulator tile (mr, t) holds ROW row0 + 32 mr + i of C
     // and, in registers 4 q .. 4 q + 3, the four consecutive columns 32 t + 8 q + 4 g + (0..3) of the wavefront's strip.  A 32 x 32
@@ -321,12 +341,10 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
     float *C = (float *)Cv;
     uint16_t *Cp = (uint16_t *)Cv;
     constexpr int EP = 136;                                                 // staged row pitch, bytes: conflict-free 8-byte writes
-    constexpr int WLB = 32 * EP + NT * 32 * 4;                              // per wavefront: one tile + the bias values of its strip
+    constexpr int WLB = 32 * EP;                                            // per wavefront: one tile
     constexpr int RD = 3;
-    char *wl = (char *)Ws + w * WLB;
-    float *bs = (float *)(wl + 32 * EP);
-    if (4 * lane < NT * 32) *(f32x4_t *)&bs[4 * lane] = bias4;
-    gs_wave_lds_order();
+    char *wl = epi_lds + w * WLB;                                           // beyond the weight buffers: the next tile's chunk 0 may sit there
+    const float *bs = bias_lds + n0 + wc * NT * 32;                         // the bias values of the wavefront's column strip
     const int rl = lane >> 3, seg = lane & 7;                               // line phase: row rl + 8 k of the tile, 16-byte segment seg
     auto epilogue = [&](const bool chk) __attribute__((always_inline)) {
 #pragma unroll
@@ -414,34 +432,54 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, const void *__rest
 #endif
 }
 
-// XCD k (= workgroup id mod 8) takes the row tiles k, k + 8, ... and walks all column tiles of one before the next.  q_full: the
-// first q_full tiles of every XCD run whole; the rest — a last, partly filled round of workgroups (N = 768: 888 tiles on 256 CUs
-// are 3.47 rounds) — run as two half-width tiles each, so that round costs half a tile's time instead of a whole one.
+// Persistent workgroups, one per CU: workgroup p serves XCD p mod 8 (the hardware deals consecutive workgroup ids round the XCDs) and
+// walks that XCD's tile list q = p / 8, p / 8 + per_round, ...  XCD k takes the row tiles k, k + 8, ... and all column tiles of one
+// before the next (the 786 KB A tile is fetched into that XCD's L2 once).  q_full: the first q_full list entries of every XCD
+// are whole tiles; the rest — a last, partly filled round (N = 768: 888 tiles on 256 CUs are 3.47 rounds) — are split into two
+// half-width tiles each, so that round costs half a tile's time instead of a whole one.
 template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
 __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restrict__ Av, int64_t M, int K,
                                                              const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
                                                              const float *__restrict__ bias, const float *R, void *Cv,
                                                              float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m,
-                                                             int64_t q_full)
+                                                             int64_t q_full, int64_t q_virtual, int per_round, int epi_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];
-    const int64_t wg = blockIdx.x;
-    const int xcd = (int)(wg & 7);
-    const int64_t q = wg >> 3;
-    if (NT % 2 || q < q_full) {
-        const int tn = (int)(q % n_tiles_n);
-        const int64_t tm = (q / n_tiles_n) * 8 + xcd;
-        if (tm >= n_tiles_m) return;
-        gemm_split_tile<MR, NT, WR, WC, EPI, APIECES, CPIECES>(Ws, Av, M, K, Wp, w_plane, N, bias, R, Cv, a_scale, out_scale, c_scale, tm,
-                                                               tn * (WC * NT * 32));
-    } else {
-        constexpr int NH = NT % 2 ? NT : NT / 2;
-        const int64_t qt = q_full + ((q - q_full) >> 1);
-        const int tn = (int)(qt % n_tiles_n);
-        const int64_t tm = (qt / n_tiles_n) * 8 + xcd;
-        if (tm >= n_tiles_m) return;
-        gemm_split_tile<MR, NH, WR, WC, EPI, APIECES, CPIECES>(Ws, Av, M, K, Wp, w_plane, N, bias, R, Cv, a_scale, out_scale, c_scale, tm,
-                                                               tn * (WC * NT * 32) + (int)((q - q_full) & 1) * (WC * NH * 32));
+    constexpr bool HALF_OK = NT % 2 == 0 && (WC * (NT / 2) * 32) % (16 * WR * WC) == 0;       // the half tile's weight staging plan exists
+    constexpr int NH = HALF_OK ? NT / 2 : NT;
+    const int xcd = (int)(blockIdx.x & 7);
+    typename gs_xf<MR>::type xf, xg;
+    int par = 0;
+    bool primed = false;
+    struct Tile { int64_t tm; int n0; bool half, valid; };
+    auto decode = [&](int64_t qv) {
+        Tile t;
+        t.half = HALF_OK && qv >= q_full;
+        const int64_t qt = t.half ? q_full + ((qv - q_full) >> 1) : qv;
+        t.tm = (qt / n_tiles_n) * 8 + xcd;
+        t.n0 = (int)(qt % n_tiles_n) * (WC * NT * 32) + (t.half ? (int)((qv - q_full) & 1) * (WC * NH * 32) : 0);
+        t.valid = qv < q_virtual && t.tm < n_tiles_m;
+        return t;
+    };
+    // the whole (padded) bias row, once per workgroup, behind the epilogue's tile blocks
+    char *epi_lds = (char *)Ws + epi_off;
+    float *bias_lds = (float *)(epi_lds + (WR * WC) * (32 * 136));
+    for (int e = threadIdx.x; e < n_tiles_n * (WC * NT * 32); e += 64 * WR * WC) bias_lds[e] = (bias && e < N) ? bias[e] : 0.f;
+    __syncthreads();
+    for (int64_t qv = blockIdx.x >> 3; qv < q_virtual; qv += per_round) {
+        const Tile cur = decode(qv), nxt = decode(qv + per_round);
+        if (!cur.valid) { primed = false; continue; }
+        const bool has_next = nxt.valid && nxt.half == cur.half;
+        const int prof_idx = (int)(qv * 8 + xcd);
+        if (!cur.half)
+            gemm_split_tile<MR, NT, WR, WC, EPI, APIECES, CPIECES>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
+                                                                   out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0, par,
+                                                                   xf, xg, prof_idx);
+        else
+            gemm_split_tile<MR, NH, WR, WC, EPI, APIECES, CPIECES>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
+                                                                   out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0, par,
+                                                                   xf, xg, prof_idx);
+        primed = has_next && K / GS_KC >= 2;
     }
 }
 
@@ -748,10 +786,12 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const int64_t q_all = groups * n_tiles_n, per_round = n_cu / 8 > 0 ? n_cu / 8 : 1;
     const int64_t q_rem = q_all % per_round;
     const int64_t q_full = (tile == 1 && tail_env && q_rem > 0 && 2 * q_rem <= per_round && q_all > per_round) ? q_all - q_rem : q_all;
-    const int64_t n_wg = (q_full + 2 * (q_all - q_full)) * 8;
+    const int64_t q_virtual = q_full + 2 * (q_all - q_full);
+    const int64_t n_wg = (q_virtual < per_round ? q_virtual : per_round) * 8;     // persistent: one workgroup per CU
     const size_t lds_loop = (size_t)2 * 2 * TCOLS * GS_PITCH * sizeof(uint16_t);
-    const size_t lds_epi = (size_t)(NTHR / 64) * (32 * 136 + TCOLS * 4);          // the epilogue's per-wavefront tile + bias strip
-    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    const size_t lds_epi = (size_t)(NTHR / 64) * (32 * 136);                      // the epilogue's per-wavefront tile blocks
+    const size_t lds = lds_loop + lds_epi + (size_t)n_pad * sizeof(float);        // + the bias row
+    if (lds > 160 * 1024) { bsc_set_error("bsc_enc_gemm_split: N = %d does not fit the kernel's LDS plan (bias row)", N); return BSC_E_INVALID; }
     hipStream_t s = (hipStream_t)hip_stream;
     const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
 #define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
@@ -759,12 +799,12 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
         static bool attr_set = false;                                                                                                \
         if (!attr_set) {                                                                                                             \
             BSC_HIP(hipFuncSetAttribute((const void *)k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>,                              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                      \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
         hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, M, K,\
                            (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
-                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full);                                                       \
+                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full, q_virtual, (int)per_round, (int)lds_loop);                   \
     } while (0)
 #define BSC_GEMM_LAUNCH(EPIV, APV, CPV)                                                                                              \
     do {                                                                                                                             \
@@ -795,7 +835,7 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
         static uint64_t host[GS_PROF_MAX][6];
         BSC_HIP(hipStreamSynchronize(s));
         BSC_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_prof), sizeof(host)));
-        const int64_t n = n_wg < GS_PROF_MAX ? n_wg : GS_PROF_MAX;
+        const int64_t n = q_virtual * 8 < GS_PROF_MAX ? q_virtual * 8 : GS_PROF_MAX;
         for (int64_t w = 0; w < n; ++w)
             fprintf(stderr, "GP %lld %llx %llu %llu %llu %llu %llu\n", (long long)w, (unsigned long long)host[w][0], (unsigned long long)host[w][1],
                     (unsigned long long)host[w][2], (unsigned long long)host[w][3], (unsigned long long)host[w][4], (unsigned long long)host[w][5]);
