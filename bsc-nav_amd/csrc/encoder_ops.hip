@@ -281,6 +281,10 @@ extern "C" bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *del
 // stream and one write of y per LayerNorm instead of two reads and two writes (k_add_layernorm), and the residual add
 // itself happens in the GEMM's f32 accumulator (one rounding to bf16 instead of two).
 // SKIP > 0: only rows [skip, T) of every image are normalised and written densely (the final LayerNorm of the patch rows).
+// A wavefront takes BLN_RPW consecutive rows: gamma, beta and the bias sums (5 x the bytes of a bf16 row) are loaded once per
+// wavefront instead of once per row — they come out of the L1, whose bandwidth they otherwise share with the rows — and the rows'
+// loads are all requested before the first reduction.
+#define BLN_RPW 4
 template <int NG, int OUT>      // OUT 0: bf16, 1: f32 (the bf16-rounded value widened)
 __global__ __launch_bounds__(TPB) void k_bias_layernorm(const ushort4 *__restrict__ u, const float4 *__restrict__ bias_sum,
                                                         const ushort4 *__restrict__ gamma, const ushort4 *__restrict__ beta,
@@ -288,36 +292,49 @@ __global__ __launch_bounds__(TPB) void k_bias_layernorm(const ushort4 *__restric
                                                         float eps)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t orow = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
-    if (orow >= rows_out) return;
+    const int64_t orow0 = (((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6) * BLN_RPW;
+    if (orow0 >= rows_out) return;
     const int w4 = width >> 2;
-    int64_t row = orow;
-    if (skip > 0) {
-        const int np = T - skip;
-        const int64_t b = orow / np;
-        row = b * T + skip + (orow - b * np);
-    }
-    float v[NG][4];
+    ushort4 raw[BLN_RPW][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int c = lane + 64 * g;
-        const ushort4 a = u[row * w4 + c];
-        const float4 bs = bias_sum[c];
-        v[g][0] = bf2f(a.x) + bs.x; v[g][1] = bf2f(a.y) + bs.y; v[g][2] = bf2f(a.z) + bs.z; v[g][3] = bf2f(a.w) + bs.w;
-    }
-    float mean, rstd;
-    ln_stats<NG>(v, width, eps, mean, rstd);
+    for (int r = 0; r < BLN_RPW; ++r) {
+        const int64_t orow = orow0 + r < rows_out ? orow0 + r : rows_out - 1;
+        int64_t row = orow;
+        if (skip > 0) {
+            const int np = T - skip;
+            const int64_t b = orow / np;
+            row = b * T + skip + (orow - b * np);
+        }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int c = lane + 64 * g;
-        const ushort4 ga = gamma[c], be = beta[c];
-        ushort4 o;
-        o.x = f2bf((v[g][0] - mean) * rstd * bf2f(ga.x) + bf2f(be.x));
-        o.y = f2bf((v[g][1] - mean) * rstd * bf2f(ga.y) + bf2f(be.y));
-        o.z = f2bf((v[g][2] - mean) * rstd * bf2f(ga.z) + bf2f(be.z));
-        o.w = f2bf((v[g][3] - mean) * rstd * bf2f(ga.w) + bf2f(be.w));
-        if (OUT) ((float4 *)y)[orow * w4 + c] = make_float4(bf2f(o.x), bf2f(o.y), bf2f(o.z), bf2f(o.w));
-        else ((ushort4 *)y)[orow * w4 + c] = o;
+        for (int g = 0; g < NG; ++g) raw[r][g] = u[row * w4 + lane + 64 * g];
+    }
+    float4 bs[NG];
+    ushort4 ga[NG], be[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { bs[g] = bias_sum[lane + 64 * g]; ga[g] = gamma[lane + 64 * g]; be[g] = beta[lane + 64 * g]; }
+#pragma unroll
+    for (int r = 0; r < BLN_RPW; ++r) {
+        const int64_t orow = orow0 + r;
+        if (orow >= rows_out) break;
+        float v[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const ushort4 a = raw[r][g];
+            v[g][0] = bf2f(a.x) + bs[g].x; v[g][1] = bf2f(a.y) + bs[g].y; v[g][2] = bf2f(a.z) + bs[g].z; v[g][3] = bf2f(a.w) + bs[g].w;
+        }
+        float mean, rstd;
+        ln_stats<NG>(v, width, eps, mean, rstd);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int c = lane + 64 * g;
+            ushort4 o;
+            o.x = f2bf((v[g][0] - mean) * rstd * bf2f(ga[g].x) + bf2f(be[g].x));
+            o.y = f2bf((v[g][1] - mean) * rstd * bf2f(ga[g].y) + bf2f(be[g].y));
+            o.z = f2bf((v[g][2] - mean) * rstd * bf2f(ga[g].z) + bf2f(be[g].z));
+            o.w = f2bf((v[g][3] - mean) * rstd * bf2f(ga[g].w) + bf2f(be[g].w));
+            if (OUT) ((float4 *)y)[orow * w4 + c] = make_float4(bf2f(o.x), bf2f(o.y), bf2f(o.z), bf2f(o.w));
+            else ((ushort4 *)y)[orow * w4 + c] = o;
+        }
     }
 }
 
@@ -331,7 +348,7 @@ extern "C" bsc_status bsc_enc_bias_layernorm(const void *u_dev, const void *bias
         return BSC_E_INVALID;
     }
     const int64_t rows = (int64_t)B * (T - skip);
-    const dim3 grid((unsigned)((rows * 64 + TPB - 1) / TPB)), block(TPB);
+    const dim3 grid((unsigned)(((rows + BLN_RPW - 1) / BLN_RPW * 64 + TPB - 1) / TPB)), block(TPB);
 #define BL(NG)                                                                                                                  \
     do {                                                                                                                        \
         if (out_f32)                                                                                                            \
