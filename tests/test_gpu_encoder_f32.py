@@ -12,11 +12,13 @@ def _pieces_back(p, M, K, scale=1.0):
     return (v[:, :, 0].double() + v[:, :, 1].double()).reshape(M, K) / scale
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 768, 2304), (777, 3072, 768), (257, 64, 96), (31, 32, 8), (50, 64, 30), (20741, 64, 768)])
+@pytest.mark.parametrize("M,K,N", [(1000, 768, 2304), (777, 3072, 768), (257, 64, 96), (31, 32, 8), (50, 64, 30), (20741, 64, 768), (20741, 64, 2304)])
 @pytest.mark.parametrize("epilogue", [0, 1, 2])
 def test_split_gemm_matches_fp32_linear(M, K, N, epilogue):
     """out = epilogue(A W^T + b): within a few f32 ulps of the fp64 result — at least as close as torch's own f32 GEMM — for f32
-    rows and for pre-split pieces, ragged M / N (tile edges), every epilogue."""
+    rows and for pre-split pieces, ragged M / N (tile edges), every epilogue.  M = 20741: more tiles than CUs — N = 768 takes the
+    half-width tiles of the last round, N = 2304 gives every persistent workgroup several tiles (the next tile's first chunks
+    requested under the last ones); N = 30: the element-by-element epilogue."""
     import torch
     import torch.nn.functional as F
     from bsc_nav_amd import encoder
