@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — RGB-D frames/s into the voxel feature memory (BASELINE.json metric), one rank per GPU.
 
-A step = one batch of synthetic 640x480 RGB-D frames through the hot path, inputs resident in HBM:
+A step = one batch (--batch, default 768) of synthetic 640x480 RGB-D frames through the hot path, inputs resident in HBM:
     ViT patch features (random weights, bf16 MFMA via PyTorch-ROCm/hipBLASLt + libbscnav's fused kernels)
     -> libbscnav bsc_ingest (fp64 unprojection, first-touch voxel ids, rgb chain, top-down map, dense per-voxel
        feature reduce).
