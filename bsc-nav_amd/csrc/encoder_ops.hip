@@ -284,7 +284,9 @@ extern "C" bsc_status bsc_enc_final_layernorm(const void *x_dev, const void *del
 // A wavefront takes BLN_RPW consecutive rows: gamma, beta and the bias sums (5 x the bytes of a bf16 row) are loaded once per
 // wavefront instead of once per row — they come out of the L1, whose bandwidth they otherwise share with the rows — and the rows'
 // loads are all requested before the first reduction.
+#ifndef BLN_RPW
 #define BLN_RPW 4
+#endif
 template <int NG, int OUT>      // OUT 0: bf16, 1: f32 (the bf16-rounded value widened)
 __global__ __launch_bounds__(TPB) void k_bias_layernorm(const ushort4 *__restrict__ u, const float4 *__restrict__ bias_sum,
                                                         const ushort4 *__restrict__ gamma, const ushort4 *__restrict__ beta,
