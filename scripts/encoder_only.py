@@ -3,11 +3,11 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import shutil, tempfile
-_src = os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
+_src = os.environ.get("BSC_TUNABLEOP_FILE") or os.path.join(ROOT, "bsc-nav_amd", "tunableop_gfx950.csv")
 _dst = os.path.join(tempfile.gettempdir(), f"bsc_tunableop_{os.getpid()}_.csv")
 if not os.environ.get("BSC_TUNE_FRESH"):
     shutil.copy(_src, _dst[:-4] + "0.csv")
-os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=_dst, PYTORCH_TUNABLEOP_VERBOSE="0")
+os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING=os.environ.get("BSC_TUNING", "1"), PYTORCH_TUNABLEOP_FILENAME=_dst, PYTORCH_TUNABLEOP_VERBOSE="0")
 import torch
 if os.environ.get("BSC_FA"):
     print("fa library ->", os.environ["BSC_FA"], torch.backends.cuda.preferred_rocm_fa_library(os.environ["BSC_FA"]))
@@ -20,7 +20,7 @@ for _ in range(3):
     vit.patch_tokens(rgb)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 8
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 for _ in range(n):
     vit.patch_tokens(rgb)
 torch.cuda.synchronize()
