@@ -724,3 +724,28 @@ def test_simulator_driven_loops_over_a_fake_env(tmp_path):
     mem2.explore_entire_space(max_iterations=2)
     assert mem2.max_id > 100 and (mem2.cv_map.sum(-1) != 0).sum() > 50
     assert hasattr(mem2, "FrontierMap") or mem2.find_frontiers(mem2.build_navigable_mask()) == []
+
+
+@pytest.mark.parametrize("B,T,skip,out_f32", [(3, 7, 0, 0), (5, 9, 2, 0), (2, 197, 1, 1), (1, 1, 0, 0)])
+def test_bias_layernorm_rows_and_tails(B, T, skip, out_f32):
+    """bsc_enc_bias_layernorm (four rows per wavefront): row counts that are not multiples of four, the skip form (final
+    LayerNorm of the patch rows only), f32 output = the bf16 result widened; against LayerNorm(u + bias_sum) in f32."""
+    import ctypes as C
+    import torch
+    from bsc_nav_amd import _lib
+    torch.manual_seed(B * 100 + T)
+    Wd = 768
+    u = torch.randn(B, T, Wd, device="cuda").to(torch.bfloat16)
+    bs = 0.3 * torch.randn(Wd, device="cuda")
+    ga = (1 + 0.2 * torch.randn(Wd, device="cuda")).to(torch.bfloat16)
+    be = (0.2 * torch.randn(Wd, device="cuda")).to(torch.bfloat16)
+    y = torch.full((B, T - skip, Wd), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    _lib.check(_lib.load().bsc_enc_bias_layernorm(C.c_void_p(u.data_ptr()), C.c_void_p(bs.data_ptr()), C.c_void_p(ga.data_ptr()),
+                                                  C.c_void_p(be.data_ptr()), C.c_void_p(y.data_ptr()), out_f32, B, T, skip, Wd, 1e-6,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ref = torch.nn.functional.layer_norm(u.float()[:, skip:] + bs, (Wd,), ga.float(), be.float(), 1e-6)
+    assert torch.isfinite(y.float()).all()
+    if out_f32:
+        assert torch.equal(y, y.to(torch.bfloat16).float())
+    # one bf16 rounding of the result: half an ulp of |ref| (2^-9 relative) plus the f32 noise of the statistics
+    assert ((y.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all()
