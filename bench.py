@@ -101,7 +101,7 @@ def ingest_alg_bytes(F, N, g, D, tok_bytes, U, P_sampled=0):
     return F * (8 * N + g * g * D * tok_bytes) + U * (2 * D * 4 + 8) + U * 2 * (3 + 4 + 12) + 4 * P_sampled
 
 
-def pmc_traffic():
+def pmc_traffic(frames_per_call):
     """HBM-side bytes per bsc_ingest call from the committed rocprofv3 PMC passes of this same workload
     (profiles/r04_pmc_ingest_kernels.json, scripts/pmc_summary.py: read / write requests of the L2's memory side counted by
     request size — 32 / 64 / 128 B —, two separate --pmc passes, summed over the call's kernels; the counters are checked on
@@ -109,6 +109,8 @@ def pmc_traffic():
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
+        if d.get("frames_per_call", frames_per_call) != frames_per_call:      # measured at another --batch: no figure
+            return None, None
         return float(d["ingest_traffic_bytes_per_call"]), d.get("commit")
     except Exception:
         return None, None
@@ -772,7 +774,7 @@ def main():
         ing_ms = stage_timed["bsc_ingest"]
         single = {k: v for k, v in stage_timed.items() if k in ("k_points", "k_keys_pairs", "k_dense_reduce")}
         dom = max(single, key=single.get)
-        traffic, traffic_commit = pmc_traffic()
+        traffic, traffic_commit = pmc_traffic(a.batch)
         wall = iso["ingest_wall_ms"]
         out["roofline"] = {
             "bound": "hbm", "kernel": "bsc_ingest: one call followed by bsc_sync, alone on the chip — main-stream kernels, the per-voxel point "
