@@ -38,6 +38,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define GS_KC 32                 // K chunk
 #define GS_PITCH 40              // fp16 elements per staged weight row (80 bytes)
 #define GS_TPB 256
+#ifndef GS_RESID_DEPTH
+#define GS_RESID_DEPTH 3             // tiles of residual rows in flight in the epilogue (incl. the one in use)
+#endif
 #ifndef BSC_GEMM_NARROW_TILE
 #define BSC_GEMM_NARROW_TILE 1           // tile variant for N <= 1024 (see bsc_enc_gemm_split)
 #endif
@@ -342,7 +345,7 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
     uint16_t *Cp = (uint16_t *)Cv;
     constexpr int EP = 136;                                                 // staged row pitch, bytes: conflict-free 8-byte writes
     constexpr int WLB = 32 * EP;                                            // per wavefront: one tile
-    constexpr int RD = 3;
+    constexpr int RD = GS_RESID_DEPTH;
     char *wl = epi_lds + w * WLB;                                           // beyond the weight buffers: the next tile's chunk 0 may sit there
     const float *bs = bias_lds + n0 + wc * NT * 32;                         // the bias values of the wavefront's column strip
     const int rl = lane >> 3, seg = lane & 7;                               // line phase: row rl + 8 k of the tile, 16-byte segment seg
