@@ -149,6 +149,94 @@ __global__ __launch_bounds__(GS_TPB) void k_layernorm_split(const float *__restr
     }
 }
 
+// Token assembly of the f32 forward + the first LayerNorm, one pass (one wavefront per token row): row (b, 0) = cls + pos[0], rows
+// (b, 1 .. R) = the register tokens (no position term), rows (b, 1 + R + j) = patch[b][j] + pos[1 + j] -> the residual stream u
+// (f32) and LayerNorm(u) as the pieces the first qkv GEMM reads.
+template <int VPL>
+__global__ __launch_bounds__(GS_TPB) void k_embed_layernorm_split(const float *__restrict__ patch, const float *__restrict__ cls,
+                                                                  const float *__restrict__ reg, const float *__restrict__ pos,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                  int64_t rows, int T, int R, float eps, float *__restrict__ u,
+                                                                  uint16_t *__restrict__ out)
+{
+    constexpr int Wd = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const int64_t b = row / T;
+    const int t = (int)(row - b * T);
+    const int np = T - 1 - R;
+    const float4 *src = (const float4 *)(t == 0 ? cls : t <= R ? reg + (int64_t)(t - 1) * Wd : patch + (b * np + (t - 1 - R)) * Wd);
+    const float4 *pp = (t >= 1 && t <= R) ? nullptr : (const float4 *)(pos + (int64_t)(t == 0 ? 0 : t - R) * Wd);
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j] = src[lane + 64 * j];
+        if (pp) { const float4 q = pp[lane + 64 * j]; v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w; }
+        ((float4 *)(u + row * Wd))[lane + 64 * j] = v[j];
+        sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / Wd);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / Wd) + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int k = 4 * (lane + 64 * j);
+        const float4 gm = ((const float4 *)gamma)[lane + 64 * j], bt = ((const float4 *)beta)[lane + 64 * j];
+        uint32_t h0, l0, h1, l1;
+        split2(v[j].x * rstd * gm.x + bt.x, v[j].y * rstd * gm.y + bt.y, h0, l0);
+        split2(v[j].z * rstd * gm.z + bt.z, v[j].w * rstd * gm.w + bt.w, h1, l1);
+        uint16_t *o = out + p32_off(row, Wd, k);
+        *(uint2 *)o = make_uint2(h0, h1);
+        *(uint2 *)(o + 32) = make_uint2(l0, l1);
+    }
+}
+
+// The final LayerNorm of the f32 forward over the PATCH rows only (cls and register rows skipped), written as the token tensor
+// (B, g*g, width) f32 the memory path reads (memory_2.py:739 x_norm_patchtokens)
+template <int VPL>
+__global__ __launch_bounds__(GS_TPB) void k_final_layernorm_f32(const float *__restrict__ u, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, int64_t out_rows, int T, int skip,
+                                                                float eps, float *__restrict__ out)
+{
+    constexpr int Wd = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t orow = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) >> 6;
+    if (orow >= out_rows) return;
+    const int np = T - skip;
+    const int64_t b = orow / np;
+    const int64_t row = b * T + skip + (orow - b * np);
+    const float4 *xr = (const float4 *)(u + row * Wd);
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { v[j] = xr[lane + 64 * j]; sum += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / Wd);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / Wd) + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const float4 gm = ((const float4 *)gamma)[lane + 64 * j], bt = ((const float4 *)beta)[lane + 64 * j];
+        ((float4 *)(out + orow * Wd))[lane + 64 * j] =
+            make_float4(v[j].x * rstd * gm.x + bt.x, v[j].y * rstd * gm.y + bt.y, v[j].z * rstd * gm.z + bt.z, v[j].w * rstd * gm.w + bt.w);
+    }
+}
+
 // f32 rows -> pieces (attention output, patch matrix)
 __global__ __launch_bounds__(GS_TPB) void k_split_rows(const float *__restrict__ x, int64_t M, int K, float a_scale,
                                                        uint16_t *__restrict__ out)
@@ -711,6 +799,17 @@ __global__ __launch_bounds__(64 * NW) void k_attention_split(const uint16_t *__r
     }
 }
 
+// current device ordinal and its CU count (cached per ordinal; kernel attributes and the persistent grids are per device)
+static bsc_status gs_device(int *dev, int *n_cu)
+{
+    static int cus[64] = {0};
+    BSC_HIP(hipGetDevice(dev));
+    int &c = cus[*dev & 63];
+    if (!c) BSC_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, *dev));
+    *n_cu = c;
+    return BSC_OK;
+}
+
 extern "C" bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                                               void *out_pieces_dev, float out_scale, int32_t *work2_dev, void *hip_stream)
 {
@@ -720,22 +819,18 @@ extern "C" bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_
         return BSC_E_INVALID;
     }
     hipStream_t s = (hipStream_t)hip_stream;
-    static int n_cu = 0;                // one workgroup per CU
-    if (!n_cu) {
-        int dev = 0;
-        BSC_HIP(hipGetDevice(&dev));
-        BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int dev = 0, n_cu = 0;              // one workgroup per CU of the CURRENT device (attributes are per device)
+    BSC_TRY(gs_device(&dev, &n_cu));
     const int64_t items = (int64_t)B * heads;
     const dim3 grid((unsigned)(items < n_cu ? items : n_cu));
 #define BSC_ATT_LAUNCH(NTV, NWV, PFV)                                                                                                   \
     do {                                                                                                                             \
         constexpr int TPv = NTV * 16, VPv = 4 * (((TPv / 4 - 1) | 7) + 1) + 8;                                                       \
         const size_t lds = (size_t)2 * (TPv * 72 + 64 * VPv) * sizeof(uint16_t);                                                     \
-        static bool attr_set = false;                                                                                                \
-        if (!attr_set) {                                                                                                             \
+        static uint64_t attr_set = 0;       /* bit per device ordinal */                                                              \
+        if (!(attr_set >> (dev & 63) & 1)) {                                                                                         \
             BSC_HIP(hipFuncSetAttribute((const void *)k_attention_split<NTV, NWV, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_set = true;                                                                                                         \
+            attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
         hipLaunchKernelGGL((k_attention_split<NTV, NWV, PFV>), grid, dim3(64 * NWV), lds, s, (const uint16_t *)qkv_pieces_dev, T, heads,  \
                            (int)items, (uint16_t *)out_pieces_dev, out_scale, (int *)work2_dev);                                     \
@@ -780,12 +875,8 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
     // a last round that fills at most half of the CUs runs as half-width tiles (tile 1 only; BSC_GEMM_TAIL=0: whole tiles)
     static const int tail_env = getenv("BSC_GEMM_TAIL") ? atoi(getenv("BSC_GEMM_TAIL")) : 1;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        BSC_HIP(hipGetDevice(&dev));
-        BSC_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int dev = 0, n_cu = 0;
+    BSC_TRY(gs_device(&dev, &n_cu));
     const int64_t q_all = groups * n_tiles_n, per_round = n_cu / 8 > 0 ? n_cu / 8 : 1;
     const int64_t q_rem = q_all % per_round;
     const int64_t q_full = (tile == 1 && tail_env && q_rem > 0 && 2 * q_rem <= per_round && q_all > per_round) ? q_all - q_rem : q_all;
@@ -799,11 +890,11 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
 #define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
     do {                                                                                                                             \
-        static bool attr_set = false;                                                                                                \
-        if (!attr_set) {                                                                                                             \
+        static uint64_t attr_set = 0;       /* bit per device ordinal */                                                              \
+        if (!(attr_set >> (dev & 63) & 1)) {                                                                                         \
             BSC_HIP(hipFuncSetAttribute((const void *)k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                      \
-            attr_set = true;                                                                                                         \
+            attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
         hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, M, K,\
                            (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
@@ -872,6 +963,55 @@ extern "C" bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t 
     if (!x_dev || !pieces_dev || M <= 0 || K <= 0 || (K % 32)) { bsc_set_error("bsc_enc_split_rows: K must be a multiple of 32"); return BSC_E_INVALID; }
     hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((M * K / 4 + GS_TPB - 1) / GS_TPB)), dim3(GS_TPB), 0, (hipStream_t)hip_stream, x_dev, M,
                        K, a_scale, (uint16_t *)pieces_dev);
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_embed_layernorm_f32(const float *patch_dev, const float *cls_dev, const float *reg_dev, const float *pos_dev,
+                                                  const float *gamma_dev, const float *beta_dev, int32_t B, int32_t T, int32_t registers,
+                                                  int32_t width, float eps, float *u_dev, void *pieces_dev, void *hip_stream)
+{
+    if (!patch_dev || !cls_dev || !pos_dev || !gamma_dev || !beta_dev || !u_dev || !pieces_dev || B < 1 || T < 2 || registers < 0 ||
+        registers > T - 2 || (registers > 0 && !reg_dev) || (width != 256 && width != 512 && width != 768 && width != 1024)) {
+        bsc_set_error("bsc_enc_embed_layernorm_f32: invalid argument (width must be 256, 512, 768 or 1024)");
+        return BSC_E_INVALID;
+    }
+    const int64_t rows = (int64_t)B * T;
+    const dim3 grid((unsigned)((rows * 64 + GS_TPB - 1) / GS_TPB)), block(GS_TPB);
+    hipStream_t s = (hipStream_t)hip_stream;
+    uint16_t *out = (uint16_t *)pieces_dev;
+#define BSC_EMB(V) hipLaunchKernelGGL(k_embed_layernorm_split<V>, grid, block, 0, s, patch_dev, cls_dev, reg_dev, pos_dev, gamma_dev, beta_dev, \
+                                      rows, T, registers, eps, u_dev, out)
+    switch (width / 256) {
+    case 1: BSC_EMB(1); break;
+    case 2: BSC_EMB(2); break;
+    case 3: BSC_EMB(3); break;
+    default: BSC_EMB(4); break;
+    }
+#undef BSC_EMB
+    BSC_HIP(hipGetLastError());
+    return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_final_layernorm_f32(const float *u_dev, const float *gamma_dev, const float *beta_dev, int32_t B, int32_t T,
+                                                  int32_t skip, int32_t width, float eps, float *out_dev, void *hip_stream)
+{
+    if (!u_dev || !gamma_dev || !beta_dev || !out_dev || B < 1 || skip < 0 || skip >= T ||
+        (width != 256 && width != 512 && width != 768 && width != 1024)) {
+        bsc_set_error("bsc_enc_final_layernorm_f32: invalid argument (width must be 256, 512, 768 or 1024)");
+        return BSC_E_INVALID;
+    }
+    const int64_t rows = (int64_t)B * (T - skip);
+    const dim3 grid((unsigned)((rows * 64 + GS_TPB - 1) / GS_TPB)), block(GS_TPB);
+    hipStream_t s = (hipStream_t)hip_stream;
+#define BSC_FIN(V) hipLaunchKernelGGL(k_final_layernorm_f32<V>, grid, block, 0, s, u_dev, gamma_dev, beta_dev, rows, T, skip, eps, out_dev)
+    switch (width / 256) {
+    case 1: BSC_FIN(1); break;
+    case 2: BSC_FIN(2); break;
+    case 3: BSC_FIN(3); break;
+    default: BSC_FIN(4); break;
+    }
+#undef BSC_FIN
     BSC_HIP(hipGetLastError());
     return BSC_OK;
 }

@@ -1413,6 +1413,18 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
         BSC_TRY(assign_ids(s));
     }
     if (x->hscal[DS_ERROR]) {
+        if (early) {
+            // k_totals has already advanced max_id by the (clipped) count of new voxels: their ids are still assigned — on the side
+            // stream, as the order stage would have done — so that the map the refused call leaves behind is consistent
+            void *const keep_tmp = x->prim_tmp;
+            BSC_HIP(hipStreamWaitEvent(x->side, x->ev_tot, 0));
+            x->stream = x->side; x->prim_tmp = x->prim_tmp_side;
+            const bsc_status ist = assign_ids(x->side);
+            x->stream = s; x->prim_tmp = keep_tmp;
+            BSC_TRY(ist);
+            BSC_HIP(hipEventRecord(x->ev_ids, x->side));
+            BSC_HIP(hipStreamWaitEvent(s, x->ev_ids, 0));
+        }
         bsc_set_error("voxel capacity %d exceeded", x->c.voxel_capacity);
         return BSC_E_CAPACITY;
     }

@@ -875,8 +875,11 @@ static bsc_status select_topk_batched(bsc_ctx *x, const CandArgs &ca, int nq, in
         cur = 0;
         const unsigned nbf = (unsigned)(((int64_t)ca.n_cand + FILT_PER_BLOCK - 1) / FILT_PER_BLOCK);
         if (!ca.exact) {
-            const int64_t words = 2 * (((int64_t)ca.max_id + 63) / 64) + 2;
-            BSC_TRY(grow_dev((void **)&x->l_valid, &x->l_sel_cap[6], sizeof(uint32_t) * words));
+            // every wavefront of the ceil(max_id / TPB) workgroups stores one 64-bit word: TPB / 32 uint32 per workgroup.  Grown with
+            // slack (a map that gains a few voxels between two queries keeps its bitmap allocation)
+            const int64_t words = (TPB / 32) * (((int64_t)ca.max_id + TPB - 1) / TPB) + 2;
+            if ((int64_t)sizeof(uint32_t) * words > x->l_sel_cap[6])
+                BSC_TRY(grow_dev((void **)&x->l_valid, &x->l_sel_cap[6], sizeof(uint32_t) * (words + words / 4 + 1024)));
             if (ca.max_id > 0)
                 hipLaunchKernelGGL(k_valid_bits, dim3((unsigned)((ca.max_id + TPB - 1) / TPB)), dim3(TPB), 0, x->stream, ca.cnt, ca.max_id, x->l_valid);
         }

@@ -353,9 +353,15 @@ class RandomViT(nn.Module):
         """the fp16 pieces of a Linear's weight, made on first use (f32 weights on the device)"""
         cache = self.__dict__.setdefault("_split_cache", {})
         key = id(lin)
-        if key not in cache or cache[key][0] != lin.weight.data_ptr():
-            cache[key] = (lin.weight.data_ptr(), SplitLinear(lin))
+        # in-place updates (load_state_dict, copy_) keep the pointer and bump the version counter
+        tag = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+        if key not in cache or cache[key][0] != tag:
+            cache[key] = (tag, SplitLinear(lin))
         return cache[key][1]
+
+    def invalidate_split_weights(self):
+        """drop the cached fp16 weight pieces (after replacing weights by a route the version counters do not see)"""
+        self.__dict__.pop("_split_cache", None)
 
     def _forward_f32_split(self, t, t_pieces=False):
         """The f32 forward (the reference's precision) with every dense layer on the fp16 matrix cores at f32 accuracy:
@@ -522,12 +528,17 @@ class RandomViT(nn.Module):
 class GraphedEncoder:
     """Replays the encoder for a fixed batch shape from a captured HIP graph (launch-bound at small batch).  The graph starts
     at the patch matrix: the fused preprocessing kernel runs eagerly on the caller's frames and writes the graph's input, so
-    the frames themselves are never copied."""
+    the frames themselves are never copied.  Both precisions: the bf16 encoder (bf16 patch matrix) and the f32 encoder on
+    split-operand GEMMs (patch matrix as fp16 pieces, or f32 rows when 3 p^2 is not a multiple of 32)."""
 
     def __init__(self, vit, batch, H, W, channels=4, keep_dtype=False):
         self.vit, self.keep_dtype = vit, keep_dtype
         probe = torch.zeros((batch, H, W, channels), dtype=torch.uint8, device="cuda")
-        self.from_patches = vit.can_fuse_preprocess(probe) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
+        self.f32 = (not vit.can_fuse_preprocess(probe)) and vit.can_fuse_preprocess_f32(probe)
+        self.pp_mode = 0
+        if self.f32:
+            self.pp_mode = 2 if (3 * vit.patch * vit.patch) % 32 == 0 else 1
+        self.from_patches = (vit.can_fuse_preprocess(probe) or self.f32) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
         s = torch.cuda.Stream()
         # this graph's attention counters: allocated before the capture (outside the graph's private pool), used by every
         # attention launch of the warm-up and of the captured forward
@@ -539,7 +550,10 @@ class GraphedEncoder:
             _ATT_WORK_OVERRIDE.pop()
 
     def _capture(self, vit, batch, probe, keep_dtype, s):
-        if self.from_patches:
+        if self.from_patches and self.f32:
+            self.static_in = vit.preprocess_patches(probe, mode=self.pp_mode)
+            run = lambda: vit._forward_f32_split(self.static_in, self.pp_mode == 2).reshape(batch, vit.grid, vit.grid, -1)
+        elif self.from_patches:
             self.static_in = vit.preprocess_patches(probe)
             run = lambda: vit._forward_patches(self.static_in, keep_dtype)["x_norm_patchtokens"].reshape(
                 batch, vit.grid, vit.grid, -1)
@@ -556,10 +570,8 @@ class GraphedEncoder:
             self.static_out = run()
 
     def __call__(self, rgb):
-        if self.from_patches and self.vit.can_fuse_preprocess(rgb):
-            self.vit.preprocess_patches(rgb, out=self.static_in)
-        elif self.from_patches:
-            self.vit.preprocess_patches(rgb.contiguous(), out=self.static_in)
+        if self.from_patches:
+            self.vit.preprocess_patches(rgb if rgb.is_contiguous() else rgb.contiguous(), out=self.static_in, mode=self.pp_mode)
         else:
             self.static_in.copy_(rgb)
         self.graph.replay()

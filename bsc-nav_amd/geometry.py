@@ -137,10 +137,16 @@ class SamplePrefetcher:
         scratch = np.empty(self.n_pixels, np.int32)
         while not self._stop:
             out = np.empty((self.n_pixels + self.rate - 1) // self.rate, np.int32)
-            self._check(self._lib.bsc_host_shuffled_sample(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos), self.n_pixels,
-                                                           self.rate, scratch.ctypes.data_as(C.c_void_p),
-                                                           out.ctypes.data_as(C.c_void_p)))
-            item = (out, ("MT19937", self._key.copy(), self._pos.value) + self._rest)
+            try:
+                self._check(self._lib.bsc_host_shuffled_sample(self._key.ctypes.data_as(C.c_void_p), C.byref(self._pos), self.n_pixels,
+                                                               self.rate, scratch.ctypes.data_as(C.c_void_p),
+                                                               out.ctypes.data_as(C.c_void_p)))
+                item = (out, ("MT19937", self._key.copy(), self._pos.value) + self._rest)
+            except BaseException as e:      # noqa: BLE001 — handed to the consumer: next() re-raises it instead of waiting forever
+                item = (e, None)
+                self._stop = True
+                self._q.put(item)
+                return
             while not self._stop:
                 try:
                     self._q.put(item, timeout=0.05)
@@ -151,7 +157,16 @@ class SamplePrefetcher:
     def next(self):
         if self._fallback:
             return sample_indices(self.n_pixels, self.rate)
-        idx, state = self._q.get()
+        import queue
+        while True:
+            try:
+                idx, state = self._q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not self._thread.is_alive():
+                    raise RuntimeError("SamplePrefetcher: the worker thread is gone") from None
+        if isinstance(idx, BaseException):
+            raise idx
         self._tail = state
         return idx
 

@@ -253,7 +253,11 @@ class VoxelTokenMemory:
 
     def _next_sample(self, n_pixels):
         pf = getattr(self, "_prefetcher", None)
-        if pf is not None and pf.n_pixels == n_pixels and pf.rate == self.depth_sample_rate:
+        if pf is not None:
+            if pf.n_pixels != n_pixels or pf.rate != self.depth_sample_rate:
+                # drawing this frame from the global stream would be overwritten by close(): the two streams cannot be mixed
+                raise ValueError(f"prefetched_sampling was opened for {pf.n_pixels} pixels at rate {pf.rate}; this frame has "
+                                 f"{n_pixels} pixels at rate {self.depth_sample_rate} — close the prefetcher first")
             return pf.next()
         return sample_indices(n_pixels, self.depth_sample_rate)
 
