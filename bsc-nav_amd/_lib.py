@@ -77,6 +77,10 @@ SIGNATURES = {
     "bsc_host_shuffled_sample": (_I32, [_VP, _VP, _I64, _I32, _VP, _VP]),
     "bsc_enc_split_weights": (_I32, [_VP, _I32, _I32, C.c_float, _VP, _VP]),
     "bsc_enc_gemm_split": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP]),
+    "bsc_enc_gemm_split_ln": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP, _VP,
+                                     C.c_float, _VP]),
+    "bsc_enc_embed_layernorm_f32": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP, _VP, _VP, _VP, _VP]),
+    "bsc_enc_final_layernorm_f32": (_I32, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP, _VP]),
     "bsc_enc_layernorm_split": (_I32, [_VP, _VP, _VP, _I64, _I32, C.c_float, C.c_float, _VP, _VP]),
     "bsc_enc_split_rows": (_I32, [_VP, _I64, _I32, C.c_float, _VP, _VP]),
     "bsc_enc_attention_split": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, C.c_float, _VP, _VP]),

@@ -39,13 +39,19 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define GS_PITCH 40              // fp16 elements per staged weight row (80 bytes)
 #define GS_TPB 256
 #ifndef GS_RESID_DEPTH
-#define GS_RESID_DEPTH 3             // tiles of residual rows in flight in the epilogue (incl. the one in use)
+#define GS_RESID_DEPTH 1             // tiles of residual rows in flight in the epilogue (incl. the one in use).  Round 5 sweep at 768 frames
+                                     // (proj / fc2, us): depth 3 736 / 2466, 2 719 / 2405, 1 679 / 2328 — the registers of the prefetched rows
+                                     // (16 per tile in flight) are worth more to the main loop than the prefetch is to the epilogue
+#endif
+#ifndef GS_STATS_RESID_DEPTH
+#define GS_STATS_RESID_DEPTH 1       // the same in the epilogue that also takes the row statistics
 #endif
 #ifndef BSC_GEMM_NARROW_TILE
 #define BSC_GEMM_NARROW_TILE 1           // tile variant for N <= 1024 (see bsc_enc_gemm_split)
 #endif
 
 enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
+#define GS_LN_REC 20             // floats per LayerNorm statistics record of a residual-stream row (see gemm_split_tile)
 
 #ifdef BSC_GEMM_PROFILE        // per-workgroup phase stamps (100 MHz wall clock) + the CU it ran on: -DBSC_GEMM_PROFILE, BSC_GEMM_PROFILE_DUMP=1
 #define GS_PROF_MAX 8192
@@ -79,6 +85,14 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t &h, uint32_t &
     const half2_t hv = *(const half2_t *)&h;
     const f32x2_t hb = __builtin_convertvector(hv, f32x2_t);
     l = pack_f16_rne(a - hb[0], b - hb[1]);
+}
+
+__device__ __forceinline__ void split2v(f32x2_t v, uint32_t &h, uint32_t &l)
+{
+    const half2_t hv = __builtin_convertvector(v, half2_t);
+    h = *(const uint32_t *)&hv;
+    const half2_t lv = __builtin_convertvector(v - __builtin_convertvector(hv, f32x2_t), half2_t);
+    l = *(const uint32_t *)&lv;
 }
 
 // W (N,K) f32 -> planes h, l of (n_pad, K) fp16 pieces of scale * W (rows N..n_pad-1 zero)
@@ -157,7 +171,8 @@ __global__ __launch_bounds__(GS_TPB) void k_embed_layernorm_split(const float *_
                                                                   const float *__restrict__ reg, const float *__restrict__ pos,
                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                   int64_t rows, int T, int R, float eps, float *__restrict__ u,
-                                                                  uint16_t *__restrict__ out)
+                                                                  uint16_t *__restrict__ out, float *__restrict__ stats,
+                                                                  float *__restrict__ mu)
 {
     constexpr int Wd = 256 * VPL;
     const int lane = threadIdx.x & 63;
@@ -186,6 +201,11 @@ __global__ __launch_bounds__(GS_TPB) void k_embed_layernorm_split(const float *_
         sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (stats) {        // the row's statistics record for a GEMM that folds the LayerNorm into its operand load (GS_LN_REC): exact two-pass
+        if (lane < GS_LN_REC) stats[row * GS_LN_REC + lane] = lane == 0 ? mean : lane == 3 ? sq : 0.f;
+        if (lane == 0) mu[row] = mean;
+    }
+    if (!out) return;
     const float rstd = 1.0f / sqrtf(sq * (1.0f / Wd) + eps);
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -263,14 +283,26 @@ __global__ __launch_bounds__(GS_TPB) void k_split_rows(const float *__restrict__
 // the same shape — so that a workgroup's tiles form one continuous stream of chunks and only its first tile pays the latency of
 // a prologue.  par: parity of the LDS buffer that holds chunk 0 (advances by the chunk count per tile).
 template <int MR> struct gs_xf { typedef uint32_t type __attribute__((ext_vector_type(16 * MR))); };
-template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
+// AMODE: how the activation operand arrives — GS_A_F32 f32 rows (split in registers), GS_A_PIECES P32 pieces, GS_A_LN f32 rows of
+// the residual stream that are LayerNorm'd while they are split: y = (x - mean) * rstd per row (gamma is folded into the weight
+// columns and beta into the bias by the host, once per matrix), mean / rstd from the row's statistics record (below).
+// STATS (residual epilogue): the tile's output rows leave their sums for the NEXT LayerNorm in the statistics records.
+//
+// LayerNorm statistics record of a row of the residual stream (GS_LN_REC floats): [0] shift s, [1] unused, [2 + 2 p] = sum (x - s),
+// [3 + 2 p] = sum (x - s)^2 over the columns [128 p, 128 p + 128) — one slot per 128-column strip, written by the wavefront whose
+// tile holds the strip (no atomics); unused slots zero.  mean = s + A / W, var = B / W - (A / W)^2 with A, B the slot sums: the
+// shift is the row's previous mean (ln_mu, written by the GEMM that consumed the previous record), so the one-pass variance is
+// taken about a point within a fraction of a standard deviation of the new mean — as accurate as the two-pass form.
+enum { GS_A_F32 = 0, GS_A_PIECES = 1, GS_A_LN = 2 };
+template <int MR, int NT, int WR, int WC, int EPI, int AMODE, bool CPIECES, bool STATS>
 __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, const float *bias_lds, const void *__restrict__ Av, int64_t M, int K,
                                                 const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
                                                 const float *R, void *Cv,
                                                 float a_scale, float out_scale, float c_scale, int64_t tm, int n0, bool primed,
                                                 bool has_next, int64_t next_tm, int next_n0, int &par, typename gs_xf<MR>::type &xf,
-                                                typename gs_xf<MR>::type &xg, int prof_idx)
+                                                typename gs_xf<MR>::type &xg, int prof_idx, float *ln_stats, float *ln_mu, float ln_eps)
 {
+    constexpr bool APIECES = AMODE == GS_A_PIECES;
     constexpr int WROWS = WC * NT * 32;                                       // Ws: [2][2][WROWS][GS_PITCH]
     constexpr int TROWS = WR * MR * 32;
     constexpr int BUF = 2 * WROWS * GS_PITCH;
@@ -300,6 +332,22 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
     const char *arow[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) arow[mr] = row_base(row0, mr);
+    // LayerNorm constants of the lane's rows (one record per row; the tile with n0 == 0 leaves the means for the next producer)
+    float ln_m[MR], ln_rs[MR];
+    if constexpr (AMODE == GS_A_LN) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int64_t row = row0 + mr * 32 + i;
+            const f32x4_t *rec = (const f32x4_t *)(ln_stats + (row < M ? row : M - 1) * GS_LN_REC);
+            const f32x4_t r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+            const float sa = ((r0[2] + r1[0]) + (r1[2] + r2[0])) + ((r2[2] + r3[0]) + (r3[2] + r4[0]));
+            const float sb = ((r0[3] + r1[1]) + (r1[3] + r2[1])) + ((r2[3] + r3[1]) + (r3[3] + r4[1]));
+            const float inv_w = 1.0f / (float)K, da = sa * inv_w;
+            ln_m[mr] = r0[0] + da;
+            ln_rs[mr] = 1.0f / sqrtf(fmaxf(sb * inv_w - da * da, 0.f) + ln_eps);
+            if (n0 == 0 && wc == 0 && g == 0 && row < M) ln_mu[row] = ln_m[mr];
+        }
+    }
     const int nchunks = K / GS_KC;
     has_next = has_next && nchunks >= 2;
     f32x16 acc[MR][NT];
@@ -371,10 +419,20 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
             } else {
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
-                    split2(__uint_as_float(xf[16 * mr + 4 * v4]) * a_scale, __uint_as_float(xf[16 * mr + 4 * v4 + 1]) * a_scale,
-                           ah[mr][v4 >> 1][2 * (v4 & 1)], al[mr][v4 >> 1][2 * (v4 & 1)]);
-                    split2(__uint_as_float(xf[16 * mr + 4 * v4 + 2]) * a_scale, __uint_as_float(xf[16 * mr + 4 * v4 + 3]) * a_scale,
-                           ah[mr][v4 >> 1][2 * (v4 & 1) + 1], al[mr][v4 >> 1][2 * (v4 & 1) + 1]);
+                    // pairs through the packed f32 instructions (v_pk_add_f32 / v_pk_mul_f32): half the vector issue slots
+                    f32x2_t p0 = {__uint_as_float(xf[16 * mr + 4 * v4]), __uint_as_float(xf[16 * mr + 4 * v4 + 1])};
+                    f32x2_t p1 = {__uint_as_float(xf[16 * mr + 4 * v4 + 2]), __uint_as_float(xf[16 * mr + 4 * v4 + 3])};
+                    if constexpr (AMODE == GS_A_LN) {
+                        const f32x2_t mm = {ln_m[mr], ln_m[mr]}, rr = {ln_rs[mr], ln_rs[mr]};
+                        p0 = (p0 - mm) * rr;
+                        p1 = (p1 - mm) * rr;
+                    } else {
+                        const f32x2_t ss = {a_scale, a_scale};
+                        p0 *= ss;
+                        p1 *= ss;
+                    }
+                    split2v(p0, ah[mr][v4 >> 1][2 * (v4 & 1)], al[mr][v4 >> 1][2 * (v4 & 1)]);
+                    split2v(p1, ah[mr][v4 >> 1][2 * (v4 & 1) + 1], al[mr][v4 >> 1][2 * (v4 & 1) + 1]);
                 }
             }
         }
@@ -433,7 +491,7 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
     uint16_t *Cp = (uint16_t *)Cv;
     constexpr int EP = 136;                                                 // staged row pitch, bytes: conflict-free 8-byte writes
     constexpr int WLB = 32 * EP;                                            // per wavefront: one tile
-    constexpr int RD = GS_RESID_DEPTH;
+    constexpr int RD = STATS ? GS_STATS_RESID_DEPTH : GS_RESID_DEPTH;
     char *wl = epi_lds + w * WLB;                                           // beyond the weight buffers: the next tile's chunk 0 may sit there
     const float *bs = bias_lds + n0 + wc * NT * 32;                         // the bias values of the wavefront's column strip
     const int rl = lane >> 3, seg = lane & 7;                               // line phase: row rl + 8 k of the tile, 16-byte segment seg
@@ -457,6 +515,18 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
                 if (EPI == GS_EPI_RESID) {
 #pragma unroll
                     for (int t = 0; t < RD - 1 && t < NT; ++t) load_r(t, t);
+                }
+                // statistics of the finished rows for the next LayerNorm: shifted sums per 128-column strip (the line phase below
+                // holds row rl + 8 k of the tile, four columns per lane: eight lanes per row)
+                float st_s[4], st_a[4], st_b[4];
+                if constexpr (STATS) {
+                    static_assert(NT % 4 == 0 && EPI == GS_EPI_RESID && !CPIECES, "statistics ride on the f32 residual epilogue");
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t m = mbase + rl + 8 * k;
+                        st_s[k] = ln_mu[m < M ? m : M - 1];
+                        st_a[k] = 0.f; st_b[k] = 0.f;
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -494,9 +564,32 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
                             f32x4_t o = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
                             if (EPI == GS_EPI_RESID) o += rq[t % RD][k];
                             *(f32x4_t *)(C + m * N + n0 + (wc * NT + t) * 32 + 4 * seg) = o;
+                            if constexpr (STATS) {
+                                const float d0 = o[0] - st_s[k], d1 = o[1] - st_s[k], d2 = o[2] - st_s[k], d3 = o[3] - st_s[k];
+                                st_a[k] += (d0 + d1) + (d2 + d3);
+                                st_b[k] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                            }
                         }
                     }
                     gs_wave_lds_order();
+                    if constexpr (STATS) {
+                        if ((t & 3) == 3) {                                 // a 128-column strip is complete: eight lanes per row -> one
+                            const int slot = (n0 + (wc * NT + t - 3) * 32) >> 7;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float a = st_a[k], b = st_b[k];
+                                a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+                                a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+                                a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+                                const int64_t m = mbase + rl + 8 * k;
+                                if (seg == 0 && m < M && n0 + (wc * NT + t) * 32 < N) {
+                                    *(float2 *)(ln_stats + m * GS_LN_REC + 2 + 2 * slot) = make_float2(a, b);
+                                    if (slot == 0) ln_stats[m * GS_LN_REC] = st_s[k];
+                                }
+                                st_a[k] = 0.f; st_b[k] = 0.f;
+                            }
+                        }
+                    }
                 }
             } else {                    // f32 output with N not a multiple of 4 (no encoder shape): element by element
 #pragma unroll
@@ -528,12 +621,13 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
 // before the next (the 786 KB A tile is fetched into that XCD's L2 once).  q_full: the first q_full list entries of every XCD
 // are whole tiles; the rest — a last, partly filled round (N = 768: 888 tiles on 256 CUs are 3.47 rounds) — are split into two
 // half-width tiles each, so that round costs half a tile's time instead of a whole one.
-template <int MR, int NT, int WR, int WC, int EPI, bool APIECES, bool CPIECES>
+template <int MR, int NT, int WR, int WC, int EPI, int AMODE, bool CPIECES, bool STATS>
 __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restrict__ Av, int64_t M, int K,
                                                              const uint16_t *__restrict__ Wp, int64_t w_plane, int N,
                                                              const float *__restrict__ bias, const float *R, void *Cv,
                                                              float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m,
-                                                             int64_t q_full, int64_t q_virtual, int per_round, int epi_off)
+                                                             int64_t q_full, int64_t q_virtual, int per_round, int epi_off,
+                                                             float *ln_stats, float *ln_mu, float ln_eps)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];
     constexpr bool HALF_OK = NT % 2 == 0 && (WC * (NT / 2) * 32) % (16 * WR * WC) == 0;       // the half tile's weight staging plan exists
@@ -563,13 +657,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
         const bool has_next = nxt.valid && nxt.half == cur.half;
         const int prof_idx = (int)(qv * 8 + xcd);
         if (!cur.half)
-            gemm_split_tile<MR, NT, WR, WC, EPI, APIECES, CPIECES>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
-                                                                   out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0, par,
-                                                                   xf, xg, prof_idx);
+            gemm_split_tile<MR, NT, WR, WC, EPI, AMODE, CPIECES, STATS>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
+                                                                        out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0,
+                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps);
         else
-            gemm_split_tile<MR, NH, WR, WC, EPI, APIECES, CPIECES>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
-                                                                   out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0, par,
-                                                                   xf, xg, prof_idx);
+            gemm_split_tile<MR, NH, WR, WC, EPI, AMODE, CPIECES, STATS>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
+                                                                        out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0,
+                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps);
         primed = has_next && K / GS_KC >= 2;
     }
 }
@@ -855,19 +949,33 @@ extern "C" bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
-                                         const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
-                                         int32_t epilogue, int32_t a_pieces, float c_pieces_scale, void *hip_stream)
+extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
+                                            const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
+                                            int32_t epilogue, int32_t a_mode, float c_pieces_scale, float *ln_stats_dev,
+                                            float *ln_mu_dev, float ln_eps, void *hip_stream)
 {
     if (!a_dev || !pieces_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || (K % GS_KC) || epilogue < 0 || epilogue > 2 ||
-        (epilogue == GS_EPI_RESID && !resid_dev) || (c_pieces_scale != 0.f && (N % 32))) {
+        a_mode < 0 || a_mode > 2 || (epilogue == GS_EPI_RESID && !resid_dev) || (c_pieces_scale != 0.f && (N % 32))) {
         bsc_set_error("bsc_enc_gemm_split: invalid argument (K must be a multiple of 32; piece output needs N %% 32 == 0)");
+        return BSC_E_INVALID;
+    }
+    const bool ln = a_mode == GS_A_LN, stats = epilogue == GS_EPI_RESID && ln_stats_dev != nullptr;
+    if ((ln || stats) && (!ln_stats_dev || !ln_mu_dev)) {
+        bsc_set_error("bsc_enc_gemm_split_ln: the LayerNorm modes need both ln_stats_dev and ln_mu_dev");
+        return BSC_E_INVALID;
+    }
+    if (ln && (K % 128 || K > 1024 || epilogue == GS_EPI_RESID)) {
+        bsc_set_error("bsc_enc_gemm_split_ln: a_mode 2 reads rows of width K = 128 .. 1024 (multiple of 128), epilogue 0 / 1");
+        return BSC_E_INVALID;
+    }
+    if (stats && (N % 128 || N > 1024 || a_mode == GS_A_LN)) {
+        bsc_set_error("bsc_enc_gemm_split_ln: row statistics ride on the residual epilogue of a GEMM with N = 128 .. 1024 (multiple of 128)");
         return BSC_E_INVALID;
     }
     // tile shape: 256 x 256 (8 wavefronts x 32 rows x 256 columns), or — for the narrow outputs (N <= 1024: 888 tiles of 256 x 256 on
     // 256 CUs is 3.47 rounds, 13 % of the last one idle) — a smaller tile that balances better; BSC_GEMM_TILE = 1 / 3 / 4 forces one
     static const int tile_env = getenv("BSC_GEMM_TILE") ? atoi(getenv("BSC_GEMM_TILE")) : 0;
-    const int tile = tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
+    const int tile = (ln || stats) ? 1 : tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
     const int TROWS = tile == 3 ? 128 : 256, TCOLS = tile == 1 ? 256 : 128, NTHR = tile == 3 ? 256 : 512;
     const int64_t n_pad = ((int64_t)N + 255) / 256 * 256;
     const int n_tiles_n = (int)(n_pad / TCOLS);
@@ -887,39 +995,48 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     const size_t lds = lds_loop + lds_epi + (size_t)n_pad * sizeof(float);        // + the bias row
     if (lds > 160 * 1024) { bsc_set_error("bsc_enc_gemm_split: N = %d does not fit the kernel's LDS plan (bias row)", N); return BSC_E_INVALID; }
     hipStream_t s = (hipStream_t)hip_stream;
-    const bool ap = a_pieces != 0, cp = c_pieces_scale != 0.f;
-#define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, APV, CPV)                                                                         \
+    const bool ap = a_mode == GS_A_PIECES, cp = c_pieces_scale != 0.f;
+#define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV)                                                                    \
     do {                                                                                                                             \
         static uint64_t attr_set = 0;       /* bit per device ordinal */                                                              \
         if (!(attr_set >> (dev & 63) & 1)) {                                                                                         \
-            BSC_HIP(hipFuncSetAttribute((const void *)k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>,                              \
+            BSC_HIP(hipFuncSetAttribute((const void *)k_gemm_split<MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV>,                         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                      \
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
-        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, APV, CPV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, M, K,\
-                           (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,               \
-                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full, q_virtual, (int)per_round, (int)lds_loop);                   \
+        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, \
+                           M, K, (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,         \
+                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full, q_virtual, (int)per_round, (int)lds_loop, ln_stats_dev, \
+                           ln_mu_dev, ln_eps);                                                                                       \
     } while (0)
-#define BSC_GEMM_LAUNCH(EPIV, APV, CPV)                                                                                              \
+#define BSC_GEMM_LAUNCH(EPIV, AMV, CPV)                                                                                              \
     do {                                                                                                                             \
-        if (tile == 3) BSC_GEMM_LAUNCH2(1, 4, 4, 1, EPIV, APV, CPV);                                                                 \
-        else if (tile == 4) BSC_GEMM_LAUNCH2(1, 4, 8, 1, EPIV, APV, CPV);                                                            \
-        else BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, APV, CPV);                                                                           \
+        if (tile == 3) BSC_GEMM_LAUNCH2(1, 4, 4, 1, EPIV, AMV, CPV, false);                                                          \
+        else if (tile == 4) BSC_GEMM_LAUNCH2(1, 4, 8, 1, EPIV, AMV, CPV, false);                                                     \
+        else BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, AMV, CPV, false);                                                                    \
     } while (0)
-    if (epilogue == GS_EPI_GELU) {
-        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, true, true);
-        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU, true, false);
-        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, false, true);
-        else BSC_GEMM_LAUNCH(GS_EPI_GELU, false, false);
+    if (ln) {                           // LayerNorm folded into the operand load: qkv (bias) and fc1 (bias + GELU), piece output
+        if (epilogue == GS_EPI_GELU && cp) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_GELU, GS_A_LN, true, false);
+        else if (epilogue == GS_EPI_GELU) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_GELU, GS_A_LN, false, false);
+        else if (cp) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_BIAS, GS_A_LN, true, false);
+        else BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_BIAS, GS_A_LN, false, false);
+    } else if (stats) {                 // residual epilogue that leaves the row statistics for the next LayerNorm
+        if (ap) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_RESID, GS_A_PIECES, false, true);
+        else BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_RESID, GS_A_F32, false, true);
+    } else if (epilogue == GS_EPI_GELU) {
+        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_PIECES, true);
+        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_PIECES, false);
+        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, true);
+        else BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, false);
     } else if (epilogue == GS_EPI_RESID) {
         if (cp) { bsc_set_error("bsc_enc_gemm_split: the residual epilogue writes f32"); return BSC_E_INVALID; }
-        if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, true, false);
-        else BSC_GEMM_LAUNCH(GS_EPI_RESID, false, false);
+        if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, GS_A_PIECES, false);
+        else BSC_GEMM_LAUNCH(GS_EPI_RESID, GS_A_F32, false);
     } else {
-        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, true);
-        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_BIAS, true, false);
-        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, false, true);
-        else BSC_GEMM_LAUNCH(GS_EPI_BIAS, false, false);
+        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, GS_A_PIECES, true);
+        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_BIAS, GS_A_PIECES, false);
+        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_BIAS, GS_A_F32, true);
+        else BSC_GEMM_LAUNCH(GS_EPI_BIAS, GS_A_F32, false);
     }
 #undef BSC_GEMM_LAUNCH
 #undef BSC_GEMM_LAUNCH2
@@ -936,6 +1053,14 @@ extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K
     }
 #endif
     return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
+                                         const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
+                                         int32_t epilogue, int32_t a_pieces, float c_pieces_scale, void *hip_stream)
+{
+    return bsc_enc_gemm_split_ln(a_dev, M, K, pieces_dev, N, bias_dev, resid_dev, c_dev, a_scale, out_scale, epilogue, a_pieces ? 1 : 0,
+                                 c_pieces_scale, nullptr, nullptr, 0.f, hip_stream);
 }
 
 extern "C" bsc_status bsc_enc_layernorm_split(const float *x_dev, const float *gamma_dev, const float *beta_dev, int64_t rows,
@@ -969,9 +1094,11 @@ extern "C" bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t 
 
 extern "C" bsc_status bsc_enc_embed_layernorm_f32(const float *patch_dev, const float *cls_dev, const float *reg_dev, const float *pos_dev,
                                                   const float *gamma_dev, const float *beta_dev, int32_t B, int32_t T, int32_t registers,
-                                                  int32_t width, float eps, float *u_dev, void *pieces_dev, void *hip_stream)
+                                                  int32_t width, float eps, float *u_dev, void *pieces_dev, float *ln_stats_dev,
+                                                  float *ln_mu_dev, void *hip_stream)
 {
-    if (!patch_dev || !cls_dev || !pos_dev || !gamma_dev || !beta_dev || !u_dev || !pieces_dev || B < 1 || T < 2 || registers < 0 ||
+    if (!patch_dev || !cls_dev || !pos_dev || !u_dev || (!pieces_dev && !ln_stats_dev) || (pieces_dev && (!gamma_dev || !beta_dev)) ||
+        (ln_stats_dev && !ln_mu_dev) || B < 1 || T < 2 || registers < 0 ||
         registers > T - 2 || (registers > 0 && !reg_dev) || (width != 256 && width != 512 && width != 768 && width != 1024)) {
         bsc_set_error("bsc_enc_embed_layernorm_f32: invalid argument (width must be 256, 512, 768 or 1024)");
         return BSC_E_INVALID;
@@ -981,7 +1108,7 @@ extern "C" bsc_status bsc_enc_embed_layernorm_f32(const float *patch_dev, const 
     hipStream_t s = (hipStream_t)hip_stream;
     uint16_t *out = (uint16_t *)pieces_dev;
 #define BSC_EMB(V) hipLaunchKernelGGL(k_embed_layernorm_split<V>, grid, block, 0, s, patch_dev, cls_dev, reg_dev, pos_dev, gamma_dev, beta_dev, \
-                                      rows, T, registers, eps, u_dev, out)
+                                      rows, T, registers, eps, u_dev, out, ln_stats_dev, ln_mu_dev)
     switch (width / 256) {
     case 1: BSC_EMB(1); break;
     case 2: BSC_EMB(2); break;

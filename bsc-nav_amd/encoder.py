@@ -67,41 +67,96 @@ class SplitLinear:
     epilogue: 0 bias, 1 bias + GELU(tanh), 2 bias + residual (in place when out is resid)."""
 
     BIAS, GELU, RESID = 0, 1, 2
+    A_F32, A_PIECES, A_LN = 0, 1, 2
 
-    def __init__(self, lin):
+    def __init__(self, lin, ln=None):
+        """ln: a LayerNorm applied to the input rows, folded into this layer — its gamma into the weight columns, its beta into
+        the bias (LN(x) W^T + b = ((x - mean) rstd) (W gamma)^T + (W beta + b)); the GEMM then normalises the rows of the residual
+        stream while it splits them (a_mode A_LN: mean / rstd from the row statistics the producing GEMM's epilogue left)."""
         from . import _lib
         w = lin.weight.detach()
         assert w.is_cuda and w.dtype == torch.float32 and w.shape[1] % 32 == 0
+        self.bias = None if lin.bias is None else lin.bias.detach().contiguous()
+        self.ln_eps = 0.0
+        if ln is not None:
+            g, b = ln.weight.detach().float(), ln.bias.detach().float()
+            # W beta in f64: a 768-term dot per output, once per matrix
+            wb = (w.double() @ b.double()).float()
+            self.bias = wb if self.bias is None else (self.bias.double() + wb.double()).float()
+            w = w * g[None, :]
+            self.ln_eps = float(ln.eps)
         self.N, self.K = w.shape
         amax = float(w.abs().max())
         self.scale = 2.0 ** (3 - int(torch.ceil(torch.log2(torch.tensor(max(amax, 1e-30))))))
         n_pad = (self.N + 255) // 256 * 256
         self.pieces = torch.empty((2, n_pad, self.K), dtype=torch.float16, device=w.device)
-        self.bias = None if lin.bias is None else lin.bias.detach().contiguous()
         lib = _lib.load()
         _lib.check(lib.bsc_enc_split_weights(C.c_void_p(w.contiguous().data_ptr()), self.N, self.K, self.scale,
                                              C.c_void_p(self.pieces.data_ptr()),
                                              C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)))
 
-    def __call__(self, x2d, epilogue=0, resid=None, out=None, a_scale=1.0, a_pieces=False, c_pieces_scale=0.0):
+    def __call__(self, x2d, epilogue=0, resid=None, out=None, a_scale=1.0, a_pieces=False, c_pieces_scale=0.0, ln_stats=None,
+                 ln_mu=None, a_ln=False):
         """x2d: (M,K) f32 rows, or (a_pieces) their (M,2K) fp16 pieces as `split_rows` / `layernorm_split` / a GELU epilogue
-        with c_pieces_scale made them, already scaled by a_scale.  -> (M,N) f32, or (c_pieces_scale) (M,2N) fp16 pieces."""
+        with c_pieces_scale made them, already scaled by a_scale.  -> (M,N) f32, or (c_pieces_scale) (M,2N) fp16 pieces.
+        a_ln: x2d = f32 rows of the residual stream, LayerNorm'd in the operand load from ln_stats (M, 20) (this object was built
+        with ln=...; writes the row means to ln_mu).  ln_stats with the residual epilogue: the finished rows leave their statistics
+        there (shifted by ln_mu) for the next a_ln GEMM."""
         from . import _lib
         M = x2d.shape[0]
         if a_pieces:
             assert x2d.dtype == torch.float16 and x2d.is_contiguous() and x2d.shape[1] == 2 * self.K
         else:
             assert x2d.dtype == torch.float32 and x2d.is_contiguous() and x2d.shape[1] == self.K
+        if a_ln or ln_stats is not None:
+            assert ln_stats.dtype == torch.float32 and ln_stats.shape == (M, LN_REC) and ln_mu.shape == (M,) and ln_stats.is_contiguous()
+            assert not a_ln or self.ln_eps > 0.0, "a_ln needs a SplitLinear built with ln="
         if out is None:
             out = (torch.empty((M, 2 * self.N), dtype=torch.float16, device=x2d.device) if c_pieces_scale else
                    torch.empty((M, self.N), dtype=torch.float32, device=x2d.device))
-        _lib.check(_lib.load().bsc_enc_gemm_split(
+        _lib.check(_lib.load().bsc_enc_gemm_split_ln(
             C.c_void_p(x2d.data_ptr()), M, self.K, C.c_void_p(self.pieces.data_ptr()), self.N,
             None if self.bias is None else C.c_void_p(self.bias.data_ptr()),
             None if resid is None else C.c_void_p(resid.data_ptr()), C.c_void_p(out.data_ptr()), float(a_scale),
-            1.0 / (float(a_scale) * self.scale), int(epilogue), 1 if a_pieces else 0, float(c_pieces_scale),
+            1.0 / (float(a_scale) * self.scale), int(epilogue), self.A_LN if a_ln else self.A_PIECES if a_pieces else self.A_F32,
+            float(c_pieces_scale), None if ln_stats is None else C.c_void_p(ln_stats.data_ptr()),
+            None if ln_mu is None else C.c_void_p(ln_mu.data_ptr()), self.ln_eps,
             C.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream)))
         return out
+
+
+LN_REC = 20       # floats per LayerNorm statistics record of a residual-stream row (csrc/encoder_gemm.hip GS_LN_REC)
+
+
+def embed_tokens_f32(vit, patches2d, B, ln=None, stats=False):
+    """Token assembly of the f32 forward in one pass (bsc_enc_embed_layernorm_f32): cls + pos[0], register tokens, patch + pos ->
+    (u (B T, W) f32, pieces of ln(u) or None, (ln_stats, ln_mu) or None)."""
+    from . import _lib
+    Wd = vit.width
+    T = 1 + vit.registers + vit.grid * vit.grid
+    dev = patches2d.device
+    u = torch.empty((B * T, Wd), dtype=torch.float32, device=dev)
+    pieces = torch.empty((B * T, 2 * Wd), dtype=torch.float16, device=dev) if ln is not None else None
+    st = (torch.empty((B * T, LN_REC), dtype=torch.float32, device=dev), torch.empty(B * T, dtype=torch.float32, device=dev)) if stats else None
+    _lib.check(_lib.load().bsc_enc_embed_layernorm_f32(
+        C.c_void_p(patches2d.data_ptr()), C.c_void_p(vit.cls.data_ptr()), None if vit.reg is None else C.c_void_p(vit.reg.data_ptr()),
+        C.c_void_p(vit.pos.data_ptr()), None if ln is None else C.c_void_p(ln.weight.data_ptr()),
+        None if ln is None else C.c_void_p(ln.bias.data_ptr()), B, T, vit.registers, Wd, float(ln.eps) if ln is not None else 0.0,
+        C.c_void_p(u.data_ptr()), None if pieces is None else C.c_void_p(pieces.data_ptr()),
+        None if st is None else C.c_void_p(st[0].data_ptr()), None if st is None else C.c_void_p(st[1].data_ptr()),
+        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return u, pieces, st
+
+
+def final_layernorm_f32(u2d, ln, B, T, skip):
+    """the last LayerNorm over the patch rows only -> (B, T - skip, W) f32 (bsc_enc_final_layernorm_f32)"""
+    from . import _lib
+    Wd = u2d.shape[1]
+    out = torch.empty((B, T - skip, Wd), dtype=torch.float32, device=u2d.device)
+    _lib.check(_lib.load().bsc_enc_final_layernorm_f32(
+        C.c_void_p(u2d.data_ptr()), C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()), B, T, skip, Wd, float(ln.eps),
+        C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(u2d.device).cuda_stream)))
+    return out
 
 
 def layernorm_split(x2d, ln, a_scale=1.0):
@@ -349,14 +404,15 @@ class RandomViT(nn.Module):
             t = self.head(t)
         return {"x_norm_patchtokens": t if keep_dtype else t.float()}
 
-    def _split(self, lin):
-        """the fp16 pieces of a Linear's weight, made on first use (f32 weights on the device)"""
+    def _split(self, lin, ln=None):
+        """the fp16 pieces of a Linear's weight, made on first use (f32 weights on the device); ln: a LayerNorm folded in"""
         cache = self.__dict__.setdefault("_split_cache", {})
-        key = id(lin)
+        key = (id(lin), None if ln is None else id(ln))
         # in-place updates (load_state_dict, copy_) keep the pointer and bump the version counter
-        tag = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+        tag = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version),
+               None if ln is None else (ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version))
         if key not in cache or cache[key][0] != tag:
-            cache[key] = (tag, SplitLinear(lin))
+            cache[key] = (tag, SplitLinear(lin, ln))
         return cache[key][1]
 
     def invalidate_split_weights(self):
@@ -376,21 +432,37 @@ class RandomViT(nn.Module):
             x = self._split(self.patch_embed)(t.reshape(B * n_patch, t.shape[2]).contiguous(), a_pieces=t_pieces).view(B, n_patch, Wd)
         else:
             x = self.patch_embed(t)
-        x = torch.cat([self.cls.expand(B, -1, -1), x], dim=1) + self.pos
-        if self.reg is not None:
-            x = torch.cat([x[:, :1], self.reg.expand(B, -1, -1), x[:, 1:]], dim=1)
-        T = x.shape[1]
-        u = x.contiguous().view(B * T, Wd)
+        T = 1 + self.registers + n_patch
         ln_ok = Wd in (256, 512, 768, 1024)
+        own_attention = hd == 64 and T <= 288 and os.environ.get("BSC_ENC_SPLIT_ATTENTION", "1") == "1"
+        # LayerNorm folded into the qkv / fc1 operand loads, its statistics from the proj / fc2 epilogues: no LayerNorm pass at all
+        # (BSC_ENC_LN_FUSED=0: LayerNorm -> pieces as a pass of its own, the round-4 form)
+        ln_fused = ln_ok and own_attention and os.environ.get("BSC_ENC_LN_FUSED", "1") == "1"
+        if ln_ok:
+            x2 = x.reshape(B * n_patch, Wd).contiguous()
+            u, y0, st = embed_tokens_f32(self, x2, B, ln=None if ln_fused else self.blocks[0].ln1, stats=ln_fused)
+        else:
+            x = torch.cat([self.cls.expand(B, -1, -1), x], dim=1) + self.pos
+            if self.reg is not None:
+                x = torch.cat([x[:, :1], self.reg.expand(B, -1, -1), x[:, 1:]], dim=1)
+            u, y0, st = x.contiguous().view(B * T, Wd), None, None
 
         def ln_in(ln):          # LayerNorm output as the next GEMM's operand: pieces straight from the LayerNorm kernel
             if ln_ok:
                 return layernorm_split(u, ln), True
             return F.layer_norm(u, (Wd,), ln.weight, ln.bias, ln.eps), False
 
-        own_attention = hd == 64 and T <= 288 and os.environ.get("BSC_ENC_SPLIT_ATTENTION", "1") == "1"
-        for blk in self.blocks:
-            y, yp = ln_in(blk.ln1)
+        if ln_fused:
+            stats, mu = st
+            for blk in self.blocks:
+                qkv = self._split(blk.qkv, blk.ln1)(u, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=1.0)
+                a = attention_split(qkv, B, T, heads, out_scale=16.0)
+                self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0, a_pieces=True, ln_stats=stats, ln_mu=mu)
+                h = self._split(blk.fc1, blk.ln2)(u, SL.GELU, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=4.0)
+                self._split(blk.fc2)(h, SL.RESID, resid=u, out=u, a_scale=4.0, a_pieces=True, ln_stats=stats, ln_mu=mu)
+            return final_layernorm_f32(u, self.norm, B, T, 1 + self.registers)
+        for bi, blk in enumerate(self.blocks):
+            y, yp = (y0, True) if (bi == 0 and y0 is not None) else ln_in(blk.ln1)
             if own_attention:
                 # q, k, v leave the GEMM as pieces, the attention kernel reads and writes pieces: no f32 copy, no transpose
                 qkv = self._split(blk.qkv)(y, a_pieces=yp, c_pieces_scale=1.0)
@@ -405,6 +477,8 @@ class RandomViT(nn.Module):
             # the hidden tensor exists only as pieces (scaled by 4): written by fc1's GELU epilogue, read by fc2
             h = self._split(blk.fc1)(y, SL.GELU, a_pieces=yp, c_pieces_scale=4.0)
             self._split(blk.fc2)(h, SL.RESID, resid=u, out=u, a_scale=4.0, a_pieces=True)
+        if ln_ok:
+            return final_layernorm_f32(u, self.norm, B, T, 1 + self.registers)
         y = F.layer_norm(u, (Wd,), self.norm.weight, self.norm.bias, self.norm.eps)
         return y.view(B, T, Wd)[:, 1 + self.registers:].contiguous()
 

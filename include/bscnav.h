@@ -289,6 +289,31 @@ bsc_status bsc_enc_layernorm_split(const float *x_dev, const float *gamma_dev, c
 bsc_status bsc_enc_split_rows(const float *x_dev, int64_t M, int32_t K, float a_scale, void *pieces_dev, void *hip_stream);
 bsc_status bsc_enc_attention_split(const void *qkv_pieces_dev, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                                    void *out_pieces_dev, float out_scale, int32_t *work2_dev, void *hip_stream);
+/* The same GEMM with the LayerNorms of the pre-LN block (memory_2.py:738-739 runs them inside DINOv2's forward) folded in — no
+ * LayerNorm pass over the residual stream at all:
+ *   a_mode 0 f32 rows / 1 pieces (as a_pieces above) / 2 f32 rows of the RESIDUAL STREAM, normalised ((x - mean) * rstd) while they
+ *          are split for the matrix cores; the LayerNorm's gamma is expected folded into the weight columns and W beta into the
+ *          bias by the caller (once per matrix); mean / rstd come from ln_stats_dev, the row means are left in ln_mu_dev;
+ *          K = LayerNorm width (multiple of 128, <= 1024), piece output (epilogues 0, 1)
+ *   epilogue 2 with ln_stats_dev != NULL: the finished rows of the residual stream leave their statistics in ln_stats_dev for
+ *          the next a_mode-2 GEMM (shift = ln_mu_dev[row], the previous mean); N = LayerNorm width, a_mode 1
+ *   ln_stats_dev (M, 20) f32, one record per row: [0] shift s, [2 + 2p] sum (x - s), [3 + 2p] sum (x - s)^2 over the columns
+ *          [128 p, 128 p + 128); ln_mu_dev (M) f32.  bsc_enc_embed_layernorm_f32 writes the first records. */
+bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N, const float *bias_dev,
+                                 const float *resid_dev, void *c_dev, float a_scale, float out_scale, int32_t epilogue,
+                                 int32_t a_mode, float c_pieces_scale, float *ln_stats_dev, float *ln_mu_dev, float ln_eps,
+                                 void *hip_stream);
+/* Token assembly of the f32 forward, one pass: row (b, 0) = cls + pos[0], rows (b, 1..registers) = the register tokens, rows
+ * (b, 1 + registers + j) = patch[b][j] + pos[1 + j] -> u_dev (B T, width) f32; pieces_dev != NULL: LayerNorm(u) (gamma, beta) as
+ * operand pieces; ln_stats_dev != NULL: the rows' statistics records + means (exact two-pass) for bsc_enc_gemm_split_ln.
+ * bsc_enc_final_layernorm_f32: the last LayerNorm over the patch rows only (the first `skip` rows of every image dropped) ->
+ * out_dev (B, T - skip, width) f32 = x_norm_patchtokens (memory_2.py:739).  width 256 / 512 / 768 / 1024. */
+bsc_status bsc_enc_embed_layernorm_f32(const float *patch_dev, const float *cls_dev, const float *reg_dev, const float *pos_dev,
+                                       const float *gamma_dev, const float *beta_dev, int32_t B, int32_t T, int32_t registers,
+                                       int32_t width, float eps, float *u_dev, void *pieces_dev, float *ln_stats_dev,
+                                       float *ln_mu_dev, void *hip_stream);
+bsc_status bsc_enc_final_layernorm_f32(const float *u_dev, const float *gamma_dev, const float *beta_dev, int32_t B, int32_t T,
+                                       int32_t skip, int32_t width, float eps, float *out_dev, void *hip_stream);
 
 /* Encoder helper: u8 frames (B,H,W,C>=3) -> /255 -> antialiased bilinear resize to (S,S) -> (x-mean)/std ->
  * bf16 patch matrix (B, (S/patch)^2, 3*patch*patch), ready for the patch-embedding GEMM

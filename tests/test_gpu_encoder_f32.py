@@ -113,3 +113,126 @@ def test_attention_split_matches_fp32_softmax(B, T, H):
     e32 = (ref32.double() - ref64).abs().max().item()
     assert (got - ref64).abs().max().item() <= max(2.0 * e32, 2e-6)
     assert (got - ref32.double()).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("Wd,N,epilogue", [(768, 2304, 0), (768, 3072, 1), (1024, 3072, 0), (256, 512, 1)])
+@pytest.mark.parametrize("M", [1000, 20741])
+def test_layernorm_folded_into_the_gemm_operand_load(Wd, N, epilogue, M):
+    """LN(x) W^T + b with the LayerNorm inside the GEMM's operand load (a_mode 2: gamma in the weight columns, W beta in the bias,
+    (x - mean) rstd per row from the statistics records the embedding kernel / a residual epilogue wrote) against PyTorch fp32
+    layer_norm -> linear and fp64; rows with a mean far from zero and mixed scales; the row means land in ln_mu."""
+    import torch
+    import torch.nn.functional as F
+    from bsc_nav_amd import encoder
+    torch.manual_seed(Wd + N + M)
+    lin = torch.nn.Linear(Wd, N).cuda().float()
+    torch.nn.init.trunc_normal_(lin.weight, std=0.02)
+    ln = torch.nn.LayerNorm(Wd, eps=1e-6).cuda()
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.uniform_(-0.5, 0.5)
+    x = torch.randn(M, Wd, device="cuda") * (0.2 + 5 * torch.rand(M, 1, device="cuda")) + 3 * torch.randn(M, 1, device="cuda")
+    # the records as a residual epilogue leaves them: shift = a previous mean (here: the true mean perturbed), sums per 128 columns
+    s = x.mean(1) + 0.3 * torch.randn(M, device="cuda") * x.std(1)
+    stats = torch.zeros(M, encoder.LN_REC, device="cuda")
+    stats[:, 0] = s
+    d = (x - s[:, None]).view(M, Wd // 128, 128)
+    stats[:, 2:2 + 2 * (Wd // 128):2] = d.sum(2)
+    stats[:, 3:3 + 2 * (Wd // 128):2] = (d * d).sum(2)
+    mu = torch.full((M,), 7.0, device="cuda")
+    sl = encoder.SplitLinear(lin, ln)
+    cp = sl(x, epilogue, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=2.0)
+    got = _pieces_back(cp, M, N, 2.0)
+    ref64 = F.layer_norm(x.double(), (Wd,), ln.weight.double(), ln.bias.double(), 1e-6) @ lin.weight.double().t() + lin.bias.double()
+    ref32 = F.layer_norm(x, (Wd,), ln.weight, ln.bias, 1e-6) @ lin.weight.t() + lin.bias
+    if epilogue == 1:
+        ref64, ref32 = F.gelu(ref64, approximate="tanh"), F.gelu(ref32, approximate="tanh")
+    e32 = (ref32.double() - ref64).abs().max().item()
+    assert (got - ref64).abs().max().item() <= max(2.0 * e32, 3e-6), ((got - ref64).abs().max().item(), e32)
+    assert (mu.double() - x.double().mean(1)).abs().max().item() < 2e-6 * (1 + x.abs().max().item())
+
+
+@pytest.mark.parametrize("Wd,K", [(768, 768), (768, 3072), (1024, 1024)])
+@pytest.mark.parametrize("M", [999, 20741])
+def test_residual_epilogue_leaves_the_rows_statistics(Wd, K, M):
+    """u += a W^T + b through the residual epilogue with ln_stats: u as without it (bit for bit), and the records give the mean and
+    variance of the NEW rows to f32 accuracy (shifted sums about the previous mean, one slot per 128 columns; whole and half-width
+    tiles, ragged M)."""
+    import torch
+    from bsc_nav_amd import encoder
+    torch.manual_seed(Wd + K + M)
+    lin = torch.nn.Linear(K, Wd).cuda().float()
+    torch.nn.init.trunc_normal_(lin.weight, std=0.02)
+    a = torch.randn(M, K, device="cuda")
+    u0 = torch.randn(M, Wd, device="cuda") * 4 + 2 * torch.randn(M, 1, device="cuda")
+    sl = encoder.SplitLinear(lin)
+    ap = encoder.split_rows(a, 4.0)
+    plain = u0.clone()
+    sl(ap, 2, resid=plain, out=plain, a_scale=4.0, a_pieces=True)
+    u = u0.clone()
+    stats = torch.full((M, encoder.LN_REC), float("nan"), device="cuda")
+    stats[:, 2 + 2 * (Wd // 128):] = 0                                   # unused slots are zero (the embedding kernel writes them)
+    stats[:, 1] = 0
+    mu = u0.mean(1).contiguous()
+    sl(ap, 2, resid=u, out=u, a_scale=4.0, a_pieces=True, ln_stats=stats, ln_mu=mu)
+    assert torch.equal(u, plain)
+    assert torch.equal(stats[:, 0], mu)
+    sa = stats[:, 2::2].double().sum(1)
+    sb = stats[:, 3::2].double().sum(1)
+    mean = stats[:, 0].double() + sa / Wd
+    var = sb / Wd - (sa / Wd) ** 2
+    u64 = u.double()
+    assert (mean - u64.mean(1)).abs().max().item() < 1e-5
+    assert ((var - u64.var(1, unbiased=False)).abs() / u64.var(1, unbiased=False)).max().item() < 2e-6
+
+
+def test_embed_and_final_layernorm_f32():
+    """token assembly (cls + pos, registers, patches + pos) with the first LayerNorm as pieces and / or as statistics records, and
+    the final LayerNorm over the patch rows, against the PyTorch ops"""
+    import torch
+    import torch.nn.functional as F
+    from bsc_nav_amd import encoder
+    for arch in ("vit_b16", "vit_l14"):
+        vit = encoder.RandomViT(arch, image_size=224, seed=3, dtype=torch.float32).cuda()
+        torch.manual_seed(11)
+        vit.cls.data.normal_(); vit.pos.data.normal_()
+        if vit.reg is not None:
+            vit.reg.data.normal_()
+        B, g, Wd, R = 3, vit.grid, vit.width, vit.registers
+        T = 1 + R + g * g
+        ln = vit.blocks[0].ln1
+        ln.weight.data.uniform_(0.5, 1.5); ln.bias.data.uniform_(-0.5, 0.5)
+        x = torch.randn(B, g * g, Wd, device="cuda") * 2 + 0.7
+        t = torch.cat([vit.cls.expand(B, -1, -1), x], dim=1) + vit.pos
+        if vit.reg is not None:
+            t = torch.cat([t[:, :1], vit.reg.expand(B, -1, -1), t[:, 1:]], dim=1)
+        u, pieces, st = encoder.embed_tokens_f32(vit, x.view(B * g * g, Wd), B, ln=ln, stats=True)
+        assert torch.equal(u.view(B, T, Wd), t)
+        ref = F.layer_norm(t.double(), (Wd,), ln.weight.double(), ln.bias.double(), ln.eps).view(B * T, Wd)
+        assert (_pieces_back(pieces, B * T, Wd) - ref).abs().max().item() < 4e-6
+        stats, mu = st
+        assert (mu.double() - t.double().mean(2).view(-1)).abs().max().item() < 1e-6
+        assert torch.equal(stats[:, 0], mu) and (stats[:, 2] == 0).all() and (stats[:, 4:] == 0).all()
+        var = stats[:, 3].double() / Wd
+        assert ((var - t.double().var(2, unbiased=False).view(-1)).abs() / var).max().item() < 2e-6
+        u2, p2, st2 = encoder.embed_tokens_f32(vit, x.view(B * g * g, Wd), B, ln=None, stats=True)
+        assert p2 is None and torch.equal(u2, u) and torch.equal(st2[0], stats)
+        out = encoder.final_layernorm_f32(u, vit.norm, B, T, 1 + R)
+        reff = F.layer_norm(t[:, 1 + R:], (Wd,), vit.norm.weight, vit.norm.bias, vit.norm.eps)
+        assert out.shape == reff.shape and (out - reff).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("arch", ["vit_b16", "vit_l14"])
+def test_f32_encoder_fused_layernorm_equals_the_unfused_form(arch, monkeypatch):
+    """the forward with LayerNorm folded into the GEMMs (default) against the one that runs LayerNorm as passes of its own"""
+    import torch
+    from bsc_nav_amd import encoder
+    vit = encoder.RandomViT(arch, image_size=224, seed=2, dtype=torch.float32).cuda()
+    for ln in [m for m in vit.modules() if isinstance(m, torch.nn.LayerNorm)]:
+        ln.weight.data = 1 + 0.1 * torch.randn_like(ln.weight)
+        ln.bias.data = 0.1 * torch.randn_like(ln.bias)
+    rgb = torch.randint(0, 255, (3, 96, 128, 4), dtype=torch.uint8, device="cuda")
+    a = vit.patch_tokens(rgb)
+    monkeypatch.setenv("BSC_ENC_LN_FUSED", "0")
+    b = vit.patch_tokens(rgb)
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    assert (a - b).abs().max().item() < 1e-5
