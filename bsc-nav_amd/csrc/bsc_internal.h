@@ -160,6 +160,11 @@ struct bsc_ctx {
     int32_t *l_out_pos;
     float *l_out_sim;
     bool names_dirty;
+    // per-row operand scale + inverse norm of the rows the batched fp16-piece scan reads (dense rows or token-pool rows), rebuilt —
+    // like the name ranks — only after the rows changed (ingest, flush, imports, merges, reset)
+    float2 *l_rscale;
+    int64_t l_rscale_cap;
+    bool row_scale_dirty;
     int last_nq, last_K;            // shape of the last bsc_localize call (its top-K stays resident for clustering)
     int32_t last_counts[1024];
     // frontier helpers (allocated on first use, gs*gs each)

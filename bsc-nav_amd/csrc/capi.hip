@@ -94,7 +94,7 @@ static bsc_status reset_state(bsc_ctx *x)
     x->n_flush = 0;
     x->pool_n_host = 0;
     x->order_base = 0;
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     x->log_n = 0;
     x->log_stale = false;
     return BSC_OK;
@@ -312,7 +312,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->d_transforms, x->d_offsets, x->f_rowdst, x->f_hit, x->f_hidx, x->f_rowseg, x->f_rowe,
                     x->f_headpos, x->f_win, x->f_draws, x->l_sims, x->l_key_a, x->l_key_b, x->l_val_a, x->l_val_b,
                     x->l_name_rank, x->l_q, x->l_qp, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
-                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->l_valid, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
+                    x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->l_valid, x->l_rscale, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
                     x->fr_centers, x->fr_gains, x->log_cell, x->log_rec, x->stage_cell, x->stage_pos};
     for (void *p : ptrs)
@@ -372,7 +372,7 @@ extern "C" bsc_status bsc_ingest_typed(bsc_ctx *x, int32_t n_frames, const float
     BSC_HIP(hipSetDevice(x->device));
     BSC_HIP(hipMemcpyAsync(x->d_transforms, transforms_host, sizeof(double) * 16 * n_frames, hipMemcpyHostToDevice,
                            x->stream));
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     bsc_status st = ingest_batch(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, token_dtype, sample_idx_dev,
                                  offsets_host, alpha_dev, draw, user);
     return st;
@@ -745,7 +745,7 @@ extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const
         if (e != hipSuccess) { bsc_set_error("bsc_import_store: %s", hipGetErrorString(e)); st = BSC_E_HIP; }
     }
     free(occ); free(h_cnt); free(h_rows);
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     if (st == BSC_OK) x->pool_n_host = nt;
     return st;
 }
@@ -759,7 +759,7 @@ extern "C" bsc_status bsc_import_dense(bsc_ctx *x, int64_t max_id, const float *
     if (max_id == 0) return BSC_OK;
     BSC_HIP(hipMemcpy(x->acc, acc, sizeof(float) * max_id * x->c.token_dim, hipMemcpyHostToDevice));
     BSC_HIP(hipMemcpy(x->acnt, cnt, sizeof(int32_t) * max_id, hipMemcpyHostToDevice));
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     return BSC_OK;
 }
 
@@ -974,7 +974,7 @@ extern "C" bsc_status bsc_dense_replace_full(bsc_ctx *x, int64_t n, const int32_
     int64_t m[2] = {n, n};
     BSC_HIP(hipMemcpyAsync(x->dscal + DS_MAX_ID, m, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
     BSC_TRY(read_scalars(x));
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     if (x->hscal[DS_ERROR]) {
         BSC_HIP(hipMemsetAsync(x->dscal + DS_ERROR, 0, sizeof(int64_t), s));
         bsc_set_error("bsc_dense_replace: a key lies outside the grid");

@@ -222,7 +222,7 @@ bsc_status flush_cache(bsc_ctx *x, bsc_draw_fn draw, void *user)
     BSC_HIP(hipGetLastError());
     x->iter_id = 0;
     x->n_flush++;
-    x->names_dirty = true;
+    x->names_dirty = true; x->row_scale_dirty = true;
     x->pool_n_host = x->hscal[DS_POOL_N];
     return BSC_OK;
 }

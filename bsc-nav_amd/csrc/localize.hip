@@ -423,6 +423,164 @@ __global__ __launch_bounds__(64 * WV) void k_cosine_bf16x3(const float *__restri
     }
 }
 
+// ---- the same scan on fp16 pieces: three products instead of six -------------------------------------------------------------
+// An f32 value is, to 22 significant bits, the sum of TWO fp16 pieces (11 significand bits each): x q = xh qh + xh ql + xl qh +
+// O(2^-22 |x q|) — three v_mfma_f32_32x32x16_f16 per product instead of the six bf16 ones above, the same f32 accumulators
+// (encoder_gemm.hip runs the encoder's dense layers this way).  What fp16 lacks is range (5 exponent bits), so both operands are
+// brought to a fixed magnitude by exact power-of-two scales that leave through the result:
+//   queries  unit vectors (k_normalize_q) x 2^11: |element| <= 2048;
+//   rows     x s_r with s_r = the power of two that puts the row's NORM in [2^11, 2^12): every element below 4096, the typical
+//            one (norm / sqrt(D)) near 2^7; an element 2^10 below the typical one keeps its l piece to an absolute 2^-25 of the
+//            scaled row — far below the 2^-22 relative error of the typical term.
+// s_r and 1 / (norm s_r 2^11) per row come from k_row_scale, one pass over the rows that is redone only after the rows changed
+// (x->row_scale_dirty: ingest, flush, imports, merges, reset) — a loaded memory that is queried many times pays it once.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#define FX_QSCALE 2048.0f
+
+__device__ __forceinline__ void split2h(f32x2_t v, uint32_t &h, uint32_t &l)      // 2 x v_cvt_pk_f16_f32 around a packed subtract
+{
+    const half2_t hv = __builtin_convertvector(v, half2_t);
+    h = *(const uint32_t *)&hv;
+    const half2_t lv = __builtin_convertvector(v - __builtin_convertvector(hv, f32x2_t), half2_t);
+    l = *(const uint32_t *)&lv;
+}
+
+// one wavefront per row: rs[row] = (s_r, 1 / (max(norm, 1e-8) s_r 2^11))
+__global__ __launch_bounds__(TPB) void k_row_scale(const float *__restrict__ X, int64_t n_rows, int D, float2 *__restrict__ rs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    const float4 *xr = (const float4 *)(X + row * D);
+    float a = 0.f;
+    for (int k = lane; k < D / 4; k += 64) {
+        const float4 v = xr[k];
+        a = fmaf(v.x, v.x, a); a = fmaf(v.y, v.y, a); a = fmaf(v.z, v.z, a); a = fmaf(v.w, v.w, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+        const float nrm = sqrtf(a);
+        int e = 0;
+        if (nrm > 0.f && nrm < INFINITY) (void)frexpf(nrm, &e);          // nrm = m 2^e, m in [0.5, 1)
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        const float sc = (nrm > 0.f && nrm < INFINITY) ? ldexpf(1.0f, 12 - e) : 1.0f;     // norm * sc in [2^11, 2^12)
+        // the result leaves as acc * (1 / (sc 2^11)) / max(norm, 1e-8): the two powers of two are exact factors
+        rs[row] = make_float2(sc, (1.0f / fmaxf(nrm, 1e-8f)) / sc * (1.0f / FX_QSCALE));
+    }
+}
+
+// qn (Q, D) f32 unit rows -> qp (2, Q, D) fp16 pieces of 2^11 qn
+__global__ __launch_bounds__(TPB) void k_split_q_f16(const float *__restrict__ qn, int64_t n, uint16_t *__restrict__ qp)
+{
+    const int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 2;
+    if (i >= n) return;
+    uint32_t h, l;
+    const f32x2_t v = {qn[i] * FX_QSCALE, qn[i + 1] * FX_QSCALE};
+    split2h(v, h, l);
+    *(uint32_t *)(qp + i) = h;
+    *(uint32_t *)(qp + n + i) = l;
+}
+
+// layout of the work as k_cosine_bf16x3: WV wavefronts x 32 rows, NT tiles of 32 queries, query pieces staged per 32-wide K chunk
+// through LDS (two planes), rows straight from global memory in fragment layout and split in registers
+template <int NT, int WV>
+__global__ __launch_bounds__(64 * WV) void k_cosine_f16x2(const float *__restrict__ X, int64_t n_rows, int D,
+                                                           const uint16_t *__restrict__ qp, int64_t q_plane, int q0, int q_valid,
+                                                           const float2 *__restrict__ rs, float *__restrict__ sims, int64_t sims_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t Qs[];           // [2][2][NT * 32][BX_PITCH]
+    constexpr int QROWS = NT * 32;
+    constexpr int BUF = 2 * QROWS * BX_PITCH;
+    constexpr int NTHR = 64 * WV;
+    constexpr int NLD = 2 * QROWS * 4 / NTHR;                                 // 16-byte pieces of a query chunk per thread
+    static_assert(2 * QROWS * 4 % NTHR == 0, "query staging plan");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * (32 * WV);
+    const int64_t row = row0 + w * 32 + n;
+    const int64_t rowc = row < n_rows ? row : n_rows - 1;                  // clamped: results of padded rows are not stored
+    const float *xrow = X + rowc * D + g * 16;
+    const float2 rsc = rs[rowc];
+    const f32x2_t sc2 = {rsc.x, rsc.x};
+    const int nchunks = D / BX_KC;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    typedef float xf_t __attribute__((ext_vector_type(16)));
+    typedef uint32_t qr_t __attribute__((ext_vector_type(4 * NLD)));
+    xf_t xf;
+    qr_t qr;
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = *(const float4 *)(xrow + c * BX_KC + 4 * i);
+            xf[4 * i] = v.x; xf[4 * i + 1] = v.y; xf[4 * i + 2] = v.z; xf[4 * i + 3] = v.w;
+        }
+    };
+    auto load_q = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + NTHR * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            const uint4 v = *(const uint4 *)(qp + (int64_t)p * q_plane + (int64_t)(q0 + q) * D + c * BX_KC + part * 8);
+            qr[4 * j] = v.x; qr[4 * j + 1] = v.y; qr[4 * j + 2] = v.z; qr[4 * j + 3] = v.w;
+        }
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + NTHR * j, p = i / (QROWS * 4), rem = i - p * (QROWS * 4), q = rem >> 2, part = rem & 3;
+            *(uint4 *)&Qs[buf * BUF + (p * QROWS + q) * BX_PITCH + part * 8] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
+        }
+    };
+    load_x(0);
+    load_q(0);
+    store_q(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        // this chunk's rows -> fp16 pieces of s_r x (two sub-steps of 8 floats), then the next chunk's loads go in flight
+        uint32_t bh[2][4], bl[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2_t p0 = (f32x2_t){xf[4 * i], xf[4 * i + 1]} * sc2, p1 = (f32x2_t){xf[4 * i + 2], xf[4 * i + 3]} * sc2;
+            split2h(p0, bh[i >> 1][2 * (i & 1)], bl[i >> 1][2 * (i & 1)]);
+            split2h(p1, bh[i >> 1][2 * (i & 1) + 1], bl[i >> 1][2 * (i & 1) + 1]);
+        }
+        if (c + 1 < nchunks) { load_x(c + 1); load_q(c + 1); }
+        const uint16_t *qb = &Qs[buf * BUF + n * BX_PITCH + g * 16];
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+            const half8_t xh = *(const half8_t *)bh[sstep], xl = *(const half8_t *)bl[sstep];
+            // one piece of the queries at a time; smallest terms first; consecutive MFMAs go to different accumulators
+            half8_t af[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *(const half8_t *)(qb + (1 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xh, acc[t], 0, 0, 0);      // ql xh
+#pragma unroll
+            for (int t = 0; t < NT; ++t) af[t] = *(const half8_t *)(qb + (0 * QROWS + t * 32) * BX_PITCH + sstep * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xl, acc[t], 0, 0, 0);      // qh xl
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], xh, acc[t], 0, 0, 0);      // qh xh
+        }
+        if (c + 1 < nchunks) store_q(buf ^ 1);
+        __syncthreads();
+    }
+    if (row < n_rows) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (q < q_valid) sims[(int64_t)q * sims_stride + row] = acc[t][r] * rsc.y;
+            }
+    }
+}
+
 __device__ __forceinline__ uint32_t float_desc_key(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -980,7 +1138,34 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
         const bool six = !(pcs && atoi(pcs) == 3);
         static const bool wv8 = getenv("BSC_COSINE_WV4") == nullptr;                     // A/B: 8 (default) or 4 wavefronts per workgroup                 // A/B: the round-2 f32 MFMA scan throughout
         const int padded = ((nq + 255) / 256) * 256 > 1024 ? 1024 : ((nq + 255) / 256) * 256;
-        if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
+        const bool bf16_pieces = getenv("BSC_COSINE_BF16") != nullptr;                 // A/B (read per call): the round-3/4 six-product bf16 scan
+        if (!f32_only && nq > 64 && !bf16_pieces) {
+            // fp16 pieces, three products (round 5): per-row scales / inverse norms cached until the rows change
+            const int64_t nel = (int64_t)padded * D;
+            if (x->row_scale_dirty || !x->l_rscale || x->l_rscale_cap < (int64_t)sizeof(float2) * n_rows) {
+                if (x->l_rscale_cap < (int64_t)sizeof(float2) * n_rows)
+                    BSC_TRY(grow_dev((void **)&x->l_rscale, &x->l_rscale_cap, sizeof(float2) * (n_rows + n_rows / 8 + 1024)));
+                hipLaunchKernelGGL(k_row_scale, dim3((unsigned)((n_rows * 64 + TPB - 1) / TPB)), block, 0, s, rows, n_rows, D, x->l_rscale);
+                x->row_scale_dirty = false;
+            }
+            hipLaunchKernelGGL(k_split_q_f16, dim3((unsigned)((nel / 2 + TPB - 1) / TPB)), block, 0, s, x->l_q, nel, x->l_qp);
+            while (done < nq) {
+                const int left = nq - done;
+                ++passes;
+#define FX_LAUNCH(NTV, ADV)                                                                                                         \
+    do {                                                                                                                            \
+        const size_t lds = (size_t)2 * 2 * (NTV * 32) * BX_PITCH * sizeof(uint16_t);                                               \
+        (void)hipFuncSetAttribute((const void *)k_cosine_f16x2<NTV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL((k_cosine_f16x2<NTV, 8>), dim3((unsigned)((n_rows + 255) / 256)), dim3(512), lds, s, rows, n_rows, D,    \
+                           (const uint16_t *)x->l_qp, nel, done, nq, (const float2 *)x->l_rscale, x->l_sims, sstride);              \
+        done += ADV;                                                                                                                \
+    } while (0)
+                if (left > 128) FX_LAUNCH(8, 256);
+                else if (left > 64) FX_LAUNCH(4, 128);
+                else { --passes; break; }                    // the remainder (<= 64 queries) goes to the f32 MFMA below
+#undef FX_LAUNCH
+            }
+        } else if (!f32_only && nq > 64) {         // measured over 2^20 x 768: 33..64 queries 1.17-1.28 ms against 1.09 ms on the f32 MFMA (HBM-bound either way)
             const int64_t nel = (int64_t)padded * D;
             hipLaunchKernelGGL(k_split_q, dim3((unsigned)((nel / 2 + TPB - 1) / TPB)), block, 0, s, x->l_q, nel, x->l_qp);
             // k_split_q wrote planes nel apart; the scan indexes them with the same stride

@@ -302,9 +302,10 @@ def test_c4_store_shape_2pow20_voxels_ragged_tokens_matches_fp64_scan():
 
 @pytest.mark.parametrize("Q", [70, 130, 300])
 def test_batched_cosine_on_bf16_pieces_keeps_f32_accuracy(Q):
-    """From 65 queries on the scan runs on the bf16 matrix cores with every f32 operand split into three bf16 pieces (six
-    MFMAs per product, f32 accumulation): rows whose scale spans eight decades (cosine is scale-free, the split must be too)
-    and elements of mixed magnitude, against the fp64 scan — scores within 3e-6, same voxels in the same order up to near-ties."""
+    """From 65 queries on the scan runs on the 16-bit matrix cores with every f32 operand split into pieces (round 5: two fp16
+    pieces, three MFMAs per product, per-row power-of-two scales; rounds 3-4: three bf16 pieces, six MFMAs), f32 accumulation:
+    rows whose scale spans eight decades (cosine is scale-free, the split must be too) and elements of mixed magnitude, against
+    the fp64 scan — scores within 3e-6, same voxels in the same order up to near-ties."""
     import torch
     import bsc_nav_amd as B
     import golden_util as gu
@@ -321,4 +322,56 @@ def test_batched_cosine_on_bf16_pieces_keeps_f32_accuracy(Q):
     for i in range(Q):
         assert n[i] == K
         gu.assert_topk_near(pos[i], sim[i], kk[idx[i].cpu().numpy()], ref[i].cpu().numpy(), tol=3e-6)
+    eng.close()
+
+
+def test_batched_cosine_row_scales_follow_the_map(monkeypatch):
+    """The fp16-piece scan keeps per-row scales / inverse norms until the rows change: a replaced map, an imported one and a map that
+    grew by an ingest must each be scanned with fresh scales (scores against the fp64 scan of the CURRENT rows), zero
+    rows score 0 like the other scans, rows from 1e-15 to 1e15 keep f32 accuracy, and the six-product bf16 scan (A/B switch)
+    agrees."""
+    import torch
+    import bsc_nav_amd as B
+    import golden_util as gu
+    V, D, gs, K, Q = 20000, 768, 64, 50, 130
+    keys, rows, gen = _big_map(torch, V, D, gs, 33)
+    eng = B.VoxelEngine(48, 64, gs, 0.1, -3.2, 3.2, 14, D, mode="mean", voxel_capacity=V + 4096, max_points=4096)
+    ones = torch.ones(V, dtype=torch.int32, device="cuda")
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    kk = keys.cpu().numpy()
+
+    def check(r, tol=3e-6, kk=kk):
+        pos, sim, n = eng.localize(q, K=K)
+        idx, ref = _fp64_topk(torch, r, q, K)
+        for i in range(0, Q, 13):
+            assert n[i] == K
+            gu.assert_topk_near(pos[i], sim[i], kk[idx[i].cpu().numpy()], ref[i].cpu().numpy(), tol=tol)
+        return sim
+
+    eng.dense_replace(keys, rows, ones)
+    check(rows)
+    # the same voxels, every row rescaled by its own factor spread over thirty decades, some rows zero
+    r2 = rows * torch.pow(10.0, torch.rand((V, 1), device="cuda", generator=gen) * 30 - 15)
+    r2[::97] = 0
+    r2 = r2[torch.randperm(V, device="cuda", generator=gen)].contiguous()      # other rows under the same keys: stale scales would be wrong
+    eng.dense_replace(keys, r2, ones)
+    s_f16 = check(r2)
+    monkeypatch.setenv("BSC_COSINE_BF16", "1")
+    s_bf16 = check(r2)
+    monkeypatch.delenv("BSC_COSINE_BF16")
+    assert np.abs(s_f16 - s_bf16).max() < 3e-6
+    # import through the host path
+    r3 = torch.randn((V, D), device="cuda", generator=gen) * 1e-3
+    eng.import_rgb(kk, np.zeros((V, 3), np.uint8), np.ones(V, np.float32))
+    eng.import_dense(r3.cpu().numpy(), np.ones(V, np.int32))
+    check(r3)
+    # an ingest on top: touched rows change, new voxels appear
+    import synth
+    rgb, depth, poses = synth.make_frames(7, 1, 48, 64, "room")
+    T = B.PoseChain().pc_transform(poses[0])[None]
+    tok = torch.randn((1, 14, 14, D), device="cuda", generator=gen)
+    eng.ingest(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), tok, T)
+    acc, cnt = eng.export_dense()
+    assert (cnt > 0).all() and len(cnt) > V
+    check(torch.from_numpy(acc).cuda(), kk=eng.export_rgb()[0])
     eng.close()
