@@ -391,12 +391,16 @@ class HostFrames:
         ready = [torch.cuda.Event() for _ in range(2)]
         free = [torch.cuda.Event() for _ in range(2)]
 
+        ch = int(os.environ.get("BSC_H2D_CHUNK_FRAMES", "16"))      # frames per hipMemcpyAsync: short copies let the library's own
+                                                                     # small readbacks through between them
+
         def feed(s):
             b, c = s & 1, s % cyc
             with torch.cuda.stream(self.copy):
                 self.copy.wait_event(free[b])             # the step that last read this buffer has passed its ingest
-                self.rgb_d[b].copy_(self.rgb_h[c], non_blocking=True)
-                self.dep_d[b].copy_(self.dep_h[c], non_blocking=True)
+                for lo in range(0, B, ch):
+                    self.rgb_d[b][lo:lo + ch].copy_(self.rgb_h[c][lo:lo + ch], non_blocking=True)
+                    self.dep_d[b][lo:lo + ch].copy_(self.dep_h[c][lo:lo + ch], non_blocking=True)
                 ready[b].record(self.copy)
         free[0].record(main); free[1].record(main)
         feed(lo)

@@ -557,8 +557,12 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                                                              const uint32_t *__restrict__ seg_start, const int64_t *dscal,
                                                              const TOK *__restrict__ tokens, int D,
                                                              float *__restrict__ acc_g, int32_t *__restrict__ acnt,
-                                                             CellCode cc, const int32_t *__restrict__ occ)
+                                                             CellCode cc, const int32_t *__restrict__ occ,
+                                                             uint32_t row_lo, uint32_t row_hi, int later_pass)
 {
+    // [row_lo, row_hi): the token rows (frame * g^2 + patch) this launch reduces.  A call whose token tile is larger than the
+    // 256 MB MALL is reduced in passes over slices of its frames (dense_reduce_batch): a voxel's pairs are in row order, so every
+    // pass takes a contiguous stretch of its segment; passes after the first add to what the earlier ones stored.
     constexpr int RF = BSC_REDUCE_RF;          // token rows in flight per wavefront
     const int lane = threadIdx.x & 63;
     const int64_t nseg = dscal[DS_B_NPSEG];
@@ -595,9 +599,13 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
             const int64_t k = base + lane;
             const bool in = k < n_pairs && code_sorted[k < n_pairs ? k : 0] == code;
             const u64 rec = in ? pair_rec[idx_sorted[k]] : 0ull;
-            const int n = __popcll(__ballot(in));
+            const int n_in = __popcll(__ballot(in));
             const uint32_t row_l = (uint32_t)(rec >> 32), cnt_l = (uint32_t)rec & 0xffffffu;
-            for (int j = 0; j < n; j += RF) {
+            const bool in_r = in && row_l >= row_lo && row_l < row_hi;
+            const int j_lo = __popcll(__ballot(in && row_l < row_lo));
+            const int n = j_lo + __popcll(__ballot(in_r));                // the lanes [j_lo, n) hold this pass's pairs of the chunk
+            const bool past = __ballot(in && row_l >= row_hi) != 0ull;     // the rest of the segment belongs to later passes
+            for (int j = j_lo; j < n; j += RF) {
                 if constexpr (sizeof(TOK) == 2 && MODE != BSC_MODE_MAX) {
                     // bf16 rows, sum: v_dot2c_f32_bf16 with (m, 0) / (0, m) as the second operand adds m x one element of the
                     // pair to the f32 accumulator — widening and multiply-add in one instruction (the row loads are 8 bytes
@@ -670,12 +678,13 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                         }
                     }
             }
-            uint32_t cs = in ? cnt_l : 0u;
+            uint32_t cs = in_r ? cnt_l : 0u;
             for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
             total += cs;
-            if (n < 64) break;
+            if (n_in < 64 || past) break;
         }
-        const bool is_new = vid >= max_id_prev;
+        const bool is_new = !later_pass && vid >= max_id_prev;
+        if (total == 0 && !is_new) continue;                               // nothing of this voxel in this pass
         float4 *dst = (float4 *)(acc_g + vid * D);
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
@@ -1040,9 +1049,23 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
                 return BSC_OK;
             }
         }
+        // BSC_REDUCE_PASS_BYTES=<n>: passes over slices of the call's frames, each slice's token rows at most n bytes (so that they
+        // stay in the 256 MB MALL while the pairs gather them).  OFF by default — measured (round 5, 768 frames of 14 x 14 x 768
+        // f32 rows = 462 MB): one pass 1.73 ms, two of 231 MB 1.67, four of 115 MB 2.05, eight 2.31: the kernel is bound by the
+        // L2 -> CU rate of its row gathers (17 GB per call at ~10 TB/s) and by its longest voxel, not by where the rows come from;
+        // every pass visits every voxel again.  Kept with its parity test (tests/test_gpu_edges.py).
+        const int64_t pass_b = getenv("BSC_REDUCE_PASS_BYTES") ? atoll(getenv("BSC_REDUCE_PASS_BYTES")) : 0;   // read per call; 0 (default): one pass
+        const int64_t tile_b = (int64_t)n_frames * x->g2 * D * (token_dtype == BSC_TOK_BF16 ? 2 : 4);
+        int n_pass = pass_b > 0 ? (int)((tile_b + pass_b - 1) / pass_b) : 1;
+        n_pass = n_pass < 1 ? 1 : (n_pass > 8 ? 8 : n_pass);
+        if (n_pass > n_frames) n_pass = n_frames;
+        const int frames_per_pass = (n_frames + n_pass - 1) / n_pass;
+        uint32_t row_lo = 0, row_hi = 0xffffffffu;
+        int later_pass = 0;
 #define LVP(NVV, MODEV, TOKT, PAIR)                                                                                            \
     hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT, PAIR>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
-                       n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ)
+                       n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ,     \
+                       row_lo, row_hi, later_pass)
 #define LV(NVV, MODEV, TOKT) LVP(NVV, MODEV, TOKT, false)
 #define LVM(NVV)                                                                                   \
     do {                                                                                           \
@@ -1053,7 +1076,12 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
             if (x->c.mode == BSC_MODE_MEAN) LV(NVV, BSC_MODE_MEAN, float); else LV(NVV, BSC_MODE_MAX, float);   \
         }                                                                                          \
     } while (0)
-        if (nv <= 1) LVM(1); else if (nv == 2) LVM(2); else if (nv == 3) LVM(3); else if (nv == 4) LVM(4); else LVM(8);
+        for (int ps = 0; ps < n_pass; ++ps) {
+            row_lo = (uint32_t)((int64_t)ps * frames_per_pass * x->g2);
+            row_hi = ps + 1 == n_pass ? 0xffffffffu : (uint32_t)((int64_t)(ps + 1) * frames_per_pass * x->g2);
+            later_pass = ps > 0;
+            if (nv <= 1) LVM(1); else if (nv == 2) LVM(2); else if (nv == 3) LVM(3); else if (nv == 4) LVM(4); else LVM(8);
+        }
 #undef LVM
 #undef LVP
 #undef LV

@@ -339,6 +339,52 @@ def test_column_sliced_reduce_against_oracle(monkeypatch, D, bf16, mode, kind):
     eng.close()
 
 
+@pytest.mark.parametrize("D,bf16,mode,kind", [(768, False, "mean", "room"), (768, True, "mean", "iid"), (1024, False, "max", "room"),
+                                               (128, True, "max", "iid")])
+def test_dense_reduce_in_passes_over_frame_slices(monkeypatch, D, bf16, mode, kind):
+    """A call whose token tile is larger than the MALL is reduced in passes over slices of its frames (forced here: 4-frame calls
+    in passes of 1 or 2 frames — the last pass takes the remainder): counts exact, max rows bit-exact, means within 1e-3 of the
+    sequential oracle and equal to a one-pass reduce up to f32 summation order; voxels that first appear in a later slice and
+    voxels whose pairs all sit in one slice included."""
+    import torch
+    import bsc_nav_amd as B
+    import synth
+    from oracle import oracle as orc
+    H, W, g, gs, F = 240, 320, 14, 128, 8
+    rgb, depth, poses = synth.make_frames(77, F, H, W, kind)
+    tokens = synth.make_tokens(77, F, g, D)
+    d_tok = torch.from_numpy(tokens).cuda()
+    if bf16:
+        d_tok = d_tok.bfloat16()
+        tokens = d_tok.float().cpu().numpy()
+    om = orc.OracleMemory(orc.make_config(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=1 if mode == "mean" else 2), voxel_capacity=400_000)
+    chain = B.PoseChain()
+    Ts = np.stack([chain.pc_transform(p) for p in poses])
+    for f in range(F):
+        om.ingest_frame(depth[f], rgb[f], None, Ts[f], tokens[f])
+    oacc, ocnt = om.export_dense()
+    res = {}
+    per_frame = g * g * D * (2 if bf16 else 4)
+    for label, pass_bytes in (("one", 0), ("per_frame", per_frame), ("three_then_one", 3 * per_frame)):
+        monkeypatch.setenv("BSC_REDUCE_PASS_BYTES", str(pass_bytes))
+        eng = B.VoxelEngine(H, W, gs, 0.1, -6.4, 6.4, g, D, mode=mode, voxel_capacity=400_000, max_points=4 * H * W)
+        for a in range(0, F, 4):
+            eng.ingest(torch.from_numpy(depth[a:a + 4]).cuda(), torch.from_numpy(rgb[a:a + 4]).cuda(), d_tok[a:a + 4].contiguous(), Ts[a:a + 4])
+        acc, cnt = eng.export_dense()
+        assert np.array_equal(eng.export_rgb()[0], om.export_rgb()[0]) and np.array_equal(cnt, ocnt) and len(cnt) > 2000
+        if mode == "max":
+            assert np.array_equal(acc, oacc)
+        else:
+            c = np.maximum(cnt, 1)[:, None].astype(np.float64)
+            np.testing.assert_allclose(acc / c, oacc / c, rtol=1e-3, atol=1e-3)
+        res[label] = acc
+        eng.close()
+    if mode == "mean":
+        c = np.maximum(ocnt, 1)[:, None].astype(np.float64)
+        assert np.abs((res["one"] - res["per_frame"]) / c).max() < 2e-5
+        assert np.abs((res["one"] - res["three_then_one"]) / c).max() < 2e-5
+
+
 def test_groups_longer_than_the_run_length_field_are_cut_into_runs():
     """A voxel capacity of 2^26 leaves 6 bits for a run's length beside the voxel id in the sort key: k_points has to cut every
     block-local group of more than 64 points into several runs (1 m cells: groups of up to 2048 points), and the chain must still
