@@ -8,7 +8,12 @@ OBJ="$HERE/_obj"
 mkdir -p "$OBJ"
 FLAGS="${BSC_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 pids=()
-for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_gemm host_rng capi; do
+# host_rng.cpp: host-only C++ (NumPy's MT19937 shuffle restated, AVX2 paths behind a runtime check) — plain g++
+if [ ! -f "$OBJ/host_rng.o" ] || [ "$HERE/host_rng.cpp" -nt "$OBJ/host_rng.o" ] || [ "$HERE/../../include/bscnav.h" -nt "$OBJ/host_rng.o" ]; then
+  ( g++ -O3 -std=c++17 -fPIC -Wall -I"$HERE/../../include" -c "$HERE/host_rng.cpp" -o "$OBJ/host_rng.o" ) &
+  pids+=($!)
+fi
+for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_gemm capi; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/bsc_internal.h" -nt "$obj" ] || [ "$HERE/geometry_dev.h" -nt "$obj" ] || [ "$HERE/../../include/bscnav.h" -nt "$obj" ]; then
     ( hipcc $FLAGS -c "$src" -o "$obj" ) &

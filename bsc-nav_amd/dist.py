@@ -285,13 +285,26 @@ def merge_dense_maps(engine, group=None):
     if not _active():
         return dict(n_union=n_union, per_rank=n_union, n_local=n_union)
     ukeys = unpack_keys(union)
-    acc, cnt = engine.dense_gather(ukeys)
     rgb, wgt = engine.dense_gather_rgb(ukeys)
-    mark("gather_rows")
     op = dist.ReduceOp.MAX if engine.mode == "max" else dist.ReduceOp.SUM
-    my_acc = reduce_scatter_rows(acc, op, per, group)
-    my_cnt = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, per, group)
-    mark("reduce_scatter")
+    # The (U, D) union of feature rows is never materialised (4.3 GB per rank at 2^20 x 1024): the reduce-scatter runs over row
+    # chunks — chunk c of EVERY rank's slice gathered from this rank's map (world x n rows), reduce-scattered into rows
+    # [c, c + n) of this rank's slice.  Same bytes on the wire, bounded staging (BSC_MERGE_CHUNK_BYTES, default 1 GiB).
+    D = int(engine.cfg.token_dim)
+    budget = int(os.environ.get("BSC_MERGE_CHUNK_BYTES", str(1 << 30)))
+    chunk = max(1, min(per, budget // max(1, world * D * 4)))
+    my_acc = torch.empty((per, D), dtype=torch.float32, device=ukeys.device)
+    my_cnt = torch.empty(per, dtype=torch.int32, device=ukeys.device)
+    have = torch.empty(world * per, dtype=torch.bool, device=ukeys.device)            # this rank holds the voxel (colour exchange)
+    uk3 = ukeys.view(world, per, 3)
+    for lo in range(0, per, chunk):
+        n = min(chunk, per - lo)
+        acc, cnt = engine.dense_gather(uk3[:, lo:lo + n].reshape(world * n, 3).contiguous())
+        have.view(world, per)[:, lo:lo + n] = (cnt > 0).view(world, n)
+        my_acc[lo:lo + n] = reduce_scatter_rows(acc, op, n, group)
+        my_cnt[lo:lo + n] = reduce_scatter_rows(cnt, dist.ReduceOp.SUM, n, group)
+        del acc, cnt
+    mark("gather_rows+reduce_scatter")
     lo, hi = rank * per, (rank + 1) * per
     if getattr(engine, "log_capacity", 0):
         # the ranks kept their points (sub-sampled modes): exact colour state by replay on the voxel's owner
@@ -300,7 +313,7 @@ def merge_dense_maps(engine, group=None):
     else:
         # colour state: 7 bytes per voxel and rank, needed only by the voxel's owner: every rank sends slice s of its
         # (rgb, weight, present) to rank s — one all-to-all of equal splits (gloo, tests: all-gather and slice)
-        all_rgb, all_w, all_present = _exchange_slices(rgb, wgt, cnt > 0, per, group)
+        all_rgb, all_w, all_present = _exchange_slices(rgb, wgt, have, per, group)
         my_rgb, my_w = merge_colour_states(all_rgb, all_w, all_present)
         colour_rule = "per-rank states as observations (approximate)"
     mark("colour")

@@ -81,6 +81,23 @@ def test_host_shuffle_matches_numpy_bit_for_bit():
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+def test_host_shuffle_plain_path_matches_numpy_too():
+    """the same with the AVX2 block functions / eight-at-a-time rejection switched off (BSC_HOST_NO_AVX2, read once per process:
+    a child process): what a host without AVX2 runs"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from bsc_nav_amd import geometry as G\n"
+            "for seed in (0, 7):\n"
+            "    for n, rate in ((1, 1), (9, 2), (1000, 7), (307200, 1000), (65537, 3)):\n"
+            "        np.random.seed(seed); a = G.sample_indices(n, rate); sa = np.random.randint(0, 1 << 30, 4)\n"
+            "        np.random.seed(seed); b = G.sample_indices_fast(n, rate); sb = np.random.randint(0, 1 << 30, 4)\n"
+            "        assert np.array_equal(a, b) and np.array_equal(sa, sb), (seed, n, rate)\n"
+            "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BSC_HOST_NO_AVX2="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_host_choice_draws_match_python_random():
     """bsc_host_choice_draws == [random.choice(range(k)) ...] (memory_2.py:352) incl. the state of Python's stream."""
     import ctypes as C

@@ -116,9 +116,14 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("chunk_bytes", [None, 256])
 @pytest.mark.parametrize("mode", ["mean", "max"])
-def test_two_rank_merge_equals_single_process_reduce(tmp_path, mode):
+def test_two_rank_merge_equals_single_process_reduce(tmp_path, mode, chunk_bytes, monkeypatch):
+    """chunk_bytes 256: the reduce-scatter of the union runs over row chunks of 4 rows per rank (bounded staging instead of
+    the whole (U, D) union on every rank) — same result"""
     world, D = 2, 8
+    if chunk_bytes:
+        monkeypatch.setenv("BSC_MERGE_CHUNK_BYTES", str(chunk_bytes))        # inherited by the spawned ranks
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(f"{tmp_path}/r{r}.pt", weights_only=False) for r in range(world)]
     # single-process reference reduce over both rank maps
