@@ -13,7 +13,7 @@ import re
 root, out_path, commit = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "unknown")
 _bench = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
 frames_per_call = int(sys.argv[4]) if len(sys.argv) > 4 else int(re.search(r'"--batch", type=int, default=(\d+)', _bench).group(1))
-ENCODER = ("k_attention", "k_add_layernorm", "k_bias_layernorm", "k_embed_layernorm", "k_final_layernorm", "k_preprocess", "k_pp_taps", "Cijk", "Custom_Cijk",
+ENCODER = ("k_gemm_split", "k_layernorm_split", "k_split_weights", "k_split_rows", "k_attention", "k_add_layernorm", "k_bias_layernorm", "k_embed_layernorm", "k_final_layernorm", "k_preprocess", "k_pp_taps", "Cijk", "Custom_Cijk",
            "at::native", "__amd_rocclr_copyBuffer", "k_cosine", "k_cand", "k_block_topk", "k_gather", "k_normalize_q", "k_name", "k_pool")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("RD", "WR"):
@@ -30,9 +30,9 @@ for name, cs in agg.items():
                  "ingest": not any(name.startswith(p) or p in name[:40] for p in ENCODER)}
 tot = sum((v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_call"] for v in out.values() if v["ingest"])
 json.dump({"command": "rocprofv3 --pmc <TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B | TCC_EA0_WRREQ TCC_EA0_WRREQ_64B> "
-                      "--kernel-trace -- python bench.py --no-cpu-baseline --no-localize --no-workloads --no-f32 --no-exact --repeats 1 (two separate passes; "
+                      "--kernel-trace -- python bench.py --no-cpu-baseline --no-localize --no-workloads --no-side-precision --no-host-feed --no-exact --repeats 1 (two separate passes; the default f32 pipeline, f32 tokens; "
                       f"8 steps x {frames_per_call} frames, room depth)",
-           "commit": commit, "frames_per_call": frames_per_call,
+           "commit": commit, "frames_per_call": frames_per_call, "token_bytes": int(os.environ.get("BSC_PMC_TOKEN_BYTES", "4")),
            "units": "bytes per launch (mean over all launches of the pass), by request size: read = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B, "
                     "write = 64 WRREQ_64B + 32 (WRREQ - WRREQ_64B); calibration: profiles/r03_pmc_calibration.txt",
            "ingest_traffic_bytes_per_call": tot, "kernels": out}, open(out_path, "w"), indent=1)
