@@ -67,7 +67,7 @@ import torch  # noqa: E402
 
 PMC_FILE = "r04_pmc_ingest_kernels.json"
 # k_points by the SQ counters of that pass (SQ_INSTS_VALU per wavefront of 512 points / 8 rounds; the f64 share from the ISA)
-KP_VALU_PER_64, KP_VALU_F64_PER_64 = 292.0, 69.0
+KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 292.0, 69.0, 103.0
 N_SIMD, CLOCK_GHZ = 1024, 2.4            # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), committed PMC pass (profiles/r04_pmc_mfma_counters.txt)
 MFMA_BUSY_COMMITTED = {"k_gemm_split": "0.385-0.443", "k_attention_split": 0.25, "hipBLASLt bf16 (same shapes)": "0.43-0.47",
@@ -972,11 +972,14 @@ def main():
         # counters of the committed PMC pass (profiles/), issue cycles = 4 per wave64 instruction, 8 for the f64 ones (half rate)
         kp_ms = iso["stages"]["k_points"]
         pts = iso["P"]
-        cyc = (KP_VALU_PER_64 - KP_VALU_F64_PER_64) * 4 + KP_VALU_F64_PER_64 * 8
+        cyc = (KP_VALU_PER_64 - KP_VALU_F64_PER_64) * 2 + KP_VALU_F64_PER_64 * 4
         need = pts / 64.0 * cyc
         out["roofline"]["k_points_valu"] = {
-            "bound": "valu issue (f64 geometry at half rate)", "kernel": "k_points", "ms_per_call": kp_ms,
-            "valu_instructions_per_64_points": KP_VALU_PER_64, "of_them_f64": KP_VALU_F64_PER_64,
+            "bound": "vector instruction issue (CDNA4 SIMD-32: a wave64 instruction issues over 2 cycles, an f64 one over 4) — the kernel's "
+                     "largest single resource; by its phase clocks (profiles/README.md) the geometry phase runs at the issue rate of its four "
+                     "co-resident wavefronts, the grouping phases wait on LDS and the CU's one scalar unit (~100 scalar instructions per 64 points)",
+            "kernel": "k_points", "ms_per_call": kp_ms,
+            "valu_instructions_per_64_points": KP_VALU_PER_64, "of_them_f64": KP_VALU_F64_PER_64, "salu_instructions_per_64_points": KP_SALU_PER_64,
             "achieved": need / (kp_ms * 1e-3) / 1e12, "peak": N_SIMD * CLOCK_GHZ * 1e9 / 1e12, "unit": "T issue-cycles/s",
             "frac": need / (kp_ms * 1e-3) / (N_SIMD * CLOCK_GHZ * 1e9),
             "hbm_frac_of_own_bytes": 8.0 * pts / (kp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

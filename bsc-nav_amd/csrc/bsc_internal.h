@@ -67,6 +67,7 @@ struct bsc_ctx {
     bool geom_fast;
     bool long_chain;           // segments of >= 64 points go to the wavefront-per-voxel chain (BSC_QUAD_CHAIN_ONLY unsets)
     uint8_t *pat_x, *pat_y;   // (W), (H): patch column / row of a pixel column / row, 255 = outside the patch grid
+    double *exp_tab;          // 64 x (hi, lo) of 2^(j/64): the table of bsc_exp (geometry_dev.h)
     // patch-aligned pair tiles (dense.hip): pixel rectangle {x0, width, y0, pixels} of every patch and the start of its
     // staging slice inside a frame; valid when every patch covers at most 3328 pixels
     bool patch_tiles;

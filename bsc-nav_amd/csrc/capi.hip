@@ -163,6 +163,16 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->cv_map, 3 * gs2);
     ALLOC(x->dscal, DS_COUNT);
     BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * (DS_COUNT + 1)));      // + a slot for the pair count read on its own
+    ALLOC(x->exp_tab, 128);
+    {
+        double tab[128];
+        for (int j = 0; j < 64; ++j) {
+            const long double v = exp2l((long double)j / 64.0L);
+            tab[2 * j] = (double)v;
+            tab[2 * j + 1] = (double)(v - (long double)tab[2 * j]);
+        }
+        if (hipMemcpy(x->exp_tab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) { bsc_set_error("bsc_create: exp table upload failed"); bsc_destroy(x); return BSC_E_HIP; }
+    }
     ALLOC(x->pat_x, c.width);
     ALLOC(x->pat_y, c.height);
     {
@@ -303,7 +313,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     hipSetDevice(x->device);
     if (x->side) hipStreamSynchronize(x->side);
     hipStreamSynchronize(x->stream);
-    void *ptrs[] = {x->pat_x, x->pat_y, x->pt_rect, x->pt_off, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
+    void *ptrs[] = {x->exp_tab, x->pat_x, x->pat_y, x->pt_rect, x->pt_off, x->occ, x->rgb_pos, x->rgb, x->weight, x->hmap, x->cv_map, x->dscal, x->cache_f, x->cache_pos,
                     x->cache_d, x->pool, x->pool_d, x->store_rows, x->store_cnt, x->acc, x->acnt, x->p_cell, x->p_patf,
                     x->p_rec_s[0], x->p_rec_s[1], x->p_r2f, x->new_cells, x->run_scan, x->seg_k0, x->seg_vid, x->blk_pass, x->blk_pass_off, x->hb_cnt, x->hb_off,
                     x->skey_a, x->sval_a, x->skey_b_s[0], x->skey_b_s[1], x->sval_b_s[0], x->sval_b_s[1], x->blk_cnt, x->blk_off,

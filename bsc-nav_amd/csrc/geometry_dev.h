@@ -19,7 +19,33 @@ struct GeomConst {
     double rcs;               // RN(1 / cs)
     const uint8_t *pat_x;     // (W) patch column of pixel column x, 255 = outside [0, g)
     const uint8_t *pat_y;     // (H) patch row of pixel row y
+    // bsc_exp (below): constants as kernel arguments (scalar registers: an f64 instruction reads them directly; as literals every
+    // use cost two register moves) and the table of 2^(j/64) as (hi, lo) pairs
+    double exp_il, exp_l1, exp_l2, exp_c2, exp_c3, exp_c4, exp_c5;
+    const double2 *exp_tab;
 };
+
+// exp(x) for the point weights alpha = exp(-r^2 / 1.2) (memory_2.py:873-875), x <= 0.  Table-driven (Tang): k = rint(x 64 / ln 2),
+// r = x - k ln2/64 in two steps (|r| <= ln2/128: the degree-5 polynomial for exp(r) - 1 is good to 2^-56), exp(x) = 2^(k >> 6)
+// T[k & 63] (1 + p) with T as (hi, lo): 14 f64 instructions against ~25 (+ ~18 register moves for its literals) of the device
+// library's exp, which this replaces on every device-alpha path.  Error <= 1 ulp (tests/test_gpu_edges.py: against NumPy's exp
+// over the whole depth range) — the same class as the library routine: the dense modes' rgb bytes differ from a host-alpha build
+// in < 0.1 % of the bytes either way; the reference-exact mode takes alpha from the host (bit-exact).  tab: 64 x (hi, lo), in LDS
+// for k_points.  Out-of-range lanes (their results are discarded): the table index stays in range, nothing traps.
+__device__ __forceinline__ double bsc_exp(double x, const GeomConst &c, const double2 *tab)
+{
+    const double kf = __builtin_rint(__dmul_rn(x, c.exp_il));
+    const int k = (int)kf;
+    double r = __fma_rn(-kf, c.exp_l1, x);
+    r = __fma_rn(-kf, c.exp_l2, r);
+    double q = __fma_rn(r, c.exp_c5, c.exp_c4);
+    q = __fma_rn(r, q, c.exp_c3);
+    q = __fma_rn(r, q, c.exp_c2);
+    q = __fma_rn(r, q, 1.0);
+    const double p = __dmul_rn(r, q);                       // exp(r) - 1
+    const double2 t = tab[k & 63];
+    return ldexp(__dadd_rn(t.x, __fma_rn(t.x, p, t.y)), k >> 6);
+}
 
 struct GeomOut {
     double pc[3], pg[3];
@@ -51,7 +77,7 @@ __device__ __forceinline__ double dot4_fma(const double *r, double a, double b, 
 
 // i: row-major pixel index inside the frame; z: its depth; T: 4x4 pc_transform (row-major)
 __device__ __forceinline__ void geom_point(const GeomConst &c, int32_t i, float zf, const double *T, GeomOut &o,
-                                           bool want_alpha)
+                                           bool want_alpha, const double2 *exp_tab)
 {
     const int y = i / c.W, x = i - y * c.W;
     const double px = (double)x + 0.5, py = (double)y + 0.5;   // utils.py:167-168
@@ -95,7 +121,7 @@ __device__ __forceinline__ void geom_point(const GeomConst &c, int32_t i, float 
     if (!(o.pat[0] < 0 || o.pat[1] < 0 || o.pat[0] >= c.g || o.pat[1] >= c.g)) o.flags |= 4;   // memory_2.py:878
     // memory_2.py:873-875  r2 = (x^2 + y^2) + z^2 ; alpha = exp(-r2 / 1.2)
     o.r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(p2, p2));
-    o.alpha = want_alpha ? exp(__ddiv_rn(-o.r2, 2 * 0.6)) : 0.0;
+    o.alpha = want_alpha ? bsc_exp(__ddiv_rn(-o.r2, 2 * 0.6), c, exp_tab) : 0.0;
 }
 
 
@@ -128,7 +154,7 @@ __device__ __forceinline__ double div_by_const(double x, double c, double rc)
 // tx, ty: the patch column / row of the pixel (c.pat_x[x], c.pat_y[y]; 255 = outside), fetched by the caller — k_points reads
 // them for all its rounds ahead of the geometry so that no round waits for a table lookup
 __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
-                                                  GeomFastOut &o, bool want_alpha, uint32_t tx, uint32_t ty)
+                                                  GeomFastOut &o, bool want_alpha, uint32_t tx, uint32_t ty, const double2 *exp_tab)
 {
     // Straight-line on purpose: every lane evaluates the whole chain and the checks only gate the result.  With early returns the
     // wavefront still issued every instruction (some lane is always valid) and paid ~40 register moves per point on top for the
@@ -163,12 +189,12 @@ __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x,
     o.sx = min(max(sx, 0), c.W - 1);
     o.sy = min(max(sy, 0), c.H - 1);
     o.r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(z, z));
-    o.alpha = want_alpha ? exp(div_by_const(-o.r2, 1.2, 1.0 / 1.2)) : 0.0;
+    o.alpha = want_alpha ? bsc_exp(div_by_const(-o.r2, 1.2, 1.0 / 1.2), c, exp_tab) : 0.0;
     o.cell = ok ? (row * c.gs + col) * c.nh + (h - c.min_h) : -1;
 }
 
 __device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, int32_t y, float zf, const double *T,
                                                 GeomFastOut &o, bool want_alpha)
 {
-    geom_point_fast_t(c, x, y, zf, T, o, want_alpha, c.pat_x[x], c.pat_y[y]);
+    geom_point_fast_t(c, x, y, zf, T, o, want_alpha, c.pat_x[x], c.pat_y[y], c.exp_tab);
 }

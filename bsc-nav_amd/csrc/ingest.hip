@@ -42,6 +42,18 @@ static GeomConst make_geom_const(const bsc_ctx *x)
     g.fast = x->geom_fast ? 1 : 0;
     g.rcs = 1.0 / x->c.cell_size;
     g.pat_x = x->pat_x; g.pat_y = x->pat_y;
+    // bsc_exp (geometry_dev.h): 64 / ln 2; ln 2 / 64 as a 40-bit head (k * head is exact for |k| < 2^13) and its tail; 1/2 .. 1/120
+    const long double l64 = 0.693147180559945309417232121458176568L / 64.0L;
+    double l1 = (double)l64;
+    uint64_t bits;
+    memcpy(&bits, &l1, 8);
+    bits &= ~((1ull << 13) - 1);
+    memcpy(&l1, &bits, 8);
+    g.exp_il = (double)(1.0L / l64);
+    g.exp_l1 = l1;
+    g.exp_l2 = (double)(l64 - (long double)l1);
+    g.exp_c2 = 0.5; g.exp_c3 = 1.0 / 6.0; g.exp_c4 = 1.0 / 24.0; g.exp_c5 = 1.0 / 120.0;
+    g.exp_tab = (const double2 *)x->exp_tab;
     return g;
 }
 
@@ -153,6 +165,8 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];          // + a spare entry for the lanes without a slot
     __shared__ uint32_t s_wsum[GW];
     __shared__ int32_t s_ovf[GW];
+    __shared__ double2 s_exp[64];                         // 2^(j/64) as (hi, lo): bsc_exp's table
+    if (threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
     u64(*s_word)[GROUP_HS + 1] = (u64(*)[GROUP_HS + 1])s_raw;
     uint32_t *s_rec = (uint32_t *)s_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,12 +273,12 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             cell = -1;
             if (FAST) {
                 GeomFastOut o;
-                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r]);
+                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r], s_exp);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
             } else {
                 GeomOut o;
-                geom_point(gc, i, z, T, o, alpha_in == nullptr);
+                geom_point(gc, i, z, T, o, alpha_in == nullptr, s_exp);
                 if (o.flags == 7u) {
                     const int32_t row = o.vox[0], col = o.vox[1], h = o.vox[2] - gc.min_h;   // memory_2.py:867
                     cell = (row * gc.gs + col) * gc.nh + h;
@@ -1242,7 +1256,7 @@ __global__ __launch_bounds__(TPB) void k_geometry_debug(GeomConst gc, const floa
     const int32_t i = idx ? idx[j] : (int32_t)j;
     GeomOut o;
     memset(&o, 0, sizeof o);
-    geom_point(gc, i, depth[i], T, o, true);
+    geom_point(gc, i, depth[i], T, o, true, gc.exp_tab);
     flags[j] = (uint8_t)o.flags;
     for (int k = 0; k < 3; ++k) { pc[3 * j + k] = o.pc[k]; pg[3 * j + k] = o.pg[k]; vox[3 * j + k] = o.vox[k]; }
     for (int k = 0; k < 2; ++k) { pix[2 * j + k] = o.pix[k]; pat[2 * j + k] = o.pat[k]; }

@@ -200,6 +200,28 @@ def test_device_alpha_within_last_ulp_effects(torch_cuda):
     eng.close()
 
 
+def test_device_exp_within_one_ulp_of_numpy(torch_cuda):
+    """bsc_exp (geometry_dev.h: table of 2^(j/64), degree-5 polynomial, constants in scalar registers) against NumPy's exp over
+    the whole range of alpha = exp(-r^2 / 1.2): depths from min_depth to max_depth over a 640x480 frame (r^2 up to ~300), through
+    the geometry export (generic chain) — never more than one ulp apart, most results identical."""
+    import bsc_nav_amd as B
+    torch = torch_cuda
+    H, W = 480, 640
+    eng = B.VoxelEngine(H, W, 256, 0.1, -12.8, 12.8, 14, 32, mode="mean", max_points=H * W)
+    rs = np.random.RandomState(4)
+    depth = np.exp(rs.uniform(np.log(0.1001), np.log(9.999), size=(H, W))).astype(np.float32)
+    T = np.eye(4)
+    o = eng.geometry(torch.from_numpy(depth).cuda(), T)
+    ok = (o["flags"] & 1) != 0
+    want = np.exp(-o["r2"][ok] / (2 * 0.6))
+    got = o["alpha"][ok]
+    assert ok.mean() > 0.99 and (got > 0).all()
+    ulps = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert ulps.max() <= 1, ulps.max()
+    assert (ulps == 0).mean() > 0.7, (ulps == 0).mean()
+    eng.close()
+
+
 @pytest.mark.parametrize("mode", ["mean", "max"])
 @pytest.mark.parametrize("name", ["g2_c1_s1000", "g2_mini_s7_yaw", "g2_c1_s50_iid"])      # one flush, at the end: no point loses its token
 def test_dense_rows_equal_reduction_of_the_reference_store(torch_cuda, name, mode):
