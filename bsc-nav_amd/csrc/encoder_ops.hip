@@ -423,6 +423,17 @@ __device__ __forceinline__ void pp_store(void *out, int mode, int64_t row, int K
     }
 }
 
+// mode 2 with 3 p^2 not a multiple of 32 (patch 14: 588): the piece rows are padded with zeros to the next multiple (Kp = 608), the
+// thread of patch pixel t < Kp - 3 p^2 writes pad column 3 p^2 + t
+__device__ __forceinline__ void pp_store3(void *out, int mode, int64_t row, int p, int py, int px, float v0, float v1, float v2)
+{
+    const int K = 3 * p * p, Kp = mode == 2 ? (K + 31) / 32 * 32 : K, t = py * p + px;
+    pp_store(out, mode, row, Kp, t, v0);
+    pp_store(out, mode, row, Kp, p * p + t, v1);
+    pp_store(out, mode, row, Kp, 2 * p * p + t, v2);
+    if (t < Kp - K) pp_store(out, mode, row, Kp, K + t, 0.f);
+}
+
 __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__restrict__ rgb, int B, int H, int W, int C,
                                                             int S, int p, void *__restrict__ out, int mode, float m0, float m1,
                                                             float m2, float s0, float s1, float s2)
@@ -465,9 +476,7 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches(const uint8_t *__res
     }
     const int g = S / p, gy = y / p, gx = x / p, py = y - gy * p, px = x - gx * p;
     const int64_t row = (int64_t)b * g * g + (int64_t)gy * g + gx;
-    pp_store(out, mode, row, 3 * p * p, py * p + px, (a0 * (1.f / 255.f) - m0) / s0);
-    pp_store(out, mode, row, 3 * p * p, p * p + py * p + px, (a1 * (1.f / 255.f) - m1) / s1);
-    pp_store(out, mode, row, 3 * p * p, 2 * p * p + py * p + px, (a2 * (1.f / 255.f) - m2) / s2);
+    pp_store3(out, mode, row, p, py, px, (a0 * (1.f / 255.f) - m0) / s0, (a1 * (1.f / 255.f) - m1) / s1, (a2 * (1.f / 255.f) - m2) / s2);
 }
 
 // RGBA frames, one workgroup per output patch.  The taps of every output row and column (first input index, count, 12
@@ -588,9 +597,7 @@ __global__ __launch_bounds__(TPB) void k_preprocess_patches_tiled(const uint32_t
         }
     }
     const int64_t row = (int64_t)b * g * g + patch;
-    pp_store(out, mode, row, 3 * p * p, py * p + px, (a0 * (1.f / 255.f) - m0) / s0);
-    pp_store(out, mode, row, 3 * p * p, p * p + py * p + px, (a1 * (1.f / 255.f) - m1) / s1);
-    pp_store(out, mode, row, 3 * p * p, 2 * p * p + py * p + px, (a2 * (1.f / 255.f) - m2) / s2);
+    pp_store3(out, mode, row, p, py, px, (a0 * (1.f / 255.f) - m0) / s0, (a1 * (1.f / 255.f) - m1) / s1, (a2 * (1.f / 255.f) - m2) / s2);
 }
 
 extern "C" bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C,
@@ -605,7 +612,7 @@ extern "C" bsc_status bsc_enc_preprocess_patches_typed(const void *rgb_dev, int3
                                                        const float *mean3_host, const float *std3_host, void *hip_stream)
 {
     if (!rgb_dev || !out_dev || !mean3_host || !std3_host || B < 1 || C < 3 || patch < 1 || S % patch != 0 || out_mode < 0 ||
-        out_mode > 2 || (out_mode == 2 && (3 * patch * patch) % 32 != 0)) {
+        out_mode > 2 || (out_mode == 2 && patch * patch < 32)) {
         bsc_set_error("bsc_enc_preprocess_patches: invalid argument");
         return BSC_E_INVALID;
     }

@@ -69,12 +69,14 @@ class SplitLinear:
     BIAS, GELU, RESID = 0, 1, 2
     A_F32, A_PIECES, A_LN = 0, 1, 2
 
-    def __init__(self, lin, ln=None):
+    def __init__(self, lin, ln=None, k_pad=None):
         """ln: a LayerNorm applied to the input rows, folded into this layer — its gamma into the weight columns, its beta into
         the bias (LN(x) W^T + b = ((x - mean) rstd) (W gamma)^T + (W beta + b)); the GEMM then normalises the rows of the residual
         stream while it splits them (a_mode A_LN: mean / rstd from the row statistics the producing GEMM's epilogue left)."""
         from . import _lib
         w = lin.weight.detach()
+        if k_pad is not None and k_pad != w.shape[1]:       # zero columns: the operand rows are padded the same way (patch matrix, K = 588)
+            w = F.pad(w, (0, k_pad - w.shape[1]))
         assert w.is_cuda and w.dtype == torch.float32 and w.shape[1] % 32 == 0
         self.bias = None if lin.bias is None else lin.bias.detach().contiguous()
         self.ln_eps = 0.0
@@ -404,15 +406,15 @@ class RandomViT(nn.Module):
             t = self.head(t)
         return {"x_norm_patchtokens": t if keep_dtype else t.float()}
 
-    def _split(self, lin, ln=None):
+    def _split(self, lin, ln=None, k_pad=None):
         """the fp16 pieces of a Linear's weight, made on first use (f32 weights on the device); ln: a LayerNorm folded in"""
         cache = self.__dict__.setdefault("_split_cache", {})
-        key = (id(lin), None if ln is None else id(ln))
+        key = (id(lin), None if ln is None else id(ln), k_pad)
         # in-place updates (load_state_dict, copy_) keep the pointer and bump the version counter
         tag = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version),
                None if ln is None else (ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version))
         if key not in cache or cache[key][0] != tag:
-            cache[key] = (tag, SplitLinear(lin, ln))
+            cache[key] = (tag, SplitLinear(lin, ln, k_pad))
         return cache[key][1]
 
     def invalidate_split_weights(self):
@@ -428,8 +430,8 @@ class RandomViT(nn.Module):
         Wd, heads = self.width, self.blocks[0].heads
         hd = Wd // heads
         SL = SplitLinear
-        if kin % 32 == 0:
-            x = self._split(self.patch_embed)(t.reshape(B * n_patch, t.shape[2]).contiguous(), a_pieces=t_pieces).view(B, n_patch, Wd)
+        if kin % 32 == 0:       # (piece rows come zero-padded to a multiple of 32: ViT-L/14's 588 columns as 608)
+            x = self._split(self.patch_embed, k_pad=kin)(t.reshape(B * n_patch, t.shape[2]).contiguous(), a_pieces=t_pieces).view(B, n_patch, Wd)
         else:
             x = self.patch_embed(t)
         T = 1 + self.registers + n_patch
@@ -569,7 +571,7 @@ class RandomViT(nn.Module):
         elif mode == 1:
             shape, dt = (B, g * g, kin), torch.float32
         else:
-            shape, dt = (B, g * g, 2 * kin), torch.float16
+            shape, dt = (B, g * g, 2 * ((kin + 31) // 32 * 32)), torch.float16
         patches = out if out is not None else torch.empty(shape, dtype=dt, device=rgb.device)
         mean = (C.c_float * 3)(*IMAGENET_MEAN)
         std = (C.c_float * 3)(*IMAGENET_STD)
@@ -585,8 +587,7 @@ class RandomViT(nn.Module):
         if self.can_fuse_preprocess(rgb):
             t = self._forward_patches(self.preprocess_patches(rgb), keep_dtype)["x_norm_patchtokens"]
         elif self.can_fuse_preprocess_f32(rgb):
-            pieces = (3 * self.patch * self.patch) % 32 == 0
-            t = self._forward_f32_split(self.preprocess_patches(rgb, mode=2 if pieces else 1), pieces)
+            t = self._forward_f32_split(self.preprocess_patches(rgb, mode=2), True)
         else:
             t = self.forward_features(self.preprocess(rgb))["x_norm_patchtokens"]
         return t.reshape(rgb.shape[0], self.grid, self.grid, -1).contiguous()
@@ -611,7 +612,7 @@ class GraphedEncoder:
         self.f32 = (not vit.can_fuse_preprocess(probe)) and vit.can_fuse_preprocess_f32(probe)
         self.pp_mode = 0
         if self.f32:
-            self.pp_mode = 2 if (3 * vit.patch * vit.patch) % 32 == 0 else 1
+            self.pp_mode = 2
         self.from_patches = (vit.can_fuse_preprocess(probe) or self.f32) and os.environ.get("BSC_GRAPH_COPY") is None   # A/B switch
         s = torch.cuda.Stream()
         # this graph's attention counters: allocated before the capture (outside the graph's private pool), used by every

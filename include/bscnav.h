@@ -322,7 +322,8 @@ bsc_status bsc_enc_preprocess_patches(const void *rgb_dev, int32_t B, int32_t H,
                                       int32_t patch, void *out_dev, const float *mean3_host, const float *std3_host,
                                       void *hip_stream);
 /* the same pass with a choice of output: out_mode 0 bf16 (as above), 1 f32, 2 fp16 pieces for the split-operand patch-embedding
- * GEMM (3 patch^2 % 32 == 0) — the reference-precision encoder starts from these */
+ * GEMM — the reference-precision encoder starts from these; piece rows are padded with zeros to K' = 3 patch^2 rounded up to a
+ * multiple of 32 (patch 14: 588 -> 608): out_dev is (B, (S/patch)^2, 2 K') fp16 */
 bsc_status bsc_enc_preprocess_patches_typed(const void *rgb_dev, int32_t B, int32_t H, int32_t W, int32_t C, int32_t S,
                                             int32_t patch, void *out_dev, int32_t out_mode, const float *mean3_host,
                                             const float *std3_host, void *hip_stream);

@@ -70,7 +70,7 @@ def test_layernorm_split_and_split_rows():
         assert (back - x.double()).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
 
 
-@pytest.mark.parametrize("arch", ["vit_b16", "vit_tiny_test"])
+@pytest.mark.parametrize("arch", ["vit_b16", "vit_tiny_test", "vit_l14"])
 def test_f32_encoder_on_split_gemms_matches_pytorch_f32(arch):
     """Tokens of the f32 ViT with every dense layer on the fp16 matrix cores against the same module on PyTorch's f32 GEMMs
     (within 2e-5 of it at a token rms of 1) and against an fp64 evaluation (no further from it than PyTorch f32 is, x1.5)."""
@@ -236,3 +236,26 @@ def test_f32_encoder_fused_layernorm_equals_the_unfused_form(arch, monkeypatch):
     b = vit.patch_tokens(rgb)
     assert a.shape == b.shape and torch.isfinite(a).all()
     assert (a - b).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("arch", ["vit_l14", "vit_b16"])
+def test_patch_matrix_as_padded_pieces(arch):
+    """the fused preprocessing as operand pieces: patch 14 has 588 columns, padded with zeros to 608 (the GEMM contracts 32 at a
+    time; the weight gets the same zero columns) — values equal the f32 output, pad columns are zero, and the patch embedding
+    through the in-tree GEMM equals the f32 nn.Linear"""
+    import torch
+    from bsc_nav_amd import encoder
+    vit = encoder.RandomViT(arch, image_size=224, seed=4, dtype=torch.float32).cuda()
+    rgb = torch.randint(0, 255, (3, 480, 640, 4), dtype=torch.uint8, device="cuda")
+    f = vit.preprocess_patches(rgb, mode=1)
+    pz = vit.preprocess_patches(rgb, mode=2)
+    K = 3 * vit.patch ** 2
+    Kp = (K + 31) // 32 * 32
+    M = 3 * vit.grid ** 2
+    assert pz.shape == (3, vit.grid ** 2, 2 * Kp)
+    back = _pieces_back(pz.view(M, 2 * Kp), M, Kp)
+    assert (back[:, :K] - f.view(M, K).double()).abs().max().item() <= 2.0 ** -21 * f.abs().max().item()
+    assert (back[:, K:] == 0).all()
+    x = vit._split(vit.patch_embed, k_pad=Kp)(pz.view(M, 2 * Kp), a_pieces=True)
+    ref = f.view(M, K).double() @ vit.patch_embed.weight.double().t() + vit.patch_embed.bias.double()
+    assert (x.double() - ref).abs().max().item() < 5e-6
