@@ -65,18 +65,15 @@ if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" n
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PMC_FILE = "r04_pmc_ingest_kernels.json"
-# k_points by the SQ counters of that pass (SQ_INSTS_VALU per wavefront of 512 points / 8 rounds; the f64 share from the ISA)
-KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 292.0, 69.0, 103.0
+PMC_FILE = "r05_pmc_ingest_kernels.json"
+# k_points by its SQ counters (profiles/r05_pmc_k_points.txt: SQ_INSTS_VALU / SQ_INSTS_SALU per wavefront of 512 points / 8 rounds;
+# the f64 share from the ISA: 664 of 2819 static vector instructions)
+KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 266.7, 63.0, 105.5
 N_SIMD, CLOCK_GHZ = 1024, 2.4            # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), committed PMC pass (profiles/r04_pmc_mfma_counters.txt)
-MFMA_BUSY_COMMITTED = {"k_gemm_split": "0.385-0.443", "k_attention_split": 0.25, "hipBLASLt bf16 (same shapes)": "0.43-0.47",
-                       "source": "profiles/r04_pmc_mfma_counters.txt"}
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_BF16_PEAK_TF = 2500.0
-MFMA_F32_PEAK_TF = 157.3
-STAGES = {2: "k_points", 3: "k_keys_pairs", 4: "ids+point_order", 5: "pair_sort", 0: "k_dense_reduce", 6: "bsc_ingest",
-          7: "k_chain"}
+# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), committed PMC pass (profiles/r05_pmc_mfma_counters.txt)
+MFMA_BUSY_COMMITTED = {"k_gemm_split qkv (LayerNorm in the load)": 0.435, "k_gemm_split fc1 + GELU (LayerNorm in the load)": 0.419,
+                       "k_gemm_split proj / fc2 (residual + statistics)": 0.430, "k_attention_split": 0.27, "k_cosine_f16x2 (Q = 256)": 0.378,
+                       "hipBLASLt bf16 (same shapes, round 4)": "0.43-0.47", "source": "profiles/r05_pmc_mfma_counters.txt"}
 
 
 def parse():
@@ -987,7 +984,7 @@ def main():
             "achieved": need / (kp_ms * 1e-3) / 1e12, "peak": N_SIMD * CLOCK_GHZ * 1e9 / 1e12, "unit": "T issue-cycles/s",
             "frac": need / (kp_ms * 1e-3) / (N_SIMD * CLOCK_GHZ * 1e9),
             "hbm_frac_of_own_bytes": 8.0 * pts / (kp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "source": f"profiles/{PMC_FILE} (SQ_INSTS_VALU, per wavefront of 512 points) x points of this run / HIP-event time of this run"}
+            "source": "profiles/r05_pmc_k_points.txt (SQ_INSTS_VALU / SQ_INSTS_SALU per wavefront of 512 points) x points of this run / HIP-event time of this run"}
         out["roofline"]["kernels"] = {"note": "bsc_ingest running alone (no encoder beside it, a synchronize per call); own algorithmic bytes per stage",
                                       **stage_rooflines(p, iso, tok_bytes)}
         fl = p.vit.flops_per_frame() * a.batch

@@ -17,7 +17,7 @@ rm -rf /tmp/prof_stats
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-workloads --no-localize --no-exact --no-side-precision --no-host-feed > $GRAFT_REPO_ROOT/gpurun_out/r05_bench_under_rocprof.json 2>/dev/null )
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/r05_bench_final_kernel_stats.csv
 LINES_MAX=1 bash scripts/prof_iso.sh gpurun_out/r05_ingest_isolated_kernel_stats.csv 6 sync 768 room > /dev/null
-bash scripts/pmc_one.sh k_points "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" -- python scripts/ingest_only.py 3 sync 768 room > gpurun_out/r05_pmc_k_points.txt 2>&1
+bash scripts/pmc_one.sh k_points "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" -- python $GRAFT_REPO_ROOT/scripts/ingest_only.py 3 sync 768 room > gpurun_out/r05_pmc_k_points.txt 2>&1
 rm -rf /tmp/pf32
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf32 -- python $GRAFT_REPO_ROOT/scripts/encoder_f32_only.py vit_b16 768 1 > $GRAFT_REPO_ROOT/gpurun_out/r05_encoder_f32.log 2>&1 )
 cp $(find /tmp/pf32 -name "*kernel_stats.csv" | head -1) gpurun_out/r05_encoder_f32_kernel_stats.csv
