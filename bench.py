@@ -74,6 +74,11 @@ N_SIMD, CLOCK_GHZ = 1024, 2.4            # 256 CUs x 4 SIMDs; peak engine clock 
 MFMA_BUSY_COMMITTED = {"k_gemm_split qkv (LayerNorm in the load)": 0.435, "k_gemm_split fc1 + GELU (LayerNorm in the load)": 0.419,
                        "k_gemm_split proj / fc2 (residual + statistics)": 0.430, "k_attention_split": 0.27, "k_cosine_f16x2 (Q = 256)": 0.378,
                        "hipBLASLt bf16 (same shapes, round 4)": "0.43-0.47", "source": "profiles/r05_pmc_mfma_counters.txt"}
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_F32_PEAK_TF = 157.3
+STAGES = {2: "k_points", 3: "k_keys_pairs", 4: "ids+point_order", 5: "pair_sort", 0: "k_dense_reduce", 6: "bsc_ingest",
+          7: "k_chain"}
 
 
 def parse():
