@@ -57,10 +57,14 @@ class VoxelTokenMemory:
         if self.n_patch_w != self.n_patch_h:
             raise ValueError("square patch grids only (the reference reshapes to (n_patch_w, n_patch_h))")
         if fuse_encoder and preload_dino is not None and not hasattr(preload_dino, "patch_tokens"):
-            # opt-in: the hub DINOv2 module's weights run through this library's fused bf16 encoder (encoder.RandomViT:
-            # same architecture, LayerScale folded, ~15x the frames/s of the f32 module); numerics are bf16, not f32
+            # opt-in: the hub DINOv2 module's weights run through this library's own encoder (encoder.RandomViT: same architecture,
+            # LayerScale folded).  fuse_encoder="f32": the reference's precision — f32 weights / activations / tokens, every dense
+            # layer and attention on the fp16 matrix cores with split operands (tokens within 1e-5 of the PyTorch f32 module,
+            # ~2.4x its speed); fuse_encoder=True / "bf16": bf16 weights and activations, library GEMMs — ~2.8x faster again,
+            # NOT at the reference's precision
             from .encoder import RandomViT
-            self.dinov2 = RandomViT.from_dinov2_state_dict(preload_dino.state_dict(), image_size=c.query_height).to(f"cuda:{gpu}")
+            dt = torch.float32 if str(fuse_encoder).lower() in ("f32", "fp32", "float32") else torch.bfloat16
+            self.dinov2 = RandomViT.from_dinov2_state_dict(preload_dino.state_dict(), image_size=c.query_height, dtype=dt).to(f"cuda:{gpu}")
         self.chain = PoseChain(c.base_forward_axis, c.base_left_axis, c.base_up_axis, c.base2cam_rot, c.sensor_height)
         self.base_transform = self.chain.base_transform
         self.base2cam_tf = self.chain.base2cam_tf

@@ -427,6 +427,38 @@ def test_dinov2_state_dict_runs_through_the_fused_encoder(shape):
     assert e.mean().item() < 1.15 * e_plain.mean().item() + 1e-3 and e.max().item() < 0.5, (e.mean().item(), e.max().item())
 
 
+def test_dinov2_state_dict_at_the_reference_precision():
+    """the same checkpoint through the f32 encoder (dtype=torch.float32: split-operand GEMMs, LayerNorm folded into them,
+    LayerScale in the weights): equals the architecture restated in f32 up to the GELU form (tanh in the epilogue, erf in DINOv2:
+    |difference| < 5e-4 per activation) — two orders of magnitude closer than the bf16 mode; VoxelTokenMemory(fuse_encoder="f32")
+    selects it"""
+    import torch
+    import bsc_nav_amd as B
+    from bsc_nav_amd import encoder
+    shape = dict(width=1024, depth=24, heads=16, mlp=4096, regs=4)
+    sd = _dinov2_state_dict(shape["width"], shape["depth"], shape["heads"], shape["mlp"], shape["regs"], seed=3)
+    vit = encoder.RandomViT.from_dinov2_state_dict(sd, image_size=224, dtype=torch.float32).cuda()
+    assert vit.split_gemm and vit.arch == "vit_l14"
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    ref = _dinov2_forward_f32(sd, x, shape["heads"], shape["regs"], antialias=True, offset=0.0)
+    out = vit.forward_features(x)["x_norm_patchtokens"]
+    e = (out - ref).abs()
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    assert e.mean().item() < 5e-4 and e.max().item() < 2e-2, (e.mean().item(), e.max().item())
+
+    class HubModule:
+        def state_dict(self):
+            return sd
+
+    args = B.MemoryArgs(width=160, height=120, grid_size=128, cell_size=0.1, floor_height=-6.4, map_height=6.4, depth_sample_rate=1,
+                        query_width=224, query_height=224, memory_path="/tmp", scene_name="fuse32", token_dim=1024, patch_size=14)
+    mem = B.VoxelTokenMemory(args, preload_dino=HubModule(), need_diffusion=False, feature_mode="mean", fuse_encoder="f32",
+                             max_frames_per_call=2, voxel_capacity=100_000)
+    assert isinstance(mem.dinov2, encoder.RandomViT) and mem.dinov2.compute_dtype == torch.float32 and mem.dinov2.split_gemm
+    mem.engine.close()
+
+
 def test_graphed_encoder_equals_eager_and_does_not_keep_old_frames():
     """encoder.GraphedEncoder (what bench.py times): the captured graph starts at the patch matrix, the preprocessing kernel
     runs eagerly on the caller's frames — replaying it on new frames must give the eager result for THOSE frames (bf16 and f32
@@ -443,6 +475,15 @@ def test_graphed_encoder_equals_eager_and_does_not_keep_old_frames():
             ref = vit.patch_tokens(frames.contiguous(), keep)
             assert out.dtype == ref.dtype and out.shape == ref.shape == (3, 14, 14, 768)
             assert torch.equal(out, ref)
+    # the f32 encoder (what bench.py's headline runs): graph from the padded piece matrix, patch 16 and patch 14
+    for arch in ("vit_b16", "vit_s14_reg"):
+        v32 = encoder.RandomViT(arch, image_size=224, seed=4, dtype=torch.float32).cuda()
+        enc = encoder.GraphedEncoder(v32, 3, 120, 160, 4, False)
+        assert enc.f32 and enc.from_patches
+        for frames in (a, b[3:], b[::2]):
+            out = enc(frames).clone()
+            ref = v32.patch_tokens(frames.contiguous())
+            assert out.dtype == torch.float32 and out.shape == ref.shape and torch.equal(out, ref)
 
 
 def test_fuse_encoder_option_takes_a_dinov2_module():
