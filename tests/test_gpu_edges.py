@@ -493,6 +493,17 @@ def test_cold_start_every_voxel_new_and_capacity_boundary():
     small = B.VoxelEngine(H, W, gs, 0.2, -6.4, 6.4, g, D, mode="mean", voxel_capacity=n - 1, max_points=F * H * W)
     with pytest.raises(B._lib.BscError, match="capacity"):
         small.ingest(d, c, t, Ts)
+    # the refused call leaves the handle in its error state (bsc_counters keeps reporting the capacity flag) until bsc_reset; the
+    # ids of the clipped new voxels were still assigned (no cell is left with a provisional claim), so a reset handle is as new
+    with pytest.raises(B._lib.BscError, match="capacity"):
+        small.counters()
+    small.reset()
+    assert small.counters()["max_id"] == 0
+    om1 = orc.OracleMemory(orc.make_config(H, W, gs, 0.2, -6.4, 6.4, g, D, mode=1), voxel_capacity=300_000)
+    om1.ingest_frame(depth[0], rgb[0], None, Ts[0], tokens[0])
+    assert om1.counters()["max_id"] < n - 1
+    small.ingest(d[:1], c[:1], t[:1], Ts[:1])
+    assert np.array_equal(small.export_rgb()[0], om1.export_rgb()[0]) and np.array_equal(small.export_dense()[1], om1.export_dense()[1])
     small.close()
 
 
