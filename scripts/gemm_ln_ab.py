@@ -43,8 +43,4 @@ for name, K, sc in (("proj", 768, 16.0), ("fc2", 3072, 4.0)):
     t1 = timeit(lambda: a(ap, 2, resid=u, out=u, a_scale=sc, a_pieces=True, ln_stats=stats, ln_mu=mu))
     t2 = timeit(lambda: a(af, 2, resid=u, out=u, a_scale=sc, ln_stats=stats, ln_mu=mu))
     print(f"{name}: residual epilogue {t0:7.1f} us | + row statistics {t1:7.1f} | the same from f32 rows {t2:7.1f}")
-lin = torch.nn.Linear(Wd, 3072).cuda().float()
-b = SL(lin, ln)
-o32 = torch.empty(M, 3072, device="cuda")
-print(f"fc1 LayerNorm in the load, f32 output: {timeit(lambda: b(u, 1, a_ln=True, ln_stats=stats, ln_mu=mu, out=o32)):7.1f} us")
 print(f"layernorm pass: {timeit(lambda: encoder.layernorm_split(u, ln)):7.1f} us")

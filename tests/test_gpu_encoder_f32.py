@@ -183,6 +183,14 @@ def test_residual_epilogue_leaves_the_rows_statistics(Wd, K, M):
     u64 = u.double()
     assert (mean - u64.mean(1)).abs().max().item() < 1e-5
     assert ((var - u64.var(1, unbiased=False)).abs() / u64.var(1, unbiased=False)).max().item() < 2e-6
+    # the same epilogue behind f32 operand rows (split in registers)
+    plain32, u32 = u0.clone(), u0.clone()
+    sl(a, 2, resid=plain32, out=plain32)
+    st2 = torch.zeros((M, encoder.LN_REC), device="cuda")
+    sl(a, 2, resid=u32, out=u32, ln_stats=st2, ln_mu=mu)
+    assert torch.equal(u32, plain32)
+    sa2, sb2 = st2[:, 2::2].double().sum(1), st2[:, 3::2].double().sum(1)
+    assert ((st2[:, 0].double() + sa2 / Wd) - u32.double().mean(1)).abs().max().item() < 1e-5
 
 
 def test_embed_and_final_layernorm_f32():
