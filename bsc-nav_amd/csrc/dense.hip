@@ -1049,12 +1049,15 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
                 return BSC_OK;
             }
         }
-        // BSC_REDUCE_PASS_BYTES=<n>: passes over slices of the call's frames, each slice's token rows at most n bytes (so that they
-        // stay in the 256 MB MALL while the pairs gather them).  OFF by default — measured (round 5, 768 frames of 14 x 14 x 768
-        // f32 rows = 462 MB): one pass 1.73 ms, two of 231 MB 1.67, four of 115 MB 2.05, eight 2.31: the kernel is bound by the
-        // L2 -> CU rate of its row gathers (17 GB per call at ~10 TB/s) and by its longest voxel, not by where the rows come from;
-        // every pass visits every voxel again.  Kept with its parity test (tests/test_gpu_edges.py).
-        const int64_t pass_b = getenv("BSC_REDUCE_PASS_BYTES") ? atoll(getenv("BSC_REDUCE_PASS_BYTES")) : 0;   // read per call; 0 (default): one pass
+        // A call whose token tile is larger than the 256 MB MALL is reduced in passes over slices of its frames, each slice's token
+        // rows at most BSC_REDUCE_PASS_BYTES (default 256 MB; 0: always one pass): 768 frames of 14 x 14 x 768 f32 rows are 462 MB ->
+        // two passes.  Measured (round 5, one box, alternating runs): the kernel itself 1.73 -> 1.67 ms (it is bound by the L2 -> CU rate
+        // of its row gathers, 17 GB per call, not by where the rows come from), but the isolated call + sync 6.09-6.17 -> 5.83-5.85 ms
+        // and the call inside the pipeline 5.59 -> 5.51: the call as a whole is bound by its HBM traffic (profiles/README.md) and
+        // the rows of a slice are gathered from the MALL instead of from HBM.  Smaller slices lose: every pass visits every voxel
+        // again (160 MB: kernel 1.86 ms; 115 MB: 2.05; 58 MB: 2.31).  A voxel's sum is then formed slice by slice (f32 order differs
+        // from the one-pass sum in the last bits; max is exact): tests/test_gpu_edges.py.
+        const int64_t pass_b = getenv("BSC_REDUCE_PASS_BYTES") ? atoll(getenv("BSC_REDUCE_PASS_BYTES")) : ((int64_t)256 << 20);   // read per call
         const int64_t tile_b = (int64_t)n_frames * x->g2 * D * (token_dtype == BSC_TOK_BF16 ? 2 : 4);
         int n_pass = pass_b > 0 ? (int)((tile_b + pass_b - 1) / pass_b) : 1;
         n_pass = n_pass < 1 ? 1 : (n_pass > 8 ? 8 : n_pass);
