@@ -493,6 +493,41 @@ def encoder_kernel_rates(vit, batch, reps=3):
     return out
 
 
+def small_batch_leg(archs=("vit_b16", "vit_l14"), batches=(1, 8)):
+    """The reference's ONLINE use of the encoder: one DINOv2 forward per simulator step (memory_2.py:732-742, a frame per call).
+    Latency of the f32 forward at 1 and 8 frames per call: the in-tree kernels (few-rows tiles of the split GEMM: 32 x 128 / 128 x
+    128 with split-K, LayerNorm as a pass) eager and HIP-graphed, against PyTorch-ROCm's f32 GEMMs + SDPA on the same module."""
+    from bsc_nav_amd import encoder
+    out = {}
+    for arch in archs:
+        vit = encoder.RandomViT(arch, image_size=224, seed=0, dtype=torch.float32).cuda()
+        for B in batches:
+            rgb = torch.randint(0, 255, (B, 480, 640, 4), dtype=torch.uint8, device="cuda")
+
+            def timed(fn, n=20):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            e = {"in_tree_eager_ms": timed(lambda: vit.patch_tokens(rgb))}
+            g = encoder.GraphedEncoder(vit, B, 480, 640, 4, False)
+            e["in_tree_graph_ms"] = timed(lambda: g(rgb))
+            vit.split_gemm = False
+            try:
+                e["pytorch_f32_gemms_ms"] = timed(lambda: vit.patch_tokens(rgb), 10)
+            finally:
+                vit.split_gemm = True
+            out[f"{arch}_B{B}"] = e
+            del g
+        del vit
+        torch.cuda.empty_cache()
+    return out
+
+
 def exact_mode_leg(a, local_rank, frames=192):
     """The reference-semantics mode (the only one whose every output is pinned to the reference's goldens): token cache of
     50 000 rows flushed into <= 10 raw tokens per voxel with random.choice replacement, host-shuffled sub-sampling on NumPy's
@@ -1127,6 +1162,7 @@ def main():
         torch.cuda.empty_cache()
         if not a.no_exact:
             guarded("exact_mode", lambda: exact_mode_leg(a, local_rank))
+            guarded("encoder_f32_frame_by_frame", small_batch_leg)
         if not a.no_localize:
             # second half of the metric: localize top-K latency over a 2^20-voxel map (BASELINE configs[3]/[4] size)
             guarded("localize", lambda: localize_leg(B, a, local_rank, D))

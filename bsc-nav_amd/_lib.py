@@ -79,6 +79,8 @@ SIGNATURES = {
     "bsc_enc_gemm_split": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP]),
     "bsc_enc_gemm_split_ln": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP, _VP,
                                      C.c_float, _VP]),
+    "bsc_enc_gemm_split_ws": (_I32, [_VP, _I64, _I32, _VP, _I32, _VP, _VP, _VP, C.c_float, C.c_float, _I32, _I32, C.c_float, _VP, _VP,
+                                     C.c_float, _VP, _I64, _VP]),
     "bsc_enc_embed_layernorm_f32": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP, _VP, _VP, _VP, _VP]),
     "bsc_enc_final_layernorm_f32": (_I32, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, C.c_float, _VP, _VP]),
     "bsc_enc_layernorm_split": (_I32, [_VP, _VP, _VP, _I64, _I32, C.c_float, C.c_float, _VP, _VP]),

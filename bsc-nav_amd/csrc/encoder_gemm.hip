@@ -300,8 +300,11 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
                                                 const float *R, void *Cv,
                                                 float a_scale, float out_scale, float c_scale, int64_t tm, int n0, bool primed,
                                                 bool has_next, int64_t next_tm, int next_n0, int &par, typename gs_xf<MR>::type &xf,
-                                                typename gs_xf<MR>::type &xg, int prof_idx, float *ln_stats, float *ln_mu, float ln_eps)
+                                                typename gs_xf<MR>::type &xg, int prof_idx, float *ln_stats, float *ln_mu, float ln_eps,
+                                                int k_full)
 {
+    // k_full: the operands' row length (A rows, weight rows); K: the stretch of it this launch contracts (split-K slices of the
+    // few-rows path: the kernel wrapper has moved the operand pointers to the slice's first column; otherwise K == k_full)
     constexpr bool APIECES = AMODE == GS_A_PIECES;
     constexpr int WROWS = WC * NT * 32;                                       // Ws: [2][2][WROWS][GS_PITCH]
     constexpr int TROWS = WR * MR * 32;
@@ -327,7 +330,7 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
         const int64_t row = first_row + mr * 32 + i;
         const int64_t rc = row < M ? row : M - 1;                           // clamped: padded rows are not stored
         // lane group g contracts k = 16 g + 8 sstep + (0..7) of the chunk in sub-step sstep — the same split of the 32 on both operands
-        return APIECES ? (const char *)((const uint16_t *)Av + rc * 2 * K + g * 16) : (const char *)((const float *)Av + rc * K + g * 16);
+        return APIECES ? (const char *)((const uint16_t *)Av + rc * 2 * k_full + g * 16) : (const char *)((const float *)Av + rc * k_full + g * 16);
     };
     const char *arow[MR];
 #pragma unroll
@@ -380,31 +383,38 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
     // (buffer loads: a 32-bit per-thread offset + a scalar offset.  With 64-bit pointers the compiler kept one loop-invariant
     // pointer per j in registers — and, in the persistent form of this kernel, in scratch.)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, (int)(4 * w_plane), 0x00020000);
-    const int wthr = ((tid >> 2) * K + (tid & 3) * 8) * 2;
+    const int wthr = ((tid >> 2) * k_full + (tid & 3) * 8) * 2;
     const int lthr = (tid >> 2) * GS_PITCH + (tid & 3) * 8;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto load_w = [&](int nbase, int c) {
+    auto load_w = [&](qr_t &q, int nbase, int c) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int uni = (int)(((int64_t)(j / PPP) * w_plane + (int64_t)(nbase + (j % PPP) * PR) * K + c * GS_KC) * 2);
+            const int uni = (int)(((int64_t)(j / PPP) * w_plane + (int64_t)(nbase + (j % PPP) * PR) * k_full + c * GS_KC) * 2);
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wthr, uni, 0);
-            qr[4 * j] = v[0]; qr[4 * j + 1] = v[1]; qr[4 * j + 2] = v[2]; qr[4 * j + 3] = v[3];
+            q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](qr_t &q, int buf) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j)
-            *(uint4 *)&Ws[buf * BUF + lthr + ((j / PPP) * WROWS + (j % PPP) * PR) * GS_PITCH] = make_uint4(qr[4 * j], qr[4 * j + 1], qr[4 * j + 2], qr[4 * j + 3]);
+            *(uint4 *)&Ws[buf * BUF + lthr + ((j / PPP) * WROWS + (j % PPP) * PR) * GS_PITCH] = make_uint4(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3]);
     };
+    // DEEP (the 32-row few-rows tile): a chunk is only 6 MFMAs per wavefront — nothing to hide a weight chunk's round trip behind —,
+    // so the weight chunks travel TWO iterations ahead in two register sets that alternate (chunk c + 2 is requested in iteration
+    // c, chunk c + 1 — requested an iteration earlier — is stored to LDS at its end): the loop turns on LDS + barrier time instead of
+    // one L2 round trip per chunk.  Such tiles do not chain (every tile has its prologue).
+    constexpr bool DEEP = MR == 1 && NT == 1 && WR == 1;
+    qr_t qr2;
     if (!primed) {
         load_a(xf, arow, 0);
-        load_w(n0, 0);
+        load_w(qr, n0, 0);
         if (nchunks > 1) load_a(xg, arow, 1);
-        store_w(par);
+        if (DEEP && nchunks > 1) load_w(qr2, n0, 1);
+        store_w(qr, par);
         __syncthreads();
     }
     GS_T(2);
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk_body = [&](const int c, qr_t &q_load, qr_t &q_store) __attribute__((always_inline)) {
         const int buf = (c + par) & 1;
         // this chunk's rows as fp16 pieces (two sub-steps of 8 halfs), then the next chunk's loads go in flight
         uint32_t ah[MR][2][4], al[MR][2][4];
@@ -440,13 +450,18 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
         // ONE load site per operand: the last two chunks request the next tile's first two (a second load site under its own
         // branch made the compiler merge the two results with register copies — and wait for the loads right there)
         const bool a_next = c + 2 >= nchunks, w_next = c + 1 >= nchunks;
-        if (!a_next || has_next) {
+        if (DEEP) {
+            // unconditional requests (the last two iterations repeat the last chunk): behind a branch the compiler cannot count on the
+            // younger loads being in flight and makes the LDS stores below wait for everything
+            load_a(xg, arow, a_next ? nchunks - 1 : c + 2);
+        } else if (!a_next || has_next) {
             const char *ap[MR];
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) ap[mr] = a_next ? row_base(next_tm * TROWS + wr * (MR * 32), mr) : arow[mr];
             load_a(xg, ap, a_next ? c + 2 - nchunks : c + 2);
         }
-        if (!w_next || has_next) load_w(w_next ? next_n0 : n0, w_next ? 0 : c + 1);
+        if (DEEP) load_w(q_load, n0, a_next ? nchunks - 1 : c + 2);
+        else if (!w_next || has_next) load_w(q_load, w_next ? next_n0 : n0, w_next ? 0 : c + 1);
         const uint16_t *wb = &Ws[buf * BUF + (wc * NT * 32 + i) * GS_PITCH + g * 16];
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
@@ -472,8 +487,21 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
                 for (int t = 0; t < NT; ++t)
                     acc[mr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t], *(const half8_t *)ah[mr][sstep], acc[mr][t], 0, 0, 0);     // h h
         }
-        if (c + 1 < nchunks || has_next) store_w(buf ^ 1);
+        if (c + 1 < nchunks || (!DEEP && has_next)) store_w(q_store, buf ^ 1);
         __syncthreads();
+    };
+    if (DEEP) {
+        // (two iterations per trip, no branch between them: a conditional second half made the compiler merge the register sets with
+        //  copies at the join — and wait for the loads just issued.  An odd chunk count — the 19 chunks of a 608-column patch matrix —
+        //  runs its last chunk after the loop.)
+        const int even = nchunks & ~1;
+        for (int c = 0; c < even; c += 2) {
+            chunk_body(c, qr, qr2);
+            chunk_body(c + 1, qr2, qr);
+        }
+        if (nchunks & 1) chunk_body(nchunks - 1, qr, qr2);
+    } else {
+        for (int c = 0; c < nchunks; ++c) chunk_body(c, qr, qr);
     }
     par = (par + nchunks) & 1;
     GS_T(3);
@@ -627,9 +655,17 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
                                                              const float *__restrict__ bias, const float *R, void *Cv,
                                                              float a_scale, float out_scale, float c_scale, int n_tiles_n, int n_tiles_m,
                                                              int64_t q_full, int64_t q_virtual, int per_round, int epi_off,
-                                                             float *ln_stats, float *ln_mu, float ln_eps)
+                                                             float *ln_stats, float *ln_mu, float ln_eps, int k_full, int64_t c_slice)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t Ws[];
+    // split-K (few rows): slice blockIdx.y contracts columns [y K, y K + K) of the k_full-long operand rows into its own f32 partial
+    // result (c_slice elements apart); k_splitk_finish adds the partials in slice order and applies the epilogue
+    if (blockIdx.y) {
+        const int64_t k0 = (int64_t)blockIdx.y * K;
+        Av = AMODE == GS_A_PIECES ? (const void *)((const uint16_t *)Av + (k0 >> 5) * 64) : (const void *)((const float *)Av + k0);
+        Wp += k0;
+        Cv = (void *)((float *)Cv + (int64_t)blockIdx.y * c_slice);
+    }
     constexpr bool HALF_OK = NT % 2 == 0 && (WC * (NT / 2) * 32) % (16 * WR * WC) == 0;       // the half tile's weight staging plan exists
     constexpr int NH = HALF_OK ? NT / 2 : NT;
     const int xcd = (int)(blockIdx.x & 7);
@@ -654,16 +690,16 @@ __global__ __launch_bounds__(64 * WR * WC) void k_gemm_split(const void *__restr
     for (int64_t qv = blockIdx.x >> 3; qv < q_virtual; qv += per_round) {
         const Tile cur = decode(qv), nxt = decode(qv + per_round);
         if (!cur.valid) { primed = false; continue; }
-        const bool has_next = nxt.valid && nxt.half == cur.half;
+        const bool has_next = nxt.valid && nxt.half == cur.half && !(MR == 1 && NT == 1 && WR == 1);      // (the few-rows tile does not chain)
         const int prof_idx = (int)(qv * 8 + xcd);
         if (!cur.half)
             gemm_split_tile<MR, NT, WR, WC, EPI, AMODE, CPIECES, STATS>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
                                                                         out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0,
-                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps);
+                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps, k_full);
         else
             gemm_split_tile<MR, NH, WR, WC, EPI, AMODE, CPIECES, STATS>(Ws, epi_lds, bias_lds, Av, M, K, Wp, w_plane, N, R, Cv, a_scale,
                                                                         out_scale, c_scale, cur.tm, cur.n0, primed, has_next, nxt.tm, nxt.n0,
-                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps);
+                                                                        par, xf, xg, prof_idx, ln_stats, ln_mu, ln_eps, k_full);
         primed = has_next && K / GS_KC >= 2;
     }
 }
@@ -893,6 +929,33 @@ __global__ __launch_bounds__(64 * NW) void k_attention_split(const uint16_t *__r
     }
 }
 
+// The epilogue of a split-K GEMM (few rows): out = epilogue(sum over the S partial results, in slice order, + bias) — the same
+// three epilogues and two output forms as k_gemm_split; four consecutive columns per thread (N % 4 == 0).
+template <int EPI, bool CPIECES>
+__global__ __launch_bounds__(GS_TPB) void k_splitk_finish(const float *__restrict__ part, int S, int64_t c_slice, int64_t M, int N,
+                                                          const float *__restrict__ bias, const float *R, void *Cv, float c_scale)
+{
+    const int64_t e = ((int64_t)blockIdx.x * GS_TPB + threadIdx.x) * 4;
+    if (e >= M * N) return;
+    const int64_t m = e / N;
+    const int n = (int)(e - m * N);
+    f32x4_t v = *(const f32x4_t *)(part + e);
+    for (int sl = 1; sl < S; ++sl) v += *(const f32x4_t *)(part + sl * c_slice + e);
+    if (bias) v += *(const f32x4_t *)(bias + n);
+    if (EPI == GS_EPI_GELU) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
+    if (EPI == GS_EPI_RESID) v += *(const f32x4_t *)(R + e);
+    if (CPIECES) {
+        uint32_t h0, l0, h1, l1;
+        split2(v[0] * c_scale, v[1] * c_scale, h0, l0);
+        split2(v[2] * c_scale, v[3] * c_scale, h1, l1);
+        uint16_t *o = (uint16_t *)Cv + p32_off(m, N, n);
+        *(uint2 *)o = make_uint2(h0, h1);
+        *(uint2 *)(o + 32) = make_uint2(l0, l1);
+    } else {
+        *(f32x4_t *)((float *)Cv + e) = v;
+    }
+}
+
 // current device ordinal and its CU count (cached per ordinal; kernel attributes and the persistent grids are per device)
 static bsc_status gs_device(int *dev, int *n_cu)
 {
@@ -949,16 +1012,17 @@ extern "C" bsc_status bsc_enc_split_weights(const float *w_dev, int32_t N, int32
     return BSC_OK;
 }
 
-extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
+extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
                                             const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
                                             int32_t epilogue, int32_t a_mode, float c_pieces_scale, float *ln_stats_dev,
-                                            float *ln_mu_dev, float ln_eps, void *hip_stream)
+                                            float *ln_mu_dev, float ln_eps, void *ws_dev, int64_t ws_bytes, void *hip_stream)
 {
     if (!a_dev || !pieces_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || (K % GS_KC) || epilogue < 0 || epilogue > 2 ||
         a_mode < 0 || a_mode > 2 || (epilogue == GS_EPI_RESID && !resid_dev) || (c_pieces_scale != 0.f && (N % 32))) {
         bsc_set_error("bsc_enc_gemm_split: invalid argument (K must be a multiple of 32; piece output needs N %% 32 == 0)");
         return BSC_E_INVALID;
     }
+    if (epilogue == GS_EPI_RESID && c_pieces_scale != 0.f) { bsc_set_error("bsc_enc_gemm_split: the residual epilogue writes f32"); return BSC_E_INVALID; }
     const bool ln = a_mode == GS_A_LN, stats = epilogue == GS_EPI_RESID && ln_stats_dev != nullptr;
     if ((ln || stats) && (!ln_stats_dev || !ln_mu_dev)) {
         bsc_set_error("bsc_enc_gemm_split_ln: the LayerNorm modes need both ln_stats_dev and ln_mu_dev");
@@ -976,8 +1040,20 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     // tile shape: 256 x 256 (8 wavefronts x 32 rows x 256 columns), or — for the narrow outputs (N <= 1024: 888 tiles of 256 x 256 on
     // 256 CUs is 3.47 rounds, 13 % of the last one idle) — a smaller tile that balances better; BSC_GEMM_TILE = 1 / 3 / 4 forces one
     static const int tile_env = getenv("BSC_GEMM_TILE") ? atoi(getenv("BSC_GEMM_TILE")) : 0;
-    const int tile = (ln || stats) ? 1 : tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
-    const int TROWS = tile == 3 ? 128 : 256, TCOLS = tile == 1 ? 256 : 128, NTHR = tile == 3 ? 256 : 512;
+    // Few rows (a frame or a handful per call: M = 197 .. ~3 500): 256-row tiles leave N / 256 = 3 .. 12 workgroups on 256 CUs and a
+    // forward of ONE frame took 6 ms (3x PyTorch's f32 GEMMs).  Tile 6 = 32 rows x 128 columns, four wavefronts side by side on the
+    // columns (each 32 x 32): 60 KB of LDS, two or three workgroups per CU cover each other's chunk latency (a 32-row tile has 6
+    // MFMAs per chunk to hide a weight chunk's round trip behind).  While even those tiles do not fill the chip, K is split over
+    // grid.y: every slice writes an f32 partial result, k_splitk_finish adds them in slice order (deterministic) and applies the
+    // epilogue.  Per flop the small tile moves 8x the weight bytes through LDS, so it is taken only while the big tiles would not fill
+    // half the chip.  (LayerNorm-in-the-load and the statistics epilogue exist for the big tile only: callers with few rows use the
+    // LayerNorm pass.)
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool few_rows = !(ln || stats) && !tile_env && big_tiles * 2 <= 256 && M <= 4096;
+    // (32-row tiles re-read the weights once per 32 rows: from ~500 rows on the launch is bound by that L2 traffic — 4.6 TB/s at
+    //  1 576 rows — and 128 x 128 tiles, 4 wavefronts x 32 rows x 128 columns, take over, with the same split-K)
+    const int tile = (ln || stats) ? 1 : few_rows ? (M <= 512 ? 6 : 3) : tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
+    const int TROWS = tile == 6 ? 32 : tile == 3 ? 128 : 256, TCOLS = tile == 1 ? 256 : 128, NTHR = (tile == 3 || tile == 6) ? 256 : 512;
     const int64_t n_pad = ((int64_t)N + 255) / 256 * 256;
     const int n_tiles_n = (int)(n_pad / TCOLS);
     const int64_t n_tiles_m = (M + TROWS - 1) / TROWS;
@@ -986,7 +1062,8 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     static const int tail_env = getenv("BSC_GEMM_TAIL") ? atoi(getenv("BSC_GEMM_TAIL")) : 1;
     int dev = 0, n_cu = 0;
     BSC_TRY(gs_device(&dev, &n_cu));
-    const int64_t q_all = groups * n_tiles_n, per_round = n_cu / 8 > 0 ? n_cu / 8 : 1;
+    // persistent workgroups: one per CU; the 60 KB few-rows tile two per CU
+    const int64_t q_all = groups * n_tiles_n, per_round = ((tile == 6 || tile == 3) ? 2 : 1) * (n_cu / 8 > 0 ? n_cu / 8 : 1);
     const int64_t q_rem = q_all % per_round;
     const int64_t q_full = (tile == 1 && tail_env && q_rem > 0 && 2 * q_rem <= per_round && q_all > per_round) ? q_all - q_rem : q_all;
     const int64_t q_virtual = q_full + 2 * (q_all - q_full);
@@ -996,7 +1073,30 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     const size_t lds = lds_loop + lds_epi + (size_t)n_pad * sizeof(float);        // + the bias row
     if (lds > 160 * 1024) { bsc_set_error("bsc_enc_gemm_split: N = %d does not fit the kernel's LDS plan (bias row)", N); return BSC_E_INVALID; }
     hipStream_t s = (hipStream_t)hip_stream;
-    const bool ap = a_mode == GS_A_PIECES, cp = c_pieces_scale != 0.f;
+    const bool ap = a_mode == GS_A_PIECES;
+    // split-K of the few-rows tile: the largest slice count that keeps the launch within two workgroups per CU, slices of whole
+    // chunks, at least two chunks each
+    int S = 1;
+    if (few_rows && (N % 4) == 0 && !getenv("BSC_GEMM_NO_SPLITK")) {
+        static const int cand[] = {24, 16, 12, 8, 6, 4, 3, 2};
+        for (int c : cand)
+            if (K % (GS_KC * c) == 0 && K / c >= 2 * GS_KC && n_tiles_m * n_tiles_n * c <= 2 * (int64_t)n_cu) { S = c; break; }
+    }
+    // f32 partial results live in the caller's workspace (stream-ordered, capture-safe: the library allocates nothing here); a
+    // workspace that is absent or too small means fewer slices
+    while (S > 1 && (!ws_dev || (int64_t)S * M * N * (int64_t)sizeof(float) > ws_bytes)) {
+        int nxt_s = 1;
+        static const int cand2[] = {16, 12, 8, 6, 4, 3, 2};
+        for (int c : cand2) if (c < S && K % (GS_KC * c) == 0 && K / c >= 2 * GS_KC) { nxt_s = c; break; }
+        S = nxt_s;
+    }
+    float *part = S > 1 ? (float *)ws_dev : nullptr;
+    const int k_len = K / S;
+    const float *bias_l = S > 1 ? nullptr : bias_dev, *resid_l = S > 1 ? nullptr : resid_dev;
+    void *c_l = S > 1 ? (void *)part : c_dev;
+    const float cps_l = S > 1 ? 0.f : c_pieces_scale;
+    const int epilogue_l = S > 1 ? (int)GS_EPI_BIAS : epilogue;
+    const bool cp = cps_l != 0.f;
 #define BSC_GEMM_LAUNCH2(MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV)                                                                    \
     do {                                                                                                                             \
         static uint64_t attr_set = 0;       /* bit per device ordinal */                                                              \
@@ -1005,14 +1105,15 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                      \
             attr_set |= 1ull << (dev & 63);                                                                                          \
         }                                                                                                                            \
-        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV>), dim3((unsigned)n_wg), dim3(NTHR), lds, s, a_dev, \
-                           M, K, (const uint16_t *)pieces_dev, n_pad * K, N, bias_dev, resid_dev, c_dev, a_scale, out_scale,         \
-                           c_pieces_scale, n_tiles_n, (int)n_tiles_m, q_full, q_virtual, (int)per_round, (int)lds_loop, ln_stats_dev, \
-                           ln_mu_dev, ln_eps);                                                                                       \
+        hipLaunchKernelGGL((k_gemm_split<MRV, NTV, WRV, WCV, EPIV, AMV, CPV, STV>), dim3((unsigned)n_wg, (unsigned)S), dim3(NTHR),   \
+                           lds, s, a_dev, M, k_len, (const uint16_t *)pieces_dev, n_pad * K, N, bias_l, resid_l, c_l, a_scale,       \
+                           out_scale, cps_l, n_tiles_n, (int)n_tiles_m, q_full, q_virtual, (int)per_round, (int)lds_loop,             \
+                           ln_stats_dev, ln_mu_dev, ln_eps, K, (int64_t)M * N);                                                       \
     } while (0)
 #define BSC_GEMM_LAUNCH(EPIV, AMV, CPV)                                                                                              \
     do {                                                                                                                             \
-        if (tile == 3) BSC_GEMM_LAUNCH2(1, 4, 4, 1, EPIV, AMV, CPV, false);                                                          \
+        if (tile == 6) BSC_GEMM_LAUNCH2(1, 1, 1, 4, EPIV, AMV, CPV, false);                                                          \
+        else if (tile == 3) BSC_GEMM_LAUNCH2(1, 4, 4, 1, EPIV, AMV, CPV, false);                                                     \
         else if (tile == 4) BSC_GEMM_LAUNCH2(1, 4, 8, 1, EPIV, AMV, CPV, false);                                                     \
         else BSC_GEMM_LAUNCH2(1, 8, 8, 1, EPIV, AMV, CPV, false);                                                                    \
     } while (0)
@@ -1022,12 +1123,12 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     } else if (stats) {                 // residual epilogue that leaves the row statistics for the next LayerNorm
         if (ap) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_RESID, GS_A_PIECES, false, true);
         else BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_RESID, GS_A_F32, false, true);
-    } else if (epilogue == GS_EPI_GELU) {
+    } else if (epilogue_l == GS_EPI_GELU) {
         if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_PIECES, true);
         else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_PIECES, false);
         else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, true);
         else BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, false);
-    } else if (epilogue == GS_EPI_RESID) {
+    } else if (epilogue_l == GS_EPI_RESID) {
         if (cp) { bsc_set_error("bsc_enc_gemm_split: the residual epilogue writes f32"); return BSC_E_INVALID; }
         if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, GS_A_PIECES, false);
         else BSC_GEMM_LAUNCH(GS_EPI_RESID, GS_A_F32, false);
@@ -1039,6 +1140,17 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     }
 #undef BSC_GEMM_LAUNCH
 #undef BSC_GEMM_LAUNCH2
+    if (S > 1) {
+        const dim3 fgrid((unsigned)(((int64_t)M * N / 4 + GS_TPB - 1) / GS_TPB));
+        const bool cpo = c_pieces_scale != 0.f;
+#define BSC_FIN(EPIV, CPV)                                                                                                           \
+    hipLaunchKernelGGL((k_splitk_finish<EPIV, CPV>), fgrid, dim3(GS_TPB), 0, s, (const float *)part, S, (int64_t)M * N, M, N, bias_dev, \
+                       resid_dev, c_dev, c_pieces_scale)
+        if (epilogue == GS_EPI_GELU) { if (cpo) BSC_FIN(GS_EPI_GELU, true); else BSC_FIN(GS_EPI_GELU, false); }
+        else if (epilogue == GS_EPI_RESID) BSC_FIN(GS_EPI_RESID, false);
+        else { if (cpo) BSC_FIN(GS_EPI_BIAS, true); else BSC_FIN(GS_EPI_BIAS, false); }
+#undef BSC_FIN
+    }
     BSC_HIP(hipGetLastError());
 #ifdef BSC_GEMM_PROFILE
     if (getenv("BSC_GEMM_PROFILE_DUMP")) {
@@ -1052,6 +1164,15 @@ extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_
     }
 #endif
     return BSC_OK;
+}
+
+extern "C" bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,
+                                            const float *bias_dev, const float *resid_dev, void *c_dev, float a_scale, float out_scale,
+                                            int32_t epilogue, int32_t a_mode, float c_pieces_scale, float *ln_stats_dev,
+                                            float *ln_mu_dev, float ln_eps, void *hip_stream)
+{
+    return bsc_enc_gemm_split_ws(a_dev, M, K, pieces_dev, N, bias_dev, resid_dev, c_dev, a_scale, out_scale, epilogue, a_mode,
+                                 c_pieces_scale, ln_stats_dev, ln_mu_dev, ln_eps, nullptr, 0, hip_stream);
 }
 
 extern "C" bsc_status bsc_enc_gemm_split(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N,

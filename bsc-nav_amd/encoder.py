@@ -116,17 +116,22 @@ class SplitLinear:
         if out is None:
             out = (torch.empty((M, 2 * self.N), dtype=torch.float16, device=x2d.device) if c_pieces_scale else
                    torch.empty((M, self.N), dtype=torch.float32, device=x2d.device))
-        _lib.check(_lib.load().bsc_enc_gemm_split_ln(
+        # few rows (a frame or a handful per call): workspace for the split-K partial results — from the caching allocator, so it is
+        # ordered on the stream and lives in a capturing graph's pool
+        ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=x2d.device) if (M <= 4096 and not a_ln and ln_stats is None) else None
+        _lib.check(_lib.load().bsc_enc_gemm_split_ws(
             C.c_void_p(x2d.data_ptr()), M, self.K, C.c_void_p(self.pieces.data_ptr()), self.N,
             None if self.bias is None else C.c_void_p(self.bias.data_ptr()),
             None if resid is None else C.c_void_p(resid.data_ptr()), C.c_void_p(out.data_ptr()), float(a_scale),
             1.0 / (float(a_scale) * self.scale), int(epilogue), self.A_LN if a_ln else self.A_PIECES if a_pieces else self.A_F32,
             float(c_pieces_scale), None if ln_stats is None else C.c_void_p(ln_stats.data_ptr()),
             None if ln_mu is None else C.c_void_p(ln_mu.data_ptr()), self.ln_eps,
+            None if ws is None else C.c_void_p(ws.data_ptr()), 0 if ws is None else SPLITK_WS_BYTES,
             C.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream)))
         return out
 
 
+SPLITK_WS_BYTES = 34 << 20      # split-K partial results of a few-rows GEMM: slices x tiles <= 2 x 256 CUs, 128 x 128 f32 each
 LN_REC = 20       # floats per LayerNorm statistics record of a residual-stream row (csrc/encoder_gemm.hip GS_LN_REC)
 
 
@@ -439,7 +444,9 @@ class RandomViT(nn.Module):
         own_attention = hd == 64 and T <= 288 and os.environ.get("BSC_ENC_SPLIT_ATTENTION", "1") == "1"
         # LayerNorm folded into the qkv / fc1 operand loads, its statistics from the proj / fc2 epilogues: no LayerNorm pass at all
         # (BSC_ENC_LN_FUSED=0: LayerNorm -> pieces as a pass of its own, the round-4 form)
-        ln_fused = ln_ok and own_attention and os.environ.get("BSC_ENC_LN_FUSED", "1") == "1"
+        # (a frame or a handful per call — at most 3 584 rows — takes the LayerNorm pass: the GEMM then runs on its 32-row tiles,
+        #  which fill the chip where the 256-row tiles of the fused forms would leave it to 3 .. 12 workgroups: bsc_enc_gemm_split_ln)
+        ln_fused = ln_ok and own_attention and os.environ.get("BSC_ENC_LN_FUSED", "1") == "1" and B * T > 3584
         if ln_ok:
             x2 = x.reshape(B * n_patch, Wd).contiguous()
             u, y0, st = embed_tokens_f32(self, x2, B, ln=None if ln_fused else self.blocks[0].ln1, stats=ln_fused)

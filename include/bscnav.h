@@ -303,6 +303,15 @@ bsc_status bsc_enc_gemm_split_ln(const void *a_dev, int64_t M, int32_t K, const 
                                  const float *resid_dev, void *c_dev, float a_scale, float out_scale, int32_t epilogue,
                                  int32_t a_mode, float c_pieces_scale, float *ln_stats_dev, float *ln_mu_dev, float ln_eps,
                                  void *hip_stream);
+/* The same with a workspace for the FEW-ROWS case (a frame or a handful per call, M <= ~3 500 rows — the reference's online use:
+ * one DINOv2 forward per simulator step, memory_2.py:732-742): the GEMM then runs on 32- or 128-row tiles and, while those do not
+ * fill the chip, splits K over the grid — every slice writes an f32 partial result into ws_dev, a second kernel adds the partials
+ * in slice order (deterministic) and applies the epilogue.  ws_bytes >= 34 MB is always enough; NULL / too small: fewer slices.
+ * bsc_enc_gemm_split_ln is this call without a workspace. */
+bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_t K, const void *pieces_dev, int32_t N, const float *bias_dev,
+                                 const float *resid_dev, void *c_dev, float a_scale, float out_scale, int32_t epilogue,
+                                 int32_t a_mode, float c_pieces_scale, float *ln_stats_dev, float *ln_mu_dev, float ln_eps,
+                                 void *ws_dev, int64_t ws_bytes, void *hip_stream);
 /* Token assembly of the f32 forward, one pass: row (b, 0) = cls + pos[0], rows (b, 1..registers) = the register tokens, rows
  * (b, 1 + registers + j) = patch[b][j] + pos[1 + j] -> u_dev (B T, width) f32; pieces_dev != NULL: LayerNorm(u) (gamma, beta) as
  * operand pieces; ln_stats_dev != NULL: the rows' statistics records + means (exact two-pass) for bsc_enc_gemm_split_ln.
