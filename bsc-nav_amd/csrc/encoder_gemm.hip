@@ -1046,10 +1046,10 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
     // MFMAs per chunk to hide a weight chunk's round trip behind).  While even those tiles do not fill the chip, K is split over
     // grid.y: every slice writes an f32 partial result, k_splitk_finish adds them in slice order (deterministic) and applies the
     // epilogue.  Per flop the small tile moves 8x the weight bytes through LDS, so it is taken only while the big tiles would not fill
-    // half the chip.  (LayerNorm-in-the-load and the statistics epilogue exist for the big tile only: callers with few rows use the
+    // the chip once.  (LayerNorm-in-the-load and the statistics epilogue exist for the big tile only: callers with few rows use the
     // LayerNorm pass.)
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    const bool few_rows = !(ln || stats) && !tile_env && big_tiles * 2 <= 256 && M <= 4096;
+    const bool few_rows = !(ln || stats) && !tile_env && big_tiles <= 256 && M <= 8192;
     // (32-row tiles re-read the weights once per 32 rows: from ~500 rows on the launch is bound by that L2 traffic — 4.6 TB/s at
     //  1 576 rows — and 128 x 128 tiles, 4 wavefronts x 32 rows x 128 columns, take over, with the same split-K)
     const int tile = (ln || stats) ? 1 : few_rows ? (M <= 512 ? 6 : 3) : tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);

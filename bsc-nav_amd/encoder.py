@@ -118,7 +118,7 @@ class SplitLinear:
                    torch.empty((M, self.N), dtype=torch.float32, device=x2d.device))
         # few rows (a frame or a handful per call): workspace for the split-K partial results — from the caching allocator, so it is
         # ordered on the stream and lives in a capturing graph's pool
-        ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=x2d.device) if (M <= 4096 and not a_ln and ln_stats is None) else None
+        ws = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=x2d.device) if (M <= 8192 and not a_ln and ln_stats is None) else None
         _lib.check(_lib.load().bsc_enc_gemm_split_ws(
             C.c_void_p(x2d.data_ptr()), M, self.K, C.c_void_p(self.pieces.data_ptr()), self.N,
             None if self.bias is None else C.c_void_p(self.bias.data_ptr()),
@@ -444,9 +444,9 @@ class RandomViT(nn.Module):
         own_attention = hd == 64 and T <= 288 and os.environ.get("BSC_ENC_SPLIT_ATTENTION", "1") == "1"
         # LayerNorm folded into the qkv / fc1 operand loads, its statistics from the proj / fc2 epilogues: no LayerNorm pass at all
         # (BSC_ENC_LN_FUSED=0: LayerNorm -> pieces as a pass of its own, the round-4 form)
-        # (a frame or a handful per call — at most 3 584 rows — takes the LayerNorm pass: the GEMM then runs on its 32-row tiles,
+        # (a frame or a handful per call — at most 6 144 rows — takes the LayerNorm pass: the GEMM then runs on its 32-row tiles,
         #  which fill the chip where the 256-row tiles of the fused forms would leave it to 3 .. 12 workgroups: bsc_enc_gemm_split_ln)
-        ln_fused = ln_ok and own_attention and os.environ.get("BSC_ENC_LN_FUSED", "1") == "1" and B * T > 3584
+        ln_fused = ln_ok and own_attention and os.environ.get("BSC_ENC_LN_FUSED", "1") == "1" and B * T > 6144
         if ln_ok:
             x2 = x.reshape(B * n_patch, Wd).contiguous()
             u, y0, st = embed_tokens_f32(self, x2, B, ln=None if ln_fused else self.blocks[0].ln1, stats=ln_fused)

@@ -4,7 +4,7 @@ from bsc_nav_amd import encoder as E
 torch.cuda.set_stream(torch.cuda.Stream())
 for arch in ("vit_b16", "vit_l14"):
     vit = E.RandomViT(arch, image_size=224, seed=0, dtype=torch.float32).cuda()
-    for B in (1, 8, 32, 64):
+    for B in [int(v) for v in sys.argv[1:]] or (1, 8, 32, 64):
         rgb = torch.randint(0, 255, (B, 480, 640, 4), dtype=torch.uint8, device="cuda")
         out = {}
         for split in (True, False):
