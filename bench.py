@@ -601,6 +601,47 @@ def exact_mode_leg(a, local_rank, frames=192):
             mem.engine.close()
         res["host_shuffle_share_frame_by_frame"] = out["host_shuffle_ms_per_frame"] / res["obs2voxeltoken"]["ms_per_frame"]
         out[f"depth_sample_rate_{rate}"] = res
+    # the reference's whole online step at its own precision: obs2voxeltoken with the f32 ViT-L/14 + 4 registers forward inside
+    # (the in-tree encoder's few-rows forms), depth_sample_rate 1000
+    def online():
+        from bsc_nav_amd import encoder
+        vit = encoder.RandomViT("vit_l14", image_size=224, seed=0, dtype=torch.float32).cuda()
+        tmp = tempfile.mkdtemp(prefix="bsc_exact_")
+        args = B.MemoryArgs(width=W, height=H, grid_size=gs, cell_size=0.1, floor_height=-12.8, map_height=12.8, depth_sample_rate=1000,
+                            query_width=224, query_height=224, memory_path=tmp, scene_name="bench", token_dim=D)
+        mem = B.VoxelTokenMemory(args, preload_dino=vit, need_diffusion=False, feature_mode="exact", voxel_capacity=400_000,
+                                 token_capacity=4_000_000)
+        np.random.seed(0); random.seed(0)
+        res = {}
+        for name in ("obs2voxeltoken", "obs2voxeltoken_prefetched_sampling"):
+            mem.engine.reset()
+            n0, n1 = 8, min(frames, 104)
+
+            def loop(lo, hi):
+                for f in range(lo, hi):
+                    mem.obs2voxeltoken({"rgb": rgb_h[f], "depth": depth_h[f]}, poses[f])
+            ctx = mem.prefetched_sampling(H * W) if name.endswith("prefetched_sampling") else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                loop(0, n0)
+                mem.engine.sync(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(n0, n1)
+                mem.engine.sync(); torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+            res[name] = {"frames_per_s": (n1 - n0) / dt, "ms_per_frame": dt / (n1 - n0) * 1e3}
+        mem.engine.close()
+        res["note"] = ("one frame per call, host frames in, the f32 ViT-L/14 + 4 registers forward (random weights) on the in-tree "
+                       "kernels inside every call; the reference's own loop with DINOv2 on its GPU: ~8.5 frames/s (BASELINE.md)")
+        return res
+    try:
+        out["online_step_f32_vit_l14_inside"] = online()
+    except Exception as e:      # noqa: BLE001
+        out["online_step_f32_vit_l14_inside"] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("frame by frame: host numpy frames -> H2D copies, host-side pose chain + NumPy-stream Fisher-Yates over all "
                    f"{H * W} pixels (bsc_host_shuffled_sample) + host alpha, then one bsc_ingest call per frame; "
                    "prefetched_sampling draws the shuffle of frame f+1 on a host thread under the work of frame f (the stream "
