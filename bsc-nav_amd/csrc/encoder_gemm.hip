@@ -1048,8 +1048,10 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
     // epilogue.  Per flop the small tile moves 8x the weight bytes through LDS, so it is taken only while the big tiles would not fill
     // the chip once.  (LayerNorm-in-the-load and the statistics epilogue exist for the big tile only: callers with few rows use the
     // LayerNorm pass.)
+    int dev = 0, n_cu = 0;
+    BSC_TRY(gs_device(&dev, &n_cu));
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    const bool few_rows = !(ln || stats) && !tile_env && big_tiles <= 256 && M <= 8192;
+    const bool few_rows = !(ln || stats) && !tile_env && big_tiles <= n_cu && M <= 8192;
     // (32-row tiles re-read the weights once per 32 rows: from ~500 rows on the launch is bound by that L2 traffic — 4.6 TB/s at
     //  1 576 rows — and 128 x 128 tiles, 4 wavefronts x 32 rows x 128 columns, take over, with the same split-K)
     const int tile = (ln || stats) ? 1 : few_rows ? (M <= 512 ? 6 : 3) : tile_env ? tile_env : (N <= 1024 ? BSC_GEMM_NARROW_TILE : 1);
@@ -1060,8 +1062,6 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
     const int64_t groups = (n_tiles_m + 7) / 8;                    // row tiles per XCD
     // a last round that fills at most half of the CUs runs as half-width tiles (tile 1 only; BSC_GEMM_TAIL=0: whole tiles)
     static const int tail_env = getenv("BSC_GEMM_TAIL") ? atoi(getenv("BSC_GEMM_TAIL")) : 1;
-    int dev = 0, n_cu = 0;
-    BSC_TRY(gs_device(&dev, &n_cu));
     // persistent workgroups: one per CU; the 60 KB few-rows tile two per CU
     const int64_t q_all = groups * n_tiles_n, per_round = ((tile == 6 || tile == 3) ? 2 : 1) * (n_cu / 8 > 0 ? n_cu / 8 : 1);
     const int64_t q_rem = q_all % per_round;
