@@ -241,13 +241,13 @@ def test_rccl_world1_merge_gather_localize(tmp_path, mode):
 RATE = 50
 
 
-def _sampled_args(tmp, name):
+def _sampled_args(tmp, name, rate=RATE):
     a = _args(tmp, name)
-    a.depth_sample_rate = RATE
+    a.depth_sample_rate = rate
     return a
 
 
-def _replay_worker(rank, world, port, out_dir):
+def _replay_worker(rank, world, port, out_dir, rate=RATE):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -257,14 +257,14 @@ def _replay_worker(rank, world, port, out_dir):
     from bsc_nav_amd import dist as bd
     from bsc_nav_amd.geometry import sample_indices_fast
     rgb, depth, poses, tokens = _inputs()
-    mem = B.VoxelTokenMemory(_sampled_args(out_dir, "merged"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+    mem = B.VoxelTokenMemory(_sampled_args(out_dir, "merged", rate), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
                              voxel_capacity=100_000)
     mem.enable_point_log(F * H * W)
     mem.set_map_origin(poses[0])
     a, b = bd.shard_frames(F)
     np.random.seed(3)
-    for _ in range(a):                                              # the shuffles the earlier ranks' frames consume
-        sample_indices_fast(H * W, RATE)
+    for _ in range(a if rate > 1 else 0):                           # the shuffles the earlier ranks' frames consume
+        sample_indices_fast(H * W, rate)
     dev = lambda x: torch.from_numpy(x[a:b]).cuda().contiguous()   # noqa: E731
     mem.ingest_frames(dev(rgb), dev(depth), poses[a:b], tokens=dev(tokens))
     if mem.merge_shards(root=0):
@@ -275,16 +275,18 @@ def _replay_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_process_colour_replay_is_bit_exact(tmp_path):
-    """depth_sample_rate = 50, two ranks, point log on: ids, counts AND rgb bytes / weights of the merged memory equal the
-    single-process build bit for bit (the owner of every voxel replays its points in global order)."""
+@pytest.mark.parametrize("rate", [RATE, 1])
+def test_two_process_colour_replay_is_bit_exact(tmp_path, rate):
+    """depth_sample_rate = 50 and 1 (EVERY pixel: the dense build of the north star), two ranks, point log on: ids, counts AND rgb
+    bytes / weights of the merged memory equal the single-process build bit for bit (the owner of every voxel replays its points
+    in global order).  The log costs 16 bytes per ingested point, which is why the every-pixel build does not keep it by default."""
     import torch
     import torch.multiprocessing as mp
     import bsc_nav_amd as B
-    mp.spawn(_replay_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_replay_worker, args=(2, _free_port(), str(tmp_path), rate), nprocs=2, join=True)
     got = np.load(f"{tmp_path}/replay_root.npz")
     rgb, depth, poses, tokens = _inputs()
-    one = B.VoxelTokenMemory(_sampled_args(tmp_path, "single"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+    one = B.VoxelTokenMemory(_sampled_args(tmp_path, "single", rate), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
                              voxel_capacity=100_000)
     np.random.seed(3)
     one.ingest_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), poses, tokens=torch.from_numpy(tokens).cuda())
@@ -293,7 +295,7 @@ def test_two_process_colour_replay_is_bit_exact(tmp_path):
     assert np.array_equal(got["rgb"], c) and np.array_equal(got["w"], w)           # exact, not "close"
     assert np.array_equal(got["cnt"], one.engine.export_dense()[1])
     # the replay kernel alone against the engine's own chain: all points of the single-process build, grouped by voxel
-    one2 = B.VoxelTokenMemory(_sampled_args(tmp_path, "single2"), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
+    one2 = B.VoxelTokenMemory(_sampled_args(tmp_path, "single2", rate), need_diffusion=False, feature_mode="mean", max_frames_per_call=F,
                               voxel_capacity=100_000)
     one2.enable_point_log(F * H * W)
     np.random.seed(3)
