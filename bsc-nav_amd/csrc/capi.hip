@@ -210,6 +210,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
                 }
             off[g2] = (int32_t)total;
             if (total > (int64_t)c.width * c.height) x->patch_tiles = false;
+            if ((int64_t)c.grid_size * c.grid_size * x->nh > (1ll << 26)) x->patch_tiles = false;   // PP_CELL_BITS of dense.hip
             if (x->patch_tiles) {
                 e = hipMemcpy(x->pt_rect, rect, sizeof(int32_t) * 4 * g2, hipMemcpyHostToDevice);
                 if (e == hipSuccess) e = hipMemcpy(x->pt_off, off, sizeof(int32_t) * (g2 + 1), hipMemcpyHostToDevice);

@@ -191,23 +191,78 @@ __global__ __launch_bounds__(TPB) void k_pair_compact(int64_t n_tiles, const int
 #define PP_HS 4096
 #define PP_R 13                 // rounds of TPB pixels: tiles of up to 3328 pixels (640x480 at 14x14 patches: 46 x 46, and 68 x 46 in
                                 // patch column 0, which int() widens to u in (-1, 1))
+#define PP_HEADS 256            // stretch heads a wavefront lists before it hashes them
+#define PP_CELL_BITS 26         // a head is cell | (points - 1) << 26: the path is taken for grids of up to 2^26 cells (capi.hip)
+// LDS accesses of ONE wavefront execute in program order; this keeps the compiler from reordering them (a fence over the LDS address
+// space alone: over all memory it is lowered to s_waitcnt vmcnt(0))
+__device__ __forceinline__ void pp_wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+}
 // Persistent workgroups walk the tiles: the 4096-slot table (sized for one cell per pixel) is cleared ONCE; every insert that
 // claims an empty slot also lists it, so a tile's pairs are emitted — and its slots cleared again — by walking that short list
 // (a few dozen entries for a surface at room distance) instead of scanning and re-initialising 4096 slots per tile.
+// Instructions per pixel (round 5: ~1000 -> ~600 per wavefront and tile):
+//   * the pixel of round r + 1 follows from the pixel of round r (TPB pixels further along the rows of the tile) with an add and a
+//     compare instead of a division per load; rounds past the tile's end are skipped;
+//   * neighbouring pixels share the cell: only the first lane of a stretch inserts, with the stretch's length — and the inserts are
+//     not made round by round by the few lanes that head a stretch (13 rounds x ~40 instructions, mostly idle lanes): every
+//     wavefront LISTS its stretch heads in LDS (ballot + rank, one store per round) and hashes the list densely, one head per
+//     lane, once per tile (or whenever the list is nearly full).
+// None of that moved the kernel's time by more than 5 % (phase stamps, -DBSC_PAIRS_PROFILE: ~10.5 k clocks per tile and workgroup in
+// every variant, the wait just moves to whichever instruction touches memory next; a prefetch of the next tile's cells into LDS
+// changed nothing either): the tile's time is its share of the memory system, which the call's side stream is loading at the same
+// time — what counts is the bytes.  A tile row is 46 pixels = 184 bytes at an arbitrary offset: 2-3 cache lines, shared with the
+// tiles left and right of it.  Tiles are therefore dealt out so that the workgroups of one XCD (blockIdx % 8: the round-robin
+// dispatch) walk CONSECUTIVE tiles at the same time and the shared lines are fetched once into that XCD's L2.
 __global__ __launch_bounds__(TPB) void k_patch_pairs(int W, int64_t N, int g, int64_t n_tiles, const int32_t *__restrict__ pt_rect,
                                                      const int32_t *__restrict__ pt_off, CellCode cc,
                                                      const int32_t *__restrict__ p_cell, u64 *__restrict__ stage_rec,
                                                      uint32_t *__restrict__ stage_blk, int32_t *__restrict__ tile_cnt)
 {
-    __shared__ uint32_t hkey[PP_HS], hcnt[PP_HS];
+    __shared__ uint32_t hkey[PP_HS];
+    __shared__ uint32_t hcnt2[PP_HS / 2];           // points per slot, 16 bits each (a tile has < 2^16 pixels): slot h in half h & 1 of word h >> 1
     __shared__ uint16_t hlist[PP_R * TPB];          // slots claimed by the tile in flight (<= one per pixel)
+    __shared__ uint32_t s_head[TPB / 64][PP_HEADS];
     __shared__ int nloc;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g2 = g * g;
-    for (int s = tid; s < PP_HS; s += TPB) { hkey[s] = 0xffffffffu; hcnt[s] = 0u; }
+    for (int s = tid; s < PP_HS; s += TPB) hkey[s] = 0xffffffffu;
+    for (int s = tid; s < PP_HS / 2; s += TPB) hcnt2[s] = 0u;
     if (tid == 0) nloc = 0;
     __syncthreads();
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef BSC_PAIRS_PROFILE
+    long long tph[4] = {0, 0, 0, 0}, tq = clock64();
+    int n_prof = 0;
+#define PP_T(k) { const long long now_ = clock64(); tph[k] += now_ - tq; tq = now_; }
+#else
+#define PP_T(k)
+#endif
+    // the wavefront's listed heads -> the table: one head per lane
+    auto hash_heads = [&](int cnt) {
+        pp_wave_lds_order();
+        for (int i = lane; i < cnt; i += 64) {
+            const uint32_t hd = s_head[wv][i];
+            const uint32_t key = hd & ((1u << PP_CELL_BITS) - 1u), len = (hd >> PP_CELL_BITS) + 1u;
+            uint32_t h = (key * 2654435761u) >> 20;            // 12 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, key);
+                if (old == 0xffffffffu) hlist[atomicAdd(&nloc, 1)] = (uint16_t)h;      // first claim of the slot: list it
+                if (old == 0xffffffffu || old == key) { atomicAdd(&hcnt2[h >> 1], len << (16 * (h & 1u))); break; }
+                h = (h + 1) & (PP_HS - 1);
+            }
+        }
+        pp_wave_lds_order();
+    };
+    // chunk c = `per` consecutive tiles; XCD x takes the chunks x, x + 8, ...; its workgroup `slot` the slot-th tile of each
+    const bool by_xcd = (gridDim.x & 7u) == 0u;
+    const int64_t per = by_xcd ? gridDim.x >> 3 : gridDim.x;
+    const int64_t slot = by_xcd ? blockIdx.x >> 3 : blockIdx.x, chunk0 = by_xcd ? blockIdx.x & 7u : 0, chunk_step = by_xcd ? 8 : 1;
+    for (int64_t chunk = chunk0; chunk * per < n_tiles; chunk += chunk_step) {
+        const int64_t tile = chunk * per + slot;
+        if (tile >= n_tiles) break;
         const int64_t f = tile / g2;
         const int p = (int)(tile - f * g2);
         const int x0 = pt_rect[4 * p], w = pt_rect[4 * p + 1], y0 = pt_rect[4 * p + 2], n = pt_rect[4 * p + 3];    // n = w * h pixels
@@ -215,54 +270,73 @@ __global__ __launch_bounds__(TPB) void k_patch_pairs(int W, int64_t N, int g, in
             if (tid == 0) tile_cnt[tile] = 0;
             continue;
         }
-        const float inv_w = 1.0f / (float)w;
+        const int dq = TPB / w, dr = TPB - dq * w;              // TPB pixels further = dq rows + dr columns (uniform)
+        const int d_off = dq * W + dr, d_wrap = W - w;
+        int py = (int)((float)tid * (1.0f / (float)w));
+        int px = tid - py * w;
+        if (px < 0) { --py; px += w; } else if (px >= w) { ++py; px -= w; }
+        int off = py * W + px;
+        const int32_t *tbase = p_cell + (f * N + (int64_t)y0 * W + x0);
         int32_t cell[PP_R];
 #pragma unroll
         for (int r = 0; r < PP_R; ++r) {                // all loads in flight before the first use (clamped addresses)
-            const int l = tid + r * TPB;
-            const int lc = l < n ? l : 0;
-            int y = (int)((float)lc * inv_w);
-            int x = lc - y * w;
-            if (x < 0) { --y; x += w; } else if (x >= w) { ++y; x -= w; }
-            const int32_t c = p_cell[f * N + (int64_t)(y0 + y) * W + x0 + x];
-            cell[r] = l < n ? c : -1;
-        }
-#pragma unroll
-        for (int r = 0; r < PP_R; ++r) {
-            if (r * TPB >= n) break;
-            // neighbouring pixels share the cell: only the first lane of a stretch inserts, with the stretch's length
-            const int32_t pc = __shfl_up(cell[r], 1);
-            const bool edge = lane == 0 || cell[r] != pc;
-            const u64 em = __ballot(edge);
-            const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
-            const int end = above ? (__ffsll((long long)above) - 1) : 64;
-            if (edge && cell[r] >= 0) {
-                const uint32_t key = (uint32_t)cell[r];
-                uint32_t h = (key * 2654435761u) >> 20;        // 12 bits
-                for (;;) {
-                    const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, key);
-                    if (old == 0xffffffffu) hlist[atomicAdd(&nloc, 1)] = (uint16_t)h;      // first claim of the slot: list it
-                    if (old == 0xffffffffu || old == key) { atomicAdd(&hcnt[h], (uint32_t)(end - lane)); break; }
-                    h = (h + 1) & (PP_HS - 1);
-                }
+            cell[r] = -1;
+            if (r * TPB < n) {
+                cell[r] = tbase[tid + r * TPB < n ? off : 0];
+                px += dr; off += d_off;
+                if (px >= w) { px -= w; off += d_wrap; }
             }
         }
+        PP_T(0)
+        int cnt = 0;                                    // heads in the wavefront's list (uniform)
+#pragma unroll
+        for (int r = 0; r < PP_R; ++r) {
+            if (r * TPB < n) {
+                if (cnt > PP_HEADS - 64) { hash_heads(cnt); cnt = 0; }
+                const int32_t c = tid + r * TPB < n ? cell[r] : -1;
+                const int32_t pc = __builtin_amdgcn_update_dpp(0, c, 0x138, 0xf, 0xf, false);      // wave_shr:1
+                const bool edge = lane == 0 || c != pc;
+                const u64 em = __ballot(edge);
+                const u64 above = lane == 63 ? 0ull : (em & (~0ull << (lane + 1)));
+                const int end = above ? (__ffsll((long long)above) - 1) : 64;
+                const bool ins = edge && c >= 0;
+                const u64 im = __ballot(ins);
+                if (ins)
+                    s_head[wv][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u))] =
+                        (uint32_t)c | ((uint32_t)(end - lane - 1) << PP_CELL_BITS);
+                cnt += __popcll(im);
+            }
+        }
+        PP_T(1)
+        hash_heads(cnt);
+        PP_T(2)
+        // the tile's distinct cells go to its private staging slice; k_patch_compact packs the slices after a scan of the counts
         __syncthreads();
         const int nl = nloc;
         const int64_t base = f * N + pt_off[p];              // the tile's staging slice: as many slots as it has pixels
         const u64 row = (u64)(f * g2 + p) << 32;
         for (int li = tid; li < nl; li += TPB) {
-            const int h = hlist[li];
+            const uint32_t h = hlist[li];
             const uint32_t key = hkey[h];
-            stage_rec[base + li] = row | (u64)hcnt[h];
+            stage_rec[base + li] = row | (u64)((hcnt2[h >> 1] >> (16 * (h & 1u))) & 0xffffu);
             stage_blk[base + li] = (uint32_t)cell_to_code(cc, (int32_t)key);
             hkey[h] = 0xffffffffu;                           // the table is clean again for the workgroup's next tile
-            hcnt[h] = 0u;
+            atomicAnd(&hcnt2[h >> 1], (h & 1u) ? 0x0000ffffu : 0xffff0000u);
         }
         __syncthreads();
         if (tid == 0) { tile_cnt[tile] = nl; nloc = 0; }
         __syncthreads();
+        PP_T(3)
+#ifdef BSC_PAIRS_PROFILE
+        ++n_prof;
+#endif
     }
+#ifdef BSC_PAIRS_PROFILE
+    if ((blockIdx.x == 100 || blockIdx.x == 611) && (tid == 0 || tid == 192))
+        printf("k_patch_pairs wg %d wave %d: %d tiles; issue %lld  arrive + list %lld  hash %lld  emit %lld (clocks per tile)\n",
+               (int)blockIdx.x, tid >> 6, n_prof, tph[0] / n_prof, tph[1] / n_prof, tph[2] / n_prof, tph[3] / n_prof);
+#endif
+#undef PP_T
 }
 
 __global__ __launch_bounds__(TPB) void k_patch_compact(int64_t n_tiles, int g2, int64_t N, const int32_t *__restrict__ pt_off,
