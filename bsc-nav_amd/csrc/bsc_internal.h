@@ -114,7 +114,12 @@ struct bsc_ctx {
     uint32_t *run_val_b;                // sorted run values
     int64_t *run_scan;                  // per 1024-run block: sum, then exclusive prefix, of (length | segment head << 32)
     int32_t *seg_k0, *seg_vid;          // voxel segments of the point order: first position, voxel id
-    uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel (read by the rgb chain)
+    uint32_t *sval_b_s[2];              // point order: j of the k-th point, voxel by voxel — written only where the quad chain reads it
+                                        // (short segments, the first points of new voxels: k_expand_short)
+    // the point order by RUNS (read by k_chain_long): position k belongs to the run whose start is the last set bit at or below k
+    u64 *run_bits_s[2];                 // bit k: a run starts at position k
+    uint32_t *ck_run_s[2], *ck_start_s[2];   // per 64 positions: the sorted run that covers position 64 w, and where it starts
+    uint32_t *run_val_s[2];             // sorted run values (first record of the run), per scratch set
     int4 *seg_info_s[2];                // per voxel segment: {first k, end k, voxel id, rank in the length-class order}
     u64 *f_keys_a, *f_keys_b;  // flush-private sort buffers (iter_size)
     int32_t *pass_list;

@@ -256,6 +256,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->pass_list, np);
     for (int k = 0; k < 2; ++k) {
         ALLOC(x->p_rec_s[k], np); ALLOC(x->skey_b_s[k], np); ALLOC(x->sval_b_s[k], np);
+        ALLOC(x->run_bits_s[k], np / 64 + 2); ALLOC(x->ck_run_s[k], np / 64 + 2); ALLOC(x->ck_start_s[k], np / 64 + 2); ALLOC(x->run_val_s[k], np);
         ALLOC(x->seg_info_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->seg_last_s[k], (np < vcap ? np : vcap) + 1); ALLOC(x->bscal_s[k], 8);
         BSC_HIP(hipEventCreateWithFlags(&x->ev_ready[k], hipEventDisableTiming));
         BSC_HIP(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
@@ -325,7 +326,8 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->l_name_rank, x->l_q, x->l_qp, x->l_out_pos, x->l_out_sim, x->l_sel_key[0], x->l_sel_key[1], x->l_sel_val[0],
                     x->l_sel_val[1], x->l_sel_thr, x->l_sel_cnt, x->l_valid, x->l_rscale, x->prim_tmp, x->prim_tmp_side, x->fr_mask, x->fr_in, x->fr_parent, x->fr_size,
                     x->fr_ord, x->fr_roots, x->fr_labels, x->fr_first, x->fr_sizes, x->fr_scal, x->fr_sumx, x->fr_sumy,
-                    x->fr_centers, x->fr_gains, x->log_cell, x->log_rec, x->stage_cell, x->stage_pos};
+                    x->fr_centers, x->fr_gains, x->log_cell, x->log_rec, x->stage_cell, x->stage_pos,
+                    x->run_bits_s[0], x->run_bits_s[1], x->ck_run_s[0], x->ck_run_s[1], x->ck_start_s[0], x->ck_start_s[1], x->run_val_s[0], x->run_val_s[1]};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (x->hscal) hipHostFree(x->hscal);

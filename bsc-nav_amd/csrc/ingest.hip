@@ -813,6 +813,37 @@ __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_
 
 struct ChainState { float w; uint32_t c0, c1, c2; };
 
+// ---- the per-voxel point order, by runs ---------------------------------------------------------------------------------------
+// The records of a run are consecutive (j0, j0 + 1, ...), so the order needs no entry per POINT (round 4: 4 bytes written by
+// k_expand and read by the chain for each of them, 1.9 GB per 768-frame call): position k belongs to the run whose start is the
+// last set bit of `bits` at or below k, and its record is j0[run] + (k - start).  Word w of `bits` holds the run starts of the
+// positions [64 w, 64 w + 64); ck_run[w] / ck_start[w] name the (sorted) run that covers position 64 w and where it starts, so a
+// lookup is stateless: one word, one checkpoint, one gather of j0 — any position, any order, no running count.
+struct RunOrder { const u64 *bits; const uint32_t *ck_run, *ck_start, *j0; };
+struct RunLook { u64 b; uint32_t r, s; };             // what the word of a position holds (loaded ahead of its use)
+__device__ __forceinline__ RunLook run_look(const RunOrder &o, int64_t k)
+{
+    const int64_t w = k >> 6;
+    RunLook l;
+    l.b = o.bits[w]; l.r = o.ck_run[w]; l.s = o.ck_start[w];
+    return l;
+}
+// -> index of the run in the sorted list, offset of position k inside it
+__device__ __forceinline__ void run_of(const RunLook &l, int64_t k, uint32_t &run, uint32_t &delta)
+{
+    const int b = (int)(k & 63);
+    const u64 below = l.b & ((2ull << b) - 1ull);        // b = 63: 2 << 63 wraps to 0, - 1 = all ones
+    run = l.r + (uint32_t)__popcll(below) - (uint32_t)(l.b & 1ull);
+    const uint32_t start = below ? (uint32_t)(k & ~63ll) + 63u - (uint32_t)__clzll((long long)below) : l.s;
+    delta = (uint32_t)k - start;
+}
+__device__ __forceinline__ uint32_t order_j(const RunOrder &o, int64_t k)
+{
+    uint32_t run, delta;
+    run_of(run_look(o, k), k, run, delta);
+    return o.j0[run] + delta;
+}
+
 // rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
 // after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
 // One round: 64 consecutive points of a voxel (lane l = point l of the round; invalid lanes carry alpha 0 and do not count),
@@ -866,26 +897,37 @@ __device__ __forceinline__ void chain_round_step(const PointRec rec, const bool 
 
 // rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
 // after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
-__device__ __forceinline__ void chain_rounds(const uint32_t *__restrict__ sj, const PointRec *__restrict__ p_rec, int64_t k,
+__device__ __forceinline__ void chain_rounds(const RunOrder &o, const PointRec *__restrict__ p_rec, int64_t k,
                                              const int64_t k1, const int64_t kend, ChainState &st, const int lane)
 {
     if (k >= k1) return;
     float w = st.w;
     uint32_t c0 = st.c0, c1 = st.c1, c2 = st.c2;
-    // records of round n+1 and order indices of round n+2 are in flight while round n is worked on
+    // in flight while round n is worked on: the records of round n+1, the run (j0 gather) of round n+2, the word and checkpoint of
+    // round n+3
     const int64_t klast = kend - 1;
-    uint32_t j_nxt;
     PointRec rec, rec_nxt;
+    uint32_t j0_nxt, d_nxt;
+    RunLook lk;
     {
-        const int64_t ka = k + lane, kb = k + 64 + lane;
-        rec = p_rec[sj[ka < kend ? ka : klast]];
-        j_nxt = sj[kb < kend ? kb : klast];
+        const int64_t ka = k + lane < kend ? k + lane : klast, kb = k + 64 + lane < kend ? k + 64 + lane : klast;
+        const int64_t kc = k + 128 + lane < kend ? k + 128 + lane : klast;
+        const RunLook la = run_look(o, ka), lb = run_look(o, kb);
+        lk = run_look(o, kc);
+        uint32_t ra, da, rb;
+        run_of(la, ka, ra, da);
+        run_of(lb, kb, rb, d_nxt);
+        rec = p_rec[o.j0[ra] + da];
+        j0_nxt = o.j0[rb];
     }
     for (; k < k1; k += 64) {
-        rec_nxt = p_rec[j_nxt];
+        rec_nxt = p_rec[j0_nxt + d_nxt];
         {
-            const int64_t kc = k + 128 + lane;
-            j_nxt = sj[kc < kend ? kc : klast];
+            const int64_t kc = k + 128 + lane < kend ? k + 128 + lane : klast, kd = k + 192 + lane < kend ? k + 192 + lane : klast;
+            uint32_t rc;
+            run_of(lk, kc, rc, d_nxt);
+            j0_nxt = o.j0[rc];
+            lk = run_look(o, kd);
         }
         chain_round_step(rec, k + lane < k1, w, c0, c1, c2, lane);
         rec = rec_nxt;
@@ -894,13 +936,13 @@ __device__ __forceinline__ void chain_rounds(const uint32_t *__restrict__ sj, co
 }
 
 __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_t vid, const int32_t s, const int64_t klast,
-                                             const uint32_t *__restrict__ sj, const int32_t *__restrict__ rgb_pos,
+                                             const RunOrder &o, const int32_t *__restrict__ rgb_pos,
                                              uint8_t *__restrict__ rgb, float *__restrict__ weight, u64 *hmap,
                                              int32_t *__restrict__ seg_last, int gs, int64_t order_base)
 {
     rgb[3 * (int64_t)vid] = (uint8_t)st.c0; rgb[3 * (int64_t)vid + 1] = (uint8_t)st.c1; rgb[3 * (int64_t)vid + 2] = (uint8_t)st.c2;
     weight[vid] = st.w;
-    const uint32_t lj = sj[klast];                      // order indices grow along a segment
+    const uint32_t lj = order_j(o, klast);              // record indices grow along a segment
     const int32_t row = rgb_pos[3 * (int64_t)vid], col = rgb_pos[3 * (int64_t)vid + 1], h = rgb_pos[3 * (int64_t)vid + 2];
     atomicMax(&hmap[(int64_t)row * gs + col], ((u64)(h + 1) << 40) | (u64)(order_base + lj));
     seg_last[s] = (int32_t)lj;
@@ -914,7 +956,7 @@ __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_
 // state, and so on down the line.  A binade crossing or a colour change inside the segment costs the rest of it a second
 // run; otherwise a segment of n points takes n / (64 * wavefronts) rounds.
 template <int NWV>      // wavefronts per workgroup: the width of the hot-segment split
-__global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restrict__ sj, int64_t *bscal,
+__global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64_t *bscal,
                                                         const int4 *__restrict__ seg_info,
                                                         const PointRec *__restrict__ p_rec,
                                                         const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
@@ -947,10 +989,23 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
         for (int64_t tile = k; tile < k1; tile += (int64_t)NWV * HOT_RPT * 64) {
             const int64_t ka = tile + (int64_t)wv * HOT_RPT * 64;          // this wavefront's slice [ka, ka + HOT_RPT * 64) of the tile
             PointRec rec[HOT_RPT];
+            {
+                RunLook lk[HOT_RPT];
+                uint32_t j0r[HOT_RPT], dr[HOT_RPT];
 #pragma unroll
-            for (int r = 0; r < HOT_RPT; ++r) {
-                const int64_t kk = ka + r * 64 + lane;
-                rec[r] = p_rec[sj[kk < k1 ? kk : klast]];
+                for (int r = 0; r < HOT_RPT; ++r) {
+                    const int64_t kk = ka + r * 64 + lane;
+                    lk[r] = run_look(o, kk < k1 ? kk : klast);
+                }
+#pragma unroll
+                for (int r = 0; r < HOT_RPT; ++r) {
+                    const int64_t kk = ka + r * 64 + lane;
+                    uint32_t run;
+                    run_of(lk[r], kk < k1 ? kk : klast, run, dr[r]);
+                    j0r[r] = o.j0[run];
+                }
+#pragma unroll
+                for (int r = 0; r < HOT_RPT; ++r) rec[r] = p_rec[j0r[r] + dr[r]];
             }
             // chunks < first are final; `st` is the true state at the start of chunk `first`
             for (int first = 0;;) {
@@ -994,7 +1049,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
             st = s_exit[NWV - 1];                               // the state after the tile (every thread reads the same entry)
             __syncthreads();                                    // before the next tile's pass overwrites the shared arrays
         }
-        if (threadIdx.x == 0) chain_finish(st, vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
+        if (threadIdx.x == 0) chain_finish(st, vid, s, k1 - 1, o, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
     // ---- the other long segments: one wavefront each, static schedule over the length-ordered list, back and forth (wave g
     // takes g, 2n-1-g, 2n+g, ...): no queue — an `if (lane == 0) atomicAdd` at the head of a loop that ends in another
@@ -1021,8 +1076,8 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
         st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
         st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
         st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
-        chain_rounds(sj, p_rec, k, k1, k1, st, lane);
-        if (lane == 0) chain_finish(st, vid, s, k1 - 1, sj, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
+        chain_rounds(o, p_rec, k, k1, k1, st, lane);
+        if (lane == 0) chain_finish(st, vid, s, k1 - 1, o, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
 }
 
@@ -1032,7 +1087,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const uint32_t *__restr
 // of its voxel" flags: both ride in one 64-bit value (length | head << 32), summed per block of EB runs (k_run_blocksum),
 // scanned over the ~R / 1024 block sums, and finished inside the block by k_expand — no R-sized scan array.
 #define EB 1024
-#define EXPAND_RUN_DRIVEN 16    // k_expand: wave-groups whose longest run has at most this many points are written run by run
+#define EXPAND_WORDS 2048          // k_expand: 64-position words of start bits a block collects in LDS (16 KB)
 // (length | head << 32) of sorted run i from its key and its predecessor's.  The two keys are loaded by the caller, unconditionally
 // (clamped indices) and for all its runs at once: read inside this function behind `if (i >= R)` and `if (v == vmask)`, every run
 // cost two dependent memory round trips, four runs per thread in a row.
@@ -1065,28 +1120,27 @@ __global__ __launch_bounds__(TPB) void k_run_blocksum(int64_t R, int vb, const u
     if (threadIdx.x == 0) blk_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// point order: sj[off(i) + t] = j0(i) + t.  One wavefront per 64 sorted runs (16 groups of 64 per block); the outputs
-// of the 64 runs are contiguous, so the lanes walk them with coalesced stores and find their run by bisection in LDS.
-// The first run of a voxel also records the segment: seg_k0[s] = off, seg_vid[s] = voxel id.
+// Position of every run in the per-voxel point order: its start bit, and the checkpoints of the 64-position words it covers
+// (RunOrder above).  One thread per sorted run, four per thread; the first run of a voxel also records the segment:
+// seg_k0[s] = off, seg_vid[s] = voxel id.
 __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_t *__restrict__ rkey_sorted,
-                                                const uint32_t *__restrict__ rval_sorted, const int64_t *__restrict__ blk_base,
-                                                uint32_t *__restrict__ sj, int32_t *__restrict__ seg_k0,
-                                                int32_t *__restrict__ seg_vid, int64_t *bscal)
+                                                const int64_t *__restrict__ blk_base, u64 *__restrict__ bits,
+                                                uint32_t *__restrict__ ck_run, uint32_t *__restrict__ ck_start,
+                                                int32_t *__restrict__ seg_k0, int32_t *__restrict__ seg_vid, int64_t *bscal)
 {
-    __shared__ int32_t s_off[TPB / 64][64], s_j0[TPB / 64][64];
     __shared__ uint32_t s_grp[EB / 64];
+    __shared__ u64 s_bits[EXPAND_WORDS];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t vmask = vb >= 32 ? 0xffffffffu : ((1u << vb) - 1u);
     // exclusive prefix of (length, head) inside the block, both in ONE 32-bit word — a block's 1024 runs hold at most 2^20
     // points (bits 0..20) and 1024 heads (bits 21..31) — scanned with DPP row shifts instead of 64-bit shuffles
     uint32_t item[EB / TPB], incl[EB / TPB];
-    uint32_t kc[EB / TPB], kp[EB / TPB], vc[EB / TPB];          // key, predecessor's key and value of the thread's four runs
+    uint32_t kc[EB / TPB], kp[EB / TPB];                         // key and predecessor's key of the thread's four runs
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
         const int64_t i = (int64_t)blockIdx.x * EB + (r * (TPB / 64) + wid) * 64 + lane, ic = i < R ? i : R - 1;
         kc[r] = rkey_sorted[ic];
         kp[r] = rkey_sorted[ic > 0 ? ic - 1 : 0];
-        vc[r] = rval_sorted[ic];
     }
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
@@ -1107,6 +1161,19 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
     }
     __syncthreads();
     const int64_t base = blk_base[blockIdx.x];
+    // The block's runs tile the positions [p_lo, p_lo + n_pos): their start bits are collected in LDS and leave as whole words —
+    // atomically only where a word is shared with the neighbouring blocks (one global atomic per run, 4 to a word on average, cost
+    // the order stage 0.2 ms per call and slowed the kernels beside it).  A block of very long runs (> EXPAND_WORDS x 64 positions)
+    // sets its bits in global memory directly.
+    uint32_t tot32 = 0;
+    for (int k = 0; k < EB / 64; ++k) tot32 += s_grp[k];
+    const int64_t p_lo = base & 0xffffffffll, n_pos = (int64_t)(tot32 & 0x1fffffu);
+    const int64_t w_lo = p_lo >> 6, n_words = n_pos ? ((p_lo + n_pos + 63) >> 6) - w_lo : 0;
+    const bool in_lds = n_words <= EXPAND_WORDS;
+    if (in_lds) {
+        for (int w = threadIdx.x; w < n_words; w += TPB) s_bits[w] = 0ull;
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < EB / TPB; ++r) {
         const int g = r * (TPB / 64) + wid;
@@ -1115,45 +1182,50 @@ __global__ __launch_bounds__(TPB) void k_expand(int64_t R, int vb, const uint32_
         pre32 += incl[r] - item[r];                                 // exclusive prefix of this run inside the block
         const int64_t sc = base + (int64_t)(pre32 & 0x1fffffu) + ((int64_t)(pre32 >> 21) << 32);
         const int64_t i = (int64_t)blockIdx.x * EB + g * 64 + lane;
-        int32_t off = INT_MAX, len = 0, j0 = 0;
-        if (i < R) {
-            const uint32_t key = kc[r];
-            const uint32_t v = key & vmask;
-            j0 = (int32_t)vc[r];
-            off = (int32_t)(sc & 0xffffffffll);
-            if (v != vmask) {
-                len = (int32_t)(key >> vb) + 1;
-                const bool head = (item[r] >> 21) != 0;
-                if (head) { seg_k0[sc >> 32] = off; seg_vid[sc >> 32] = (int32_t)v; }
-                if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = (int64_t)off + len; }
-            } else if (i == R - 1) {
-                bscal[0] = sc >> 32; bscal[2] = off;            // runs without a voxel sort last and take no room
-            }
+        if (i >= R) continue;
+        const uint32_t key = kc[r];
+        const uint32_t v = key & vmask;
+        const int64_t off = sc & 0xffffffffll;
+        if (v != vmask) {
+            const int64_t len = (int64_t)(key >> vb) + 1;
+            const bool head = (item[r] >> 21) != 0;
+            if (head) { seg_k0[sc >> 32] = (int32_t)off; seg_vid[sc >> 32] = (int32_t)v; }
+            if (i == R - 1) { bscal[0] = (sc >> 32) + (head ? 1 : 0); bscal[2] = off + len; }
+            if (in_lds) atomicOr(&s_bits[(off >> 6) - w_lo], 1ull << (off & 63));
+            else atomicOr(&bits[off >> 6], 1ull << (off & 63));
+            for (int64_t m = (off + 63) & ~63ll; m < off + len; m += 64) { ck_run[m >> 6] = (uint32_t)i; ck_start[m >> 6] = (uint32_t)off; }
+        } else if (i == R - 1) {
+            bscal[0] = sc >> 32; bscal[2] = off;            // runs without a voxel sort last and take no room
         }
-        __builtin_amdgcn_wave_barrier();
-        s_off[wid][lane] = len > 0 ? off : INT_MAX;
-        s_j0[wid][lane] = j0;
-        int32_t begin = len > 0 ? off : INT_MAX, end = len > 0 ? off + len : 0, longest = len;
-        for (int o = 32; o > 0; o >>= 1) {
-            begin = min(begin, __shfl_xor(begin, o)); end = max(end, __shfl_xor(end, o)); longest = max(longest, __shfl_xor(longest, o));
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < n_words; w += TPB) {
+            const u64 v = s_bits[w];
+            if (!v) continue;                                       // the array is cleared before the kernel
+            if (w == 0 || w == n_words - 1) atomicOr(&bits[w_lo + w], v);
+            else bits[w_lo + w] = v;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (begin == INT_MAX) continue;
-        if (longest <= EXPAND_RUN_DRIVEN) {
-            // short runs (the usual case: a voxel a few metres away covers a handful of pixels of an image row): every lane
-            // writes its own run; the runs of neighbouring lanes are neighbours in the output, so each of the `longest` store
-            // instructions covers a few cache lines — no search per output point
-            for (int t = 0; t < longest; ++t)
-                if (t < len) sj[off + t] = (uint32_t)(j0 + t);
-            continue;
+    }
+}
+
+// The quad chain (k_chain: short segments, and the first LONG_EARLY points of the long segments of NEW voxels) reads one order
+// index per point: written here, for those positions only.  One wavefront per segment of the length-ordered list.
+__global__ __launch_bounds__(TPB) void k_expand_short(const int64_t *bscal, const int4 *__restrict__ seg_info, const RunOrder o,
+                                                      uint32_t *__restrict__ sj, int early)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nseg = bscal[0], max_id_prev = bscal[1], nlong = bscal[4];
+    const int64_t nwaves = (int64_t)gridDim.x * (TPB / 64);
+    for (int64_t turn = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); turn < nseg; turn += nwaves) {
+        const int4 info = seg_info[seg_info[turn].w];
+        const int64_t k0 = info.x;
+        int64_t k1 = info.y;
+        if (turn < nlong) {
+            if ((int64_t)(uint32_t)info.z < max_id_prev) continue;          // an old voxel's long segment: k_chain_long alone
+            k1 = k1 - k0 > early ? k0 + early : k1;
         }
-        for (int32_t pnt = begin + lane; pnt < end; pnt += 64) {
-            int lo = 0;                         // largest lo with s_off[lo] <= pnt (offsets ascend; empty runs sort last)
-#pragma unroll
-            for (int stp = 32; stp > 0; stp >>= 1)
-                if (s_off[wid][lo + stp] <= pnt) lo += stp;
-            sj[pnt] = (uint32_t)(s_j0[wid][lo] + (pnt - s_off[wid][lo]));
-        }
+        for (int64_t k = k0 + lane; k < k1; k += 64) sj[k] = order_j(o, k);
     }
 }
 
@@ -1301,12 +1373,13 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     nw = nw < 64 ? 64 : (nw > long_waves ? long_waves : nw);
     static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 16;
     if (x->long_chain) {
+        const RunOrder ro = {x->run_bits_s[set], x->ck_run_s[set], x->ck_start_s[set], x->run_val_s[set]};
         if (long_nwv == 16)
-            hipLaunchKernelGGL(k_chain_long<16>, dim3((unsigned)((nw + 15) / 16)), dim3(1024), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
+            hipLaunchKernelGGL(k_chain_long<16>, dim3((unsigned)((nw + 15) / 16)), dim3(1024), 0, x->side, ro, x->bscal_s[set],
                                x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
                                x->c.grid_size, x->chain_order_base);
         else
-            hipLaunchKernelGGL(k_chain_long<8>, dim3((unsigned)((nw + 7) / 8)), dim3(512), 0, x->side, x->sval_b_s[set], x->bscal_s[set],
+            hipLaunchKernelGGL(k_chain_long<8>, dim3((unsigned)((nw + 7) / 8)), dim3(512), 0, x->side, ro, x->bscal_s[set],
                                x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
                                x->c.grid_size, x->chain_order_base);
     }
@@ -1487,12 +1560,13 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     if (R > 0) {        // a batch without a single passing point has no runs (k_totals left the segment count at 0)
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_b, (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_s[set], (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
         const int64_t neb = (R + EB - 1) / EB;
         hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan);
         BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_val_b, x->run_scan + neb, sj,
-                           x->seg_k0, x->seg_vid, x->bscal_s[set]);
+        BSC_HIP(hipMemsetAsync(x->run_bits_s[set], 0, sizeof(u64) * (size_t)((P >> 6) + 2), so));
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan + neb, x->run_bits_s[set],
+                           x->ck_run_s[set], x->ck_start_s[set], x->seg_k0, x->seg_vid, x->bscal_s[set]);
     }
     const int64_t seg_cap = (x->c.max_points < x->c.voxel_capacity ? x->c.max_points : x->c.voxel_capacity) + 1;
     int64_t n_bound = R < x->hscal[DS_MAX_ID] ? R : x->hscal[DS_MAX_ID];     // segments <= runs, <= voxels
@@ -1505,6 +1579,14 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     static const int hot_log2 = getenv("BSC_NO_HOT_SPLIT") ? 0 : (getenv("BSC_HOT_LOG2") ? atoi(getenv("BSC_HOT_LOG2")) : HOT_MIN_LOG2);
     hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, so, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,
                        x->seg_info_s[set], x->long_chain ? long_log2 : 0, hot_log2);
+    if (R > 0) {
+        // order indices for the quad chain: everything when there is no long chain (bscal[4] stays 0)
+        const RunOrder ro = {x->run_bits_s[set], x->ck_run_s[set], x->ck_start_s[set], x->run_val_s[set]};
+        int64_t nw = P / 1024;
+        nw = nw < 64 ? 64 : (nw > 4096 ? 4096 : nw);
+        hipLaunchKernelGGL(k_expand_short, dim3((unsigned)((nw + TPB / 64 - 1) / (TPB / 64))), block, 0, so, x->bscal_s[set],
+                           x->seg_info_s[set], ro, sj, LONG_EARLY);
+    }
     stat_end(x, BSC_STAT_ORDER, 0.0, so);
     return BSC_OK;
     }();
