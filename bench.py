@@ -249,8 +249,8 @@ def stage_rooflines(p, iso, tok_bytes):
         "k_keys_pairs": 4.0 * P + 12.0 * pairs,                                # cells in, pairs out
         "pair_sort": 2 * 12.0 * pairs,                                         # pairs in / out once
         "k_dense_reduce": (2 * U - U_new) * D * 4 + 8 * U + F * g * g * D * tok_bytes + 12 * pairs,
-        "ids+point_order": 4.0 * P + 4.0 * P,                                  # cells in, per-voxel point order out
-        "k_chain": 16.0 * P + 19.0 * U,                                        # order index + record per point, voxel state
+        "ids+point_order": 0.25 * P,                                           # per-voxel point order out: a start bit per point + a checkpoint per 64 (runs in: not counted)
+        "k_chain": 12.0 * P + 19.0 * U,                                        # record per point, voxel state
     }
     out = {}
     for name, b in byts.items():
