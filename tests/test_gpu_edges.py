@@ -408,6 +408,24 @@ def test_long_chains_of_old_voxels_over_several_calls():
     assert longest > 100_000
 
 
+@pytest.mark.parametrize("knob", ["BSC_ORDER_MAIN=1", "BSC_QUAD_CHAIN_ONLY=1", "BSC_CHAIN_EAGER=1", "BSC_NO_HOT_SPLIT=1",
+                                  "BSC_LONG_NWV=8", "BSC_HOT_LOG2=10", "BSC_LONG_LOG2=8", "BSC_GROUP_RPW=4"])
+def test_chain_and_order_knobs_keep_the_result(knob):
+    """The library's A/B switches move work between streams and kernels (order stage on the main stream, quad chain only, chain
+    right behind its order stage, no hot split, 8-wavefront hot tiles, other length classes, 1024-point blocks) — never the
+    result: the long-chain scene in three calls, bit-exact against the oracle, under each of them.  Most are read once per
+    process, so every case runs in its own interpreter."""
+    import os, subprocess, sys
+    name, val = knob.split("=")
+    code = ("import sys; sys.path[:0] = ['.', 'tests', 'tests/golden']; import test_gpu_edges as t; "
+            "longest, n = t._dense_vs_oracle(240, 320, 16, 8, 32, 1.0, -16.0, 16.0, F=6, per_call=2, seed=10, vcap=40_000); "
+            "assert longest > 20_000, longest; print('ok', longest, n)")
+    env = dict(os.environ, **{name: val})
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_weight_ties_and_saturation_against_oracle():
     """A handful of 50 m cells take every point.  alpha = 1 until the f32 weights pass 2^23 (one ulp = 1), then values
     from {0.25, 0.5, 0.75, 1}: 0.5 is an exact tie whose rounding depends on the parity of the running weight (the
