@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbscnav.so")
+# BSC_LIB_PATH: an A/B build of the same sources (csrc/build.sh with BSC_OUT / BSC_EXTRA_FLAGS); never a different implementation
+LIB_PATH = os.environ.get("BSC_LIB_PATH") or os.path.join(_HERE, "libbscnav.so")
 
 BSC_MODE_EXACT, BSC_MODE_MEAN, BSC_MODE_MAX = 0, 1, 2
 MODES = {"exact": BSC_MODE_EXACT, "mean": BSC_MODE_MEAN, "max": BSC_MODE_MAX}

@@ -66,6 +66,11 @@ struct bsc_ctx {
     // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
     bool geom_fast;
     bool long_chain;           // segments of >= 64 points go to the wavefront-per-voxel chain (BSC_QUAD_CHAIN_ONLY unsets)
+    // 8-byte point records for the every-pixel dense build (geometry_dev.h rec8_*): possible when float_as_uint over the valid
+    // depth range (min_depth, max_depth) spans fewer than 2^28 values (BSC_REC12=1 keeps the 12-byte {alpha, rgb} records)
+    bool rec8_ok;
+    uint32_t rec8_zbase;       // bits of the largest float <= min_depth
+    bool rec8_s[2];            // record format of the call in scratch set k (its chain is launched later)
     uint8_t *pat_x, *pat_y;   // (W), (H): patch column / row of a pixel column / row, 255 = outside the patch grid
     double *exp_tab;          // 64 x (hi, lo) of 2^(j/64): the table of bsc_exp (geometry_dev.h)
     // patch-aligned pair tiles (dense.hip): pixel rectangle {x0, width, y0, pixels} of every patch and the start of its

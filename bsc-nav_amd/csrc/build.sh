@@ -3,8 +3,9 @@
 # geometry chain is explicit (__fma_rn); nothing else may be fused (bit-exact parity with the reference).
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../libbscnav.so"
-OBJ="$HERE/_obj"
+# BSC_OUT / BSC_OBJ: an A/B build (other BSC_EXTRA_FLAGS) beside the product; python picks it up through BSC_LIB_PATH
+OUT="${BSC_OUT:-$HERE/../libbscnav.so}"
+OBJ="${BSC_OBJ:-$HERE/_obj}"
 mkdir -p "$OBJ"
 FLAGS="${BSC_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 pids=()

@@ -178,6 +178,17 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     {
         uint8_t *tx = (uint8_t *)malloc(c.width), *ty = (uint8_t *)malloc(c.height);
         x->long_chain = getenv("BSC_QUAD_CHAIN_ONLY") == nullptr;
+        {
+            // 8-byte point records: a valid depth z (min_depth < z < max_depth, utils.py:175-177) as float_as_uint(z) - zbase
+            float zlo = (float)c.min_depth, zhi = (float)c.max_depth;
+            if ((double)zlo > c.min_depth) zlo = nextafterf(zlo, 0.f);
+            if ((double)zhi < c.max_depth) zhi = nextafterf(zhi, INFINITY);
+            uint32_t blo = 0, bhi = 0;
+            memcpy(&blo, &zlo, 4); memcpy(&bhi, &zhi, 4);
+            x->rec8_zbase = blo;
+            x->rec8_ok = getenv("BSC_REC12") == nullptr && c.min_depth > 0 && zlo > 0.f && c.max_depth > c.min_depth && isfinite(zhi) &&
+                         bhi - blo < (1u << 28) && (int64_t)c.height * c.width < (1ll << 31);
+        }
         x->geom_fast = getenv("BSC_GENERIC_GEOMETRY") == nullptr && c.patch_grid < 255 && pinhole(c.K) && pinhole(c.Kinv) &&
                        pinhole(c.Kpatch) && c.width < (1 << 24) / c.height &&
                        patch_table(c.width, c.Kinv[0], c.Kinv[2], c.Kpatch[0], c.Kpatch[2], c.patch_grid, tx) &&

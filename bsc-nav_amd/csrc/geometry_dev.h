@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+typedef unsigned long long u64_t;
+
 struct GeomConst {
     double K[9], Kinv[9], Kp[9];
     double cs, half_gs, min_depth, max_depth;
@@ -23,6 +25,13 @@ struct GeomConst {
     // use cost two register moves) and the table of 2^(j/64) as (hi, lo) pairs
     double exp_il, exp_l1, exp_l2, exp_c2, exp_c3, exp_c4, exp_c5;
     const double2 *exp_tab;
+    // 8-byte point records (rec8_pack / rec8_alpha below; every-pixel builds with the fast geometry): depth as an offset from
+    // zbase = the bits of a float at or below min_depth, and exact division of a point index by N = H * W and of a pixel index by W
+    // (multiply by div_*_m, shift by 32 + div_*_s: exact for every 32-bit dividend)
+    uint32_t zbase;
+    int32_t rec_lb;           // log2 of the points per k_points workgroup (the record carries the point's index inside its block)
+    int32_t div_n_s, div_w_s;
+    u64_t div_n_m, div_w_m;
 };
 
 // exp(x) for the point weights alpha = exp(-r^2 / 1.2) (memory_2.py:873-875), x <= 0.  Table-driven (Tang): k = rint(x 64 / ln 2),
@@ -198,3 +207,44 @@ __device__ __forceinline__ void geom_point_fast(const GeomConst &c, int32_t x, i
 {
     geom_point_fast_t(c, x, y, zf, T, o, want_alpha, c.pat_x[x], c.pat_y[y], c.exp_tab);
 }
+
+// ---- 8-byte point records ---------------------------------------------------------------------------------------------------
+// What the rgb chain needs of a point is its colour and its weight alpha = exp(-r^2 / 1.2) (memory_2.py:870-875).  alpha is a
+// function of the pixel and the depth alone (r^2 is taken in the camera frame), and a valid depth lies in (min_depth, max_depth):
+// float_as_uint(z) - float_as_uint(min_depth) needs 26 bits for (0.1, 10) — sign and most exponent bits are constant.  So a record
+// is   rgb (24 bits) | index of the point inside its k_points block (lb bits) | depth offset (40 - lb bits)   = 8 bytes instead of
+// the 12 of {alpha f64, rgb}: the chain recomputes alpha with the very instructions k_points used (same bsc_exp, same operand
+// order: bit-identical), from the record and the record's position (which names the block).
+__device__ __forceinline__ uint32_t div_magic(uint32_t v, u64_t m, int s)
+{
+    // floor(v / d) for the divisor the (m, s) pair was made for: m = floor(2^(32+s) / d) + 1 has 33 bits, v * m < 2^65 is taken as
+    // (v * low 32 bits of m) + (v << 32) when bit 32 of m is set — the sum is below 2^64 for v < 2^31, which every caller guarantees
+    // (point indices are below max_points < 2^31)
+    const u64_t lo = (u64_t)v * (uint32_t)m + ((m >> 32) ? ((u64_t)v << 32) : 0ull);
+    return (uint32_t)(lo >> (32 + s));
+}
+
+__device__ __forceinline__ void rec8_pack(const GeomConst &c, uint32_t rgbv, uint32_t p_local, float z, uint32_t &lo, uint32_t &hi)
+{
+    lo = (rgbv & 0xffffffu) | (p_local << 24);
+    hi = (p_local >> 8) | ((__float_as_uint(z) - c.zbase) << (c.rec_lb - 8));
+}
+
+// alpha of the record (lo, hi) that sits at position `pos` of the call's record array
+__device__ __forceinline__ double rec8_alpha(const GeomConst &c, uint32_t lo, uint32_t hi, uint32_t pos, const double2 *exp_tab)
+{
+    const int lb = c.rec_lb;
+    const uint32_t p_local = (lo >> 24) | ((hi & ((1u << (lb - 8)) - 1u)) << 8);
+    const double z = (double)__uint_as_float((hi >> (lb - 8)) + c.zbase);
+    const uint32_t j = (pos & ~((1u << lb) - 1u)) | p_local;
+    const uint32_t f = div_magic(j, c.div_n_m, c.div_n_s);
+    const uint32_t i = j - f * (uint32_t)(c.H * c.W);
+    const uint32_t y = div_magic(i, c.div_w_m, c.div_w_s);
+    const uint32_t x = i - y * (uint32_t)c.W;
+    const double px = (double)(int32_t)x + 0.5, py = (double)(int32_t)y + 0.5;
+    const double p0 = __dmul_rn(__dadd_rn(__dmul_rn(c.Kinv[0], px), c.Kinv[2]), z);
+    const double p1 = __dmul_rn(__dadd_rn(__dmul_rn(c.Kinv[4], py), c.Kinv[5]), z);
+    const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(z, z));
+    return bsc_exp(div_by_const(-r2, 1.2, 1.0 / 1.2), c, exp_tab);      // the expression of geom_point_fast_t, operand for operand
+}
+

@@ -54,6 +54,16 @@ static GeomConst make_geom_const(const bsc_ctx *x)
     g.exp_l2 = (double)(l64 - (long double)l1);
     g.exp_c2 = 0.5; g.exp_c3 = 1.0 / 6.0; g.exp_c4 = 1.0 / 24.0; g.exp_c5 = 1.0 / 120.0;
     g.exp_tab = (const double2 *)x->exp_tab;
+    // 8-byte point records (geometry_dev.h rec8_*): depth offsets from a float at or below min_depth, exact index divisions
+    g.zbase = x->rec8_zbase;
+    g.rec_lb = x->group_rpw == 16 ? 12 : (x->group_rpw == 8 ? 11 : 10);
+    const auto magic = [](uint32_t d, u64_t &m, int32_t &sft) {
+        sft = 0;
+        while ((1ull << sft) < d) ++sft;
+        m = (u64_t)((((unsigned __int128)1) << (32 + sft)) / d) + 1ull;
+    };
+    magic((uint32_t)(x->c.height * x->c.width), g.div_n_m, g.div_n_s);
+    magic((uint32_t)x->c.width, g.div_w_m, g.div_w_s);
     return g;
 }
 
@@ -137,14 +147,21 @@ __device__ __forceinline__ void claim_cells(bool want, int32_t cell, int64_t j, 
 // RPW: rounds of 64 points per wavefront; GB = GW * RPW * 64 points per workgroup.
 // PLAIN: every pixel of every frame, patch from the pixel, device alpha, no token-cache columns, no point log (the dense
 // build): idx, p_patf, p_r2f, alpha_in and g_cell are null and their code is compiled out.
-template <bool FAST, int RPW, bool PLAIN>
-__global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__restrict__ depth,
+// REC8 (with PLAIN): 8-byte records {rgb, index inside the block, depth offset} instead of {alpha f64, rgb} — alpha is evaluated
+// by the rgb chain (geometry_dev.h rec8_alpha: the same instructions on the same operands), not here.
+// Four workgroups (16 wavefronts) per CU up to 2048-point blocks: without the bound the 8-byte-record form settled at 131 registers
+// — three wavefronts per SIMD — although 95 do without a spill (-DBSC_POINTS_MIN_BLOCKS=1: the compiler's own choice)
+#ifndef BSC_POINTS_MIN_BLOCKS
+#define BSC_POINTS_MIN_BLOCKS 4
+#endif
+template <bool FAST, int RPW, bool PLAIN, bool REC8>
+__global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_points(GeomConst gc, const float *__restrict__ depth,
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
                                                 const int32_t *__restrict__ idx_, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
                                                 const double *__restrict__ alpha_in_, int64_t P, float inv_w, int cap_log2,
                                                 int32_t *occ, int32_t *__restrict__ p_cell, uint32_t *__restrict__ p_patf_,
-                                                PointRec *__restrict__ p_rec, float *__restrict__ p_r2f_,
+                                                void *__restrict__ p_rec, float *__restrict__ p_r2f_,
                                                 int32_t *__restrict__ new_cells, int64_t *dscal,
                                                 int32_t *__restrict__ blk_runs, int32_t *__restrict__ blk_pass,
                                                 uint32_t *__restrict__ stage_cell, uint32_t *__restrict__ stage_pos,
@@ -152,7 +169,9 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
 {
     constexpr int GB = GW * RPW * 64;
     constexpr int EPT = GROUP_HS / TPB;         // slots per thread in the prefix pass
-    constexpr int WORD_BYTES = GW * (GROUP_HS + 1) * 8, REC_BYTES = 12 * GB;
+    constexpr int RECW = REC8 ? 2 : 3;          // 32-bit words per record
+    constexpr int WORD_BYTES = GW * (GROUP_HS + 1) * 8, REC_BYTES = 4 * RECW * GB;
+    static_assert(!REC8 || PLAIN, "8-byte records belong to the every-pixel dense build");
     const int32_t *__restrict__ idx = PLAIN ? nullptr : idx_;
     const double *__restrict__ alpha_in = PLAIN ? nullptr : alpha_in_;
     uint32_t *__restrict__ p_patf = PLAIN ? nullptr : p_patf_;
@@ -165,8 +184,8 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
     __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];          // + a spare entry for the lanes without a slot
     __shared__ uint32_t s_wsum[GW];
     __shared__ int32_t s_ovf[GW];
-    __shared__ double2 s_exp[64];                         // 2^(j/64) as (hi, lo): bsc_exp's table
-    if (threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
+    __shared__ double2 s_exp[REC8 ? 1 : 64];              // 2^(j/64) as (hi, lo): bsc_exp's table (8-byte records: alpha is the chain's)
+    if (!REC8 && threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
     u64(*s_word)[GROUP_HS + 1] = (u64(*)[GROUP_HS + 1])s_raw;
     uint32_t *s_rec = (uint32_t *)s_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             cell = -1;
             if (FAST) {
                 GeomFastOut o;
-                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r], s_exp);
+                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, !REC8 && alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r], s_exp);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
             } else {
@@ -300,8 +319,10 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
             }
             // selects, not a branch: the record of a point outside the grid is never written, so its alpha bits may be anything
             pix_off = cell >= 0 ? ((int64_t)f * N + (int64_t)sy * gc.W + sx) * rgb_ch : 0;
-            ralo[r] = (uint32_t)__double2loint(alpha);
-            rahi[r] = (uint32_t)__double2hiint(alpha);
+            if (!REC8) {
+                ralo[r] = (uint32_t)__double2loint(alpha);
+                rahi[r] = (uint32_t)__double2hiint(alpha);
+            }
         }
         // the colour gather of every lane, unconditionally and unprocessed: nothing below needs it before the records are written,
         // so its round trip runs under the following rounds (RGBA frames: one aligned 32-bit gather; RGB: 16 + 8 bits)
@@ -429,14 +450,20 @@ __global__ __launch_bounds__(TPB) void k_points(GeomConst gc, const float *__res
         }
         if (valid) {
             const uint32_t rgbv = rgb4 ? (raw0[r] & 0xffffffu) : (raw0[r] | (raw1[r] << 16));
-            s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rgbv;
+            if (REC8) {
+                uint32_t lo, hi;
+                rec8_pack(gc, rgbv, (uint32_t)(wv * RPW * 64 + r * 64 + lane), zr[r], lo, hi);
+                s_rec[2 * pos] = lo; s_rec[2 * pos + 1] = hi;
+            } else {
+                s_rec[3 * pos] = ralo[r]; s_rec[3 * pos + 1] = rahi[r]; s_rec[3 * pos + 2] = rgbv;
+            }
             if (g_cell) g_cell[blk_base + pos] = cells[r];
         }
     }
     __syncthreads();
     {
-        uint32_t *dst = (uint32_t *)(p_rec + blk_base);       // 12 * GB bytes per block: 16-byte aligned
-        const uint32_t nd = 3u * n_valid, nq = nd >> 2;
+        uint32_t *dst = (uint32_t *)p_rec + (int64_t)RECW * blk_base;       // 12 (8) * GB bytes per block: 16-byte aligned
+        const uint32_t nd = (uint32_t)RECW * n_valid, nq = nd >> 2;
         for (uint32_t i = tid; i < nq; i += TPB) ((uint4 *)dst)[i] = ((const uint4 *)s_rec)[i];
         if (tid < (int)(nd & 3u)) dst[4 * nq + tid] = s_rec[4 * nq + tid];
         if (g_cell) {
@@ -607,16 +634,38 @@ __device__ __forceinline__ void chain_load_idx(uint32_t (&J)[CQ], bool on, int64
     }
 }
 
-__device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)[CQ], const PointRec *__restrict__ p_rec,
+template <bool REC8>
+__device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)[CQ], const void *__restrict__ p_rec,
                                                uint32_t &last_j)
 {
 #pragma unroll
     for (int i = 0; i < CQ; ++i) {
         const bool valid = J[i] != 0xffffffffu;
-        const PointRec raw = p_rec[valid ? J[i] : 0u];                         // { alpha lo, alpha hi, rgbv }: 12 bytes
-        R.alo[i] = raw.alo; R.ahi[i] = raw.ahi;
-        R.rv[i] = valid ? (raw.rgbv | 0xc0000000u) : 0u;
+        if (REC8) {
+            const uint2 raw = ((const uint2 *)p_rec)[valid ? J[i] : 0u];       // { rgb | index in block, index | depth offset }: 8 bytes,
+            R.alo[i] = raw.x; R.ahi[i] = raw.y;                                // decoded by chain_decode once the load has landed
+            R.rv[i] = valid ? 0xc0000000u : 0u;
+        } else {
+            const PointRec raw = ((const PointRec *)p_rec)[valid ? J[i] : 0u]; // { alpha lo, alpha hi, rgbv }: 12 bytes
+            R.alo[i] = raw.alo; R.ahi[i] = raw.ahi;
+            R.rv[i] = valid ? (raw.rgbv | 0xc0000000u) : 0u;
+        }
         last_j = valid ? J[i] : last_j;                                        // order indices grow along a segment
+    }
+}
+
+// 8-byte records -> {alpha, rgb} in place (geometry_dev.h rec8_alpha; J[i] is the record's position).  Slots without a point
+// decode whatever record 0 holds: their step never runs.
+template <bool REC8>
+__device__ __forceinline__ void chain_decode(ChainRegs &R, const uint32_t (&J)[CQ], const GeomConst &gc, const double2 *exp_tab)
+{
+    if (!REC8) return;
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        const uint32_t lo = R.alo[i], hi = R.ahi[i];
+        const double a = rec8_alpha(gc, lo, hi, J[i], exp_tab);
+        R.rv[i] |= lo & 0xffffffu;
+        R.alo[i] = (uint32_t)__double2loint(a); R.ahi[i] = (uint32_t)__double2hiint(a);
     }
 }
 
@@ -643,15 +692,21 @@ __device__ __forceinline__ void chain_load_rec(ChainRegs &R, const uint32_t (&J)
 #define HOT_MIN_LOG2 15                          // segments of >= 32768 points are split over the wavefronts of a workgroup
 #define CHAIN_WG 256             // 4 wavefronts per workgroup, one per SIMD of a CU
 #define CHAIN_WAVES 512
-__global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__ sj, int64_t *bscal,
+template <bool REC8>
+__global__ __launch_bounds__(CHAIN_WG) void k_chain(const GeomConst gc, const uint32_t *__restrict__ sj, int64_t *bscal,
                                               const int4 *__restrict__ seg_info,
-                                              const PointRec *__restrict__ p_rec,
+                                              const void *__restrict__ p_rec,
                                               const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
                                               float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                               int gs, int64_t order_base)
 {
     // default wave priority: raised priority (s_setprio 3) bought the chain nothing (its steps are latency-bound) and cost
     // the kernels beside it 0.7 ms per 384-frame step
+    __shared__ double2 s_exp[REC8 ? 64 : 1];
+    if (REC8) {
+        if (threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int q = lane & 3;
     const int ch = q < 3 ? q : 2;
@@ -709,9 +764,10 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
             chain_load_idx(J0, fresh, pos, q, k1, sj);
             ChainRegs R0;
             uint32_t lj = last_j;
-            chain_load_rec(R0, J0, p_rec, lj);
+            chain_load_rec<REC8>(R0, J0, p_rec, lj);
             uint32_t J1[CQ];
             chain_load_idx(J1, fresh, pos + 64, q, k1, sj);
+            chain_decode<REC8>(R0, J0, gc, s_exp);
             // :890-894 a new id takes the colour of its first point and weight f32(0 + alpha); that point is then done
             const uint32_t rv0 = quad_bcast<0>(R0.rv[0]);
             const double a0 = __hiloint2double((int)quad_bcast<0>(R0.ahi[0]), (int)quad_bcast<0>(R0.alo[0]));
@@ -732,7 +788,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
         }
 
         // ---- prefetch: records of the next chunk, order indices of the one after ----------------------------------
-        chain_load_rec(Rn, Jn, p_rec, last_j);
+        chain_load_rec<REC8>(Rn, Jn, p_rec, last_j);
         chain_load_idx(Jnn, have, pos + 128, q, k1, sj);
 
         // ---- 64 steps out of registers; a block of 16 is skipped once no quad of the wave has points left in it ----
@@ -767,6 +823,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const uint32_t *__restrict__
             have = false;
         }
         pos += 64;
+        chain_decode<REC8>(Rn, Jn, gc, s_exp);      // behind the 64 steps: the records have long arrived
 #pragma unroll
         for (int i = 0; i < CQ; ++i) {
             R.rv[i] = have ? Rn.rv[i] : 0u; R.alo[i] = Rn.alo[i]; R.ahi[i] = Rn.ahi[i];
@@ -813,6 +870,17 @@ __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_
 
 struct ChainState { float w; uint32_t c0, c1, c2; };
 
+// a point record as the long chain holds it between its load and its use: 12-byte {alpha, rgb}, or 8 bytes + the position
+template <bool REC8> struct RecT;
+template <> struct RecT<false> { PointRec r; };
+template <> struct RecT<true> { uint2 r; uint32_t pos; };
+__device__ __forceinline__ void rec_load(RecT<false> &t, const void *__restrict__ p_rec, uint32_t pos) { t.r = ((const PointRec *)p_rec)[pos]; }
+__device__ __forceinline__ void rec_load(RecT<true> &t, const void *__restrict__ p_rec, uint32_t pos) { t.r = ((const uint2 *)p_rec)[pos]; t.pos = pos; }
+__device__ __forceinline__ double rec_alpha(const RecT<false> &t, const GeomConst &, const double2 *) { return __hiloint2double((int)t.r.ahi, (int)t.r.alo); }
+__device__ __forceinline__ double rec_alpha(const RecT<true> &t, const GeomConst &gc, const double2 *tab) { return rec8_alpha(gc, t.r.x, t.r.y, t.pos, tab); }
+__device__ __forceinline__ uint32_t rec_rgb(const RecT<false> &t) { return t.r.rgbv; }
+__device__ __forceinline__ uint32_t rec_rgb(const RecT<true> &t) { return t.r.x & 0xffffffu; }
+
 // ---- the per-voxel point order, by runs ---------------------------------------------------------------------------------------
 // The records of a run are consecutive (j0, j0 + 1, ...), so the order needs no entry per POINT (round 4: 4 bytes written by
 // k_expand and read by the chain for each of them, 1.9 GB per 768-frame call): position k belongs to the run whose start is the
@@ -848,10 +916,10 @@ __device__ __forceinline__ uint32_t order_j(const RunOrder &o, int64_t k)
 // after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
 // One round: 64 consecutive points of a voxel (lane l = point l of the round; invalid lanes carry alpha 0 and do not count),
 // state (w, c0, c1, c2) wave-uniform in, the state after the round out.
-__device__ __forceinline__ void chain_round_step(const PointRec rec, const bool valid, float &w, uint32_t &c0, uint32_t &c1,
-                                                 uint32_t &c2, const int lane)
+__device__ __forceinline__ void chain_round_step(const double alpha, const uint32_t rgbv, const bool valid, float &w, uint32_t &c0,
+                                                 uint32_t &c1, uint32_t &c2, const int lane)
 {
-    const double a = valid ? __hiloint2double((int)rec.ahi, (int)rec.alo) : 0.0;      // alpha 0 leaves w as it is
+    const double a = valid ? alpha : 0.0;      // alpha 0 leaves w as it is
     // ---- weights: predict, check with the recurrence, redo from the first lane that fails ----------------------------
     float wbase = w, wp = w, wn;
     int start = 0;
@@ -875,7 +943,7 @@ __device__ __forceinline__ void chain_round_step(const PointRec rec, const bool 
     const u64 vmask = __ballot(valid);
 #define BSC_LONG_CHANNEL(cc, shift)                                                                     \
     {                                                                                                   \
-        const double ra = (double)((rec.rgbv >> shift) & 0xffu) * a;                                    \
+        const double ra = (double)((rgbv >> shift) & 0xffu) * a;                                        \
         u64 pend = vmask;                                                                               \
         for (;;) {                                                                                      \
             const double num = (double)((float)cc * wp) + ra;                                           \
@@ -897,8 +965,10 @@ __device__ __forceinline__ void chain_round_step(const PointRec rec, const bool 
 
 // rounds of 64 points over the positions [k, k1) of the per-voxel point order, from state `st` (wave-uniform) to the state
 // after the last point.  `kend` clamps the prefetch addresses (the end of the whole segment).
-__device__ __forceinline__ void chain_rounds(const RunOrder &o, const PointRec *__restrict__ p_rec, int64_t k,
-                                             const int64_t k1, const int64_t kend, ChainState &st, const int lane)
+template <bool REC8>
+__device__ __forceinline__ void chain_rounds(const RunOrder &o, const void *__restrict__ p_rec, int64_t k,
+                                             const int64_t k1, const int64_t kend, ChainState &st, const int lane,
+                                             const GeomConst &gc, const double2 *exp_tab)
 {
     if (k >= k1) return;
     float w = st.w;
@@ -906,7 +976,7 @@ __device__ __forceinline__ void chain_rounds(const RunOrder &o, const PointRec *
     // in flight while round n is worked on: the records of round n+1, the run (j0 gather) of round n+2, the word and checkpoint of
     // round n+3
     const int64_t klast = kend - 1;
-    PointRec rec, rec_nxt;
+    RecT<REC8> rec, rec_nxt;
     uint32_t j0_nxt, d_nxt;
     RunLook lk;
     {
@@ -917,11 +987,11 @@ __device__ __forceinline__ void chain_rounds(const RunOrder &o, const PointRec *
         uint32_t ra, da, rb;
         run_of(la, ka, ra, da);
         run_of(lb, kb, rb, d_nxt);
-        rec = p_rec[o.j0[ra] + da];
+        rec_load(rec, p_rec, o.j0[ra] + da);
         j0_nxt = o.j0[rb];
     }
     for (; k < k1; k += 64) {
-        rec_nxt = p_rec[j0_nxt + d_nxt];
+        rec_load(rec_nxt, p_rec, j0_nxt + d_nxt);
         {
             const int64_t kc = k + 128 + lane < kend ? k + 128 + lane : klast, kd = k + 192 + lane < kend ? k + 192 + lane : klast;
             uint32_t rc;
@@ -929,7 +999,7 @@ __device__ __forceinline__ void chain_rounds(const RunOrder &o, const PointRec *
             j0_nxt = o.j0[rc];
             lk = run_look(o, kd);
         }
-        chain_round_step(rec, k + lane < k1, w, c0, c1, c2, lane);
+        chain_round_step(rec_alpha(rec, gc, exp_tab), rec_rgb(rec), k + lane < k1, w, c0, c1, c2, lane);
         rec = rec_nxt;
     }
     st.w = w; st.c0 = c0; st.c1 = c1; st.c2 = c2;
@@ -955,20 +1025,35 @@ __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_
 // settled); (C) chunk k+1's assumed entry must equal chunk k's exit: the first chunk that fails is run again from the true
 // state, and so on down the line.  A binade crossing or a colour change inside the segment costs the rest of it a second
 // run; otherwise a segment of n points takes n / (64 * wavefronts) rounds.
-template <int NWV>      // wavefronts per workgroup: the width of the hot-segment split
-__global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64_t *bscal,
+template <int NWV, bool REC8>      // wavefronts per workgroup: the width of the hot-segment split; record format
+__global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, const RunOrder o, int64_t *bscal,
                                                         const int4 *__restrict__ seg_info,
-                                                        const PointRec *__restrict__ p_rec,
+                                                        const void *__restrict__ p_rec,
                                                         const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
                                                         float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                                         int gs, int64_t order_base)
 {
     __shared__ float s_sum[NWV];
     __shared__ ChainState s_entry[NWV], s_exit[NWV];
+    __shared__ double2 s_exp[REC8 ? 64 : 1];
+    if (REC8) {
+        if (threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nlong = bscal[4], nhot = bscal[6];
     const int64_t max_id_prev = bscal[1];
+#ifdef BSC_CHAIN_PROFILE
+    // per-phase clocks of wavefront 0 (-DBSC_CHAIN_PROFILE, scripts/variant_ab.py with an A/B build): load + alpha, pass A + barriers,
+    // pass B, check; tiles, repeated passes; the one-wavefront segments after the hot ones; wall clock (100 MHz) at entry and exit
+    long long cph[5] = {0, 0, 0, 0, 0}, cq = clock64();
+    const long long wall0 = wall_clock64();
+    int n_tiles = 0, n_again = 0, n_hotseg = 0;
+#define CP_T(k) { const long long now_ = clock64(); cph[k] += now_ - cq; cq = now_; }
+#else
+#define CP_T(k)
+#endif
     // ---- hot segments: one workgroup each, in TILES of NWV x HOT_RPT x 64 points whose records every wavefront loads ONCE into
     // registers: (A) the increments of its slice summed from registers, (B) its rounds stepped from registers from the predicted
     // entry state, (C) the slices' entry / exit states compared; a slice whose entry was wrong runs (A, B) again from registers.
@@ -986,10 +1071,16 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
         st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
         st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
         const int64_t klast = k1 - 1;
+#ifdef BSC_CHAIN_PROFILE
+        ++n_hotseg;
+#endif
         for (int64_t tile = k; tile < k1; tile += (int64_t)NWV * HOT_RPT * 64) {
+            CP_T(4)
             const int64_t ka = tile + (int64_t)wv * HOT_RPT * 64;          // this wavefront's slice [ka, ka + HOT_RPT * 64) of the tile
-            PointRec rec[HOT_RPT];
+            double al[HOT_RPT];                                            // the slice's weights and colours, in registers for the tile
+            uint32_t rg[HOT_RPT];
             {
+                RecT<REC8> rec[HOT_RPT];
                 RunLook lk[HOT_RPT];
                 uint32_t j0r[HOT_RPT], dr[HOT_RPT];
 #pragma unroll
@@ -1005,8 +1096,14 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
                     j0r[r] = o.j0[run];
                 }
 #pragma unroll
-                for (int r = 0; r < HOT_RPT; ++r) rec[r] = p_rec[j0r[r] + dr[r]];
+                for (int r = 0; r < HOT_RPT; ++r) rec_load(rec[r], p_rec, j0r[r] + dr[r]);
+#pragma unroll
+                for (int r = 0; r < HOT_RPT; ++r) { al[r] = rec_alpha(rec[r], gc, s_exp); rg[r] = rec_rgb(rec[r]); }
             }
+#ifdef BSC_CHAIN_PROFILE
+            { double sink = 0; for (int r = 0; r < HOT_RPT; ++r) sink += al[r]; asm volatile("" :: "v"(sink)); ++n_tiles; }
+#endif
+            CP_T(0)
             // chunks < first are final; `st` is the true state at the start of chunk `first`
             for (int first = 0;;) {
                 float mine = 0.f;
@@ -1015,8 +1112,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
 #pragma unroll
                     for (int r = 0; r < HOT_RPT; ++r) {
                         const bool valid = ka + r * 64 + lane < k1;
-                        const double a = __hiloint2double((int)rec[r].ahi, (int)rec[r].alo);
-                        mine += valid ? (float)(wb + a) - st.w : 0.f;
+                        mine += valid ? (float)(wb + al[r]) - st.w : 0.f;
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
@@ -1025,6 +1121,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
                 __syncthreads();                                // the shared arrays are free (previous pass / tile / segment)
                 if (lane == 0) s_sum[wv] = mine;
                 __syncthreads();
+                CP_T(1)
                 if (wv >= first) {
                     ChainState me = st;
                     for (int i = first; i < wv; ++i) me.w += s_sum[i];
@@ -1032,19 +1129,24 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
 #pragma unroll
                     for (int r = 0; r < HOT_RPT; ++r) {
                         if (ka + r * 64 >= k1) break;           // (uniform) past the segment's end
-                        chain_round_step(rec[r], ka + r * 64 + lane < k1, me.w, me.c0, me.c1, me.c2, lane);
+                        chain_round_step(al[r], rg[r], ka + r * 64 + lane < k1, me.w, me.c0, me.c1, me.c2, lane);
                     }
                     if (lane == 0) s_exit[wv] = me;
                 }
+                CP_T(2)
                 __syncthreads();
                 int bad = NWV;
                 for (int c = NWV - 1; c > first; --c) {
                     const ChainState have = s_entry[c], real = s_exit[c - 1];
                     if (!(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2)) bad = c;
                 }
+                CP_T(3)
                 if (bad == NWV) break;
                 st = s_exit[bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
                 first = bad;
+#ifdef BSC_CHAIN_PROFILE
+                ++n_again;
+#endif
             }
             st = s_exit[NWV - 1];                               // the state after the tile (every thread reads the same entry)
             __syncthreads();                                    // before the next tile's pass overwrites the shared arrays
@@ -1076,9 +1178,17 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const RunOrder o, int64
         st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
         st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
         st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
-        chain_rounds(o, p_rec, k, k1, k1, st, lane);
+        chain_rounds<REC8>(o, p_rec, k, k1, k1, st, lane, gc, s_exp);
         if (lane == 0) chain_finish(st, vid, s, k1 - 1, o, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
+#ifdef BSC_CHAIN_PROFILE
+    CP_T(4)
+    if (threadIdx.x == 0 && (blockIdx.x < 2 || (blockIdx.x & 127) == 100 || blockIdx.x == gridDim.x - 1))
+        printf("k_chain_long wg %4d: hot segs %d of %lld, tiles %d (+%d repeated passes): load+alpha %lld  A+barriers %lld  B %lld  barrier+check %lld | other %lld"
+               " (clocks) | wall %lld .. %lld (10 ns)\n", (int)blockIdx.x, n_hotseg, (long long)nhot, n_tiles, n_again, cph[0], cph[1], cph[2], cph[3], cph[4],
+               wall0 % 100000000ll, wall_clock64() % 100000000ll);
+#endif
+#undef CP_T
 }
 
 // ---- runs -> per-voxel point order ---------------------------------------------------------------------------------
@@ -1268,10 +1378,11 @@ __global__ __launch_bounds__(TPB) void k_seg_order(int64_t *bscal, const uint32_
 }
 
 // top-down map colour: the voxel whose (h, order) won the cell writes the rgb of its latest point
+template <bool REC8>
 __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const int4 *__restrict__ seg_info,
                                               const int32_t *__restrict__ seg_last,
                                               const int32_t *__restrict__ rgb_pos, const u64 *__restrict__ hmap,
-                                              const PointRec *__restrict__ p_rec, uint8_t *__restrict__ cv_map, int gs,
+                                              const void *__restrict__ p_rec, uint8_t *__restrict__ cv_map, int gs,
                                               int64_t order_base)
 {
     const int64_t nseg = bscal[0];
@@ -1282,7 +1393,7 @@ __global__ __launch_bounds__(TPB) void k_hwin(const int64_t *bscal, const int4 *
         const int64_t rc = (int64_t)row * gs + col;
         const u64 packed = ((u64)(h + 1) << 40) | (u64)(order_base + last_j);
         if (hmap[rc] == packed) {
-            const uint32_t v = p_rec[last_j].rgbv;
+            const uint32_t v = REC8 ? ((const uint2 *)p_rec)[last_j].x : ((const PointRec *)p_rec)[last_j].rgbv;
             cv_map[3 * rc + 0] = (uint8_t)(v & 0xff);
             cv_map[3 * rc + 1] = (uint8_t)((v >> 8) & 0xff);
             cv_map[3 * rc + 2] = (uint8_t)((v >> 16) & 0xff);
@@ -1364,9 +1475,14 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     // per SIMD (workgroups of 8) slow the tail itself: 6 -> 9 ms.
     stat_begin(x, BSC_STAT_CHAIN, x->side);
     static const int chain_waves = getenv("BSC_CHAIN_WAVES") ? atoi(getenv("BSC_CHAIN_WAVES")) : CHAIN_WAVES;
-    hipLaunchKernelGGL(k_chain, dim3(chain_waves * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, x->sval_b_s[set], x->bscal_s[set], x->seg_info_s[set],
-                       x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set], x->c.grid_size,
-                       x->chain_order_base);
+    const bool rec8 = x->rec8_s[set];           // the record format of the call whose chain this is
+    const GeomConst gc = make_geom_const(x);
+#define BSC_LAUNCH_CHAIN(R8)                                                                                                    \
+    hipLaunchKernelGGL(k_chain<R8>, dim3(chain_waves * 64 / CHAIN_WG), dim3(CHAIN_WG), 0, x->side, gc, x->sval_b_s[set],         \
+                       x->bscal_s[set], x->seg_info_s[set], (const void *)x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, \
+                       x->seg_last_s[set], x->c.grid_size, x->chain_order_base)
+    if (rec8) BSC_LAUNCH_CHAIN(true); else BSC_LAUNCH_CHAIN(false);
+#undef BSC_LAUNCH_CHAIN
     static const int long_waves = getenv("BSC_LONG_WAVES") ? atoi(getenv("BSC_LONG_WAVES")) : LONG_WAVES;
     // a wavefront per ~4096 points of the batch, at most long_waves (a frame-by-frame call launches a handful)
     int64_t nw = x->chain_points / 4096;
@@ -1374,17 +1490,19 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 16;
     if (x->long_chain) {
         const RunOrder ro = {x->run_bits_s[set], x->ck_run_s[set], x->ck_start_s[set], x->run_val_s[set]};
-        if (long_nwv == 16)
-            hipLaunchKernelGGL(k_chain_long<16>, dim3((unsigned)((nw + 15) / 16)), dim3(1024), 0, x->side, ro, x->bscal_s[set],
-                               x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
-                               x->c.grid_size, x->chain_order_base);
-        else
-            hipLaunchKernelGGL(k_chain_long<8>, dim3((unsigned)((nw + 7) / 8)), dim3(512), 0, x->side, ro, x->bscal_s[set],
-                               x->seg_info_s[set], x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight, x->hmap, x->seg_last_s[set],
-                               x->c.grid_size, x->chain_order_base);
+#define BSC_LAUNCH_LONG(NWVV, R8)                                                                                               \
+    hipLaunchKernelGGL((k_chain_long<NWVV, R8>), dim3((unsigned)((nw + NWVV - 1) / NWVV)), dim3(NWVV * 64), 0, x->side, gc, ro,  \
+                       x->bscal_s[set], x->seg_info_s[set], (const void *)x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight,        \
+                       x->hmap, x->seg_last_s[set], x->c.grid_size, x->chain_order_base)
+        if (long_nwv == 16) { if (rec8) BSC_LAUNCH_LONG(16, true); else BSC_LAUNCH_LONG(16, false); }
+        else { if (rec8) BSC_LAUNCH_LONG(8, true); else BSC_LAUNCH_LONG(8, false); }
+#undef BSC_LAUNCH_LONG
     }
-    hipLaunchKernelGGL(k_hwin, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],
-                       x->rgb_pos, x->hmap, x->p_rec_s[set], x->cv_map, x->c.grid_size, x->chain_order_base);
+#define BSC_LAUNCH_HWIN(R8)                                                                                                     \
+    hipLaunchKernelGGL(k_hwin<R8>, dim3(256), dim3(TPB), 0, x->side, x->bscal_s[set], x->seg_info_s[set], x->seg_last_s[set],    \
+                       x->rgb_pos, x->hmap, (const void *)x->p_rec_s[set], x->cv_map, x->c.grid_size, x->chain_order_base)
+    if (rec8) BSC_LAUNCH_HWIN(true); else BSC_LAUNCH_HWIN(false);
+#undef BSC_LAUNCH_HWIN
     stat_end(x, BSC_STAT_CHAIN, 0.0, x->side);
     BSC_HIP(hipEventRecord(x->ev_done[set], x->side));
     x->ev_done_valid[set] = true;
@@ -1437,20 +1555,24 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     int32_t *g_cell = x->log_cap ? x->log_cell + x->log_n : (int32_t *)nullptr;    // bsc_point_log_*: cells in record order
     stat_begin(x, BSC_STAT_INGEST);
     stat_begin(x, BSC_STAT_POINTS);
-#define BSC_LAUNCH_POINTS(FASTV, RPWV, PLAINV)                                                                                 \
-    hipLaunchKernelGGL((k_points<FASTV, RPWV, PLAINV>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, \
-                       x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, p_rec, r2f, x->new_cells, x->dscal,     \
+#define BSC_LAUNCH_POINTS(FASTV, RPWV, PLAINV, R8)                                                                             \
+    hipLaunchKernelGGL((k_points<FASTV, RPWV, PLAINV, R8>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, \
+                       x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, (void *)p_rec, r2f, x->new_cells, x->dscal, \
                        x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
     const bool plain = !idx && !patf && !r2f && !alpha && !g_cell;
-#define BSC_LAUNCH_POINTS_R(FASTV, PLAINV)                                                                                     \
+    // 8-byte records {rgb, index in block, depth offset} where the depth range allows (bsc_create), alpha left to the rgb chain
+    const bool rec8 = gc.fast && plain && x->rec8_ok;
+    x->rec8_s[set] = rec8;
+#define BSC_LAUNCH_POINTS_R(FASTV, PLAINV, R8)                                                                                 \
     do {                                                                                                                       \
-        if (x->group_rpw == 16) BSC_LAUNCH_POINTS(FASTV, 16, PLAINV);                                                          \
-        else if (x->group_rpw == 8) BSC_LAUNCH_POINTS(FASTV, 8, PLAINV);                                                       \
-        else BSC_LAUNCH_POINTS(FASTV, 4, PLAINV);                                                                              \
+        if (x->group_rpw == 16) BSC_LAUNCH_POINTS(FASTV, 16, PLAINV, R8);                                                      \
+        else if (x->group_rpw == 8) BSC_LAUNCH_POINTS(FASTV, 8, PLAINV, R8);                                                   \
+        else BSC_LAUNCH_POINTS(FASTV, 4, PLAINV, R8);                                                                          \
     } while (0)
-    if (gc.fast && plain) BSC_LAUNCH_POINTS_R(true, true);
-    else if (gc.fast) BSC_LAUNCH_POINTS_R(true, false);
-    else BSC_LAUNCH_POINTS_R(false, false);
+    if (rec8) BSC_LAUNCH_POINTS_R(true, true, true);
+    else if (gc.fast && plain) BSC_LAUNCH_POINTS_R(true, true, false);
+    else if (gc.fast) BSC_LAUNCH_POINTS_R(true, false, false);
+    else BSC_LAUNCH_POINTS_R(false, false, false);
 #undef BSC_LAUNCH_POINTS_R
 #undef BSC_LAUNCH_POINTS
     stat_end(x, BSC_STAT_POINTS, 0.0);
