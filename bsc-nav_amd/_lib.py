@@ -40,6 +40,7 @@ SIGNATURES = {
     "bsc_flush": (_I32, [_VP, DRAW_FN, _VP]),
     "bsc_counters": (_I32, [_VP, _VP]),
     "bsc_geometry": (_I32, [_VP, _VP, _VP, _VP, _I64] + [_VP] * 8),
+    "bsc_sort_pairs_u32": (_I32, [_VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP]),
     "bsc_export_rgb": (_I32, [_VP, _VP, _VP, _VP]),
     "bsc_export_occupied": (_I32, [_VP, _VP]),
     "bsc_export_heightmap": (_I32, [_VP, _VP, _VP]),

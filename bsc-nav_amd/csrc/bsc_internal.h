@@ -49,6 +49,18 @@ enum {
     DS_COUNT = 18
 };
 
+// workspace of the in-tree radix sort (radix.hip), one per stream that sorts
+struct RadixWs {
+    u64 *status;               // per tile and digit: epoch << 32 | state << 30 | count
+    uint32_t *partial;         // histogram partials of the workgroups of k_radix_hist
+    uint32_t *gpartial;        // ... added up per group of 32 workgroups
+    uint32_t *goff;            // (4, 256) exclusive digit offsets of the passes
+    uint32_t *tickets;         // [0] k_radix_hist's last-group ticket, [1 + p] the tile ticket of pass p, [8 + g] the ticket of group g
+    uint32_t *tmp_k, *tmp_v;   // intermediate passes
+    size_t max_items;
+    uint32_t epoch;            // host counter: one value per (sort, pass)
+};
+
 struct bsc_ctx {
     bsc_config c;
     int device;
@@ -187,6 +199,8 @@ struct bsc_ctx {
     void *prim_tmp;
     size_t prim_tmp_bytes;
     void *prim_tmp_side;       // second rocPRIM workspace: the order pipeline sorts on the side stream beside the pair sort
+    RadixWs rx_main, rx_side;  // in-tree radix sort: the pair sort (main stream) and the run sort (side stream) may run at the same time
+    bool radix_intree;         // BSC_SORT_ROCPRIM=1: both sorts through rocPRIM as until round 5
     bool order_on_side;        // per-voxel point order (k_runs .. k_seg_order) on the side stream (BSC_ORDER_MAIN=1 keeps it on the main stream)
     hipEvent_t ev_ids, ev_runs;   // voxel ids assigned; side: k_runs has read the call's cells / block offsets
     hipEvent_t ev_tot;            // main: k_totals done (the call's run / new-voxel counts exist)
@@ -228,6 +242,11 @@ bsc_status prim_sort_pairs_u32(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, 
                                size_t n, int begin_bit, int end_bit);
 bsc_status prim_sort_pairs_u32_onesweep(bsc_ctx *x, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                                         size_t n, int begin_bit, int end_bit);
+// in-tree onesweep radix sort of (u32 key, u32 value) pairs on the key bits [b0, b1): stable, input preserved (radix.hip)
+bsc_status radix_ws_create(RadixWs *ws, size_t max_items);
+void radix_ws_destroy(RadixWs *ws);
+bsc_status radix_sort_pairs_u32(bsc_ctx *x, RadixWs *ws, hipStream_t st, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                                uint32_t *vout, size_t n, int b0, int b1);
 bsc_status prim_exclusive_sum_i64(bsc_ctx *x, const int64_t *in, int64_t *out, size_t n);
 bsc_status prim_exclusive_sum_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);
 bsc_status prim_inclusive_max_i32(bsc_ctx *x, const int32_t *in, int32_t *out, size_t n);

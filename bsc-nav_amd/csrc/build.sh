@@ -14,7 +14,7 @@ if [ ! -f "$OBJ/host_rng.o" ] || [ "$HERE/host_rng.cpp" -nt "$OBJ/host_rng.o" ] 
   ( g++ -O3 -std=c++17 -fPIC -Wall -I"$HERE/../../include" -c "$HERE/host_rng.cpp" -o "$OBJ/host_rng.o" ) &
   pids+=($!)
 fi
-for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_gemm capi; do
+for f in prims radix ingest dense flush localize cluster frontier encoder_ops encoder_gemm capi; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/bsc_internal.h" -nt "$obj" ] || [ "$HERE/geometry_dev.h" -nt "$obj" ] || [ "$HERE/../../include/bscnav.h" -nt "$obj" ]; then
     ( hipcc $FLAGS -c "$src" -o "$obj" ) &
@@ -22,5 +22,5 @@ for f in prims ingest dense flush localize cluster frontier encoder_ops encoder_
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/prims.o "$OBJ"/ingest.o "$OBJ"/dense.o "$OBJ"/flush.o "$OBJ"/localize.o "$OBJ"/cluster.o "$OBJ"/frontier.o "$OBJ"/encoder_ops.o "$OBJ"/encoder_gemm.o "$OBJ"/host_rng.o "$OBJ"/capi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/prims.o "$OBJ"/radix.o "$OBJ"/ingest.o "$OBJ"/dense.o "$OBJ"/flush.o "$OBJ"/localize.o "$OBJ"/cluster.o "$OBJ"/frontier.o "$OBJ"/encoder_ops.o "$OBJ"/encoder_gemm.o "$OBJ"/host_rng.o "$OBJ"/capi.o
 echo "built $OUT"

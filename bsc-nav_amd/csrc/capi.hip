@@ -306,6 +306,8 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     e = hipMalloc(&x->prim_tmp_side, x->prim_tmp_bytes);
     if (e != hipSuccess) { bsc_set_error("hipMalloc prim workspace: %s", hipGetErrorString(e)); bsc_destroy(x); return BSC_E_HIP; }
     x->order_on_side = getenv("BSC_ORDER_MAIN") == nullptr;
+    x->radix_intree = getenv("BSC_SORT_ROCPRIM") == nullptr;
+    if (radix_ws_create(&x->rx_main, (size_t)prim_items) != BSC_OK || radix_ws_create(&x->rx_side, (size_t)prim_items) != BSC_OK) { bsc_destroy(x); return BSC_E_HIP; }
     BSC_HIP(hipEventCreateWithFlags(&x->ev_ids, hipEventDisableTiming));
     BSC_HIP(hipEventCreateWithFlags(&x->ev_runs, hipEventDisableTiming));
     BSC_HIP(hipEventCreateWithFlags(&x->ev_tot, hipEventDisableTiming));
@@ -341,6 +343,8 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->run_bits_s[0], x->run_bits_s[1], x->ck_run_s[0], x->ck_run_s[1], x->ck_start_s[0], x->ck_start_s[1], x->run_val_s[0], x->run_val_s[1]};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    radix_ws_destroy(&x->rx_main);
+    radix_ws_destroy(&x->rx_side);
     if (x->hscal) hipHostFree(x->hscal);
     if (x->side) hipStreamDestroy(x->side);
     if (x->ev_ids) hipEventDestroy(x->ev_ids);
@@ -495,6 +499,16 @@ extern "C" bsc_status bsc_geometry(bsc_ctx *x, const float *depth_dev, const dou
     }
     hipFree(flags); hipFree(pc); hipFree(pg); hipFree(vox); hipFree(pix); hipFree(pat); hipFree(r2); hipFree(al);
     return st;
+}
+
+// parity entry of the in-tree radix sort (radix.hip): device arrays in, device arrays out, on the context's stream
+extern "C" bsc_status bsc_sort_pairs_u32(bsc_ctx *x, const uint32_t *keys_dev, const uint32_t *vals_dev, int64_t n, int32_t begin_bit,
+                                         int32_t end_bit, uint32_t *keys_out_dev, uint32_t *vals_out_dev)
+{
+    if (!x || n < 0 || (n > 0 && (!keys_dev || !vals_dev || !keys_out_dev || !vals_out_dev)) || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit)
+        return BSC_E_INVALID;
+    BSC_HIP(hipSetDevice(x->device));
+    return radix_sort_pairs_u32(x, &x->rx_main, x->stream, keys_dev, keys_out_dev, vals_dev, vals_out_dev, (size_t)n, begin_bit, end_bit);
 }
 
 // ---- exports ---------------------------------------------------------------------------------------

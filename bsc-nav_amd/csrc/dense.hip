@@ -1092,7 +1092,10 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         const CellCode cc = make_cell_code32(x);
         uint32_t *pair_idx = (uint32_t *)x->pair_key_b, *idx_sorted = pair_idx + x->pair_cap;
         stat_begin(x, BSC_STAT_PAIRSORT);
-        BSC_TRY(prim_sort_pairs_u32_onesweep(x, x->pair_cnt_a, x->pair_cnt_b, pair_idx, idx_sorted, (size_t)n_pairs, 0, cell_code_bits(cc)));
+        if (x->radix_intree)
+            BSC_TRY(radix_sort_pairs_u32(x, &x->rx_main, s, x->pair_cnt_a, x->pair_cnt_b, pair_idx, idx_sorted, (size_t)n_pairs, 0, cell_code_bits(cc)));
+        else
+            BSC_TRY(prim_sort_pairs_u32_onesweep(x, x->pair_cnt_a, x->pair_cnt_b, pair_idx, idx_sorted, (size_t)n_pairs, 0, cell_code_bits(cc)));
         BSC_TRY(compact_heads_u32(x, x->pair_cnt_b, n_pairs, x->pseg_start, x->dscal + DS_B_NPSEG));
         stat_end(x, BSC_STAT_PAIRSORT, 0.0);
         stat_begin(x, BSC_STAT_DENSE);

@@ -1682,7 +1682,11 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     // ids in use are < max_id; runs without a voxel carry an all-ones id field, which sorts last under the bit mask
     const int vid_bits = ceil_log2_u64((uint64_t)x->hscal[DS_MAX_ID] + 2);
     if (R > 0) {        // a batch without a single passing point has no runs (k_totals left the segment count at 0)
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_s[set], (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
+        if (x->radix_intree)
+            BSC_TRY(radix_sort_pairs_u32(x, side_order ? &x->rx_side : &x->rx_main, so, x->skey_a, skey_b, x->sval_a, x->run_val_s[set], (size_t)R, 0,
+                                         vid_bits < vb ? vid_bits : vb));
+        else
+            BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, skey_b, x->sval_a, x->run_val_s[set], (size_t)R, 0, vid_bits < vb ? vid_bits : vb));
         const int64_t neb = (R + EB - 1) / EB;
         hipLaunchKernelGGL(k_run_blocksum, dim3((unsigned)neb), block, 0, so, R, vb, skey_b, x->run_scan);
         BSC_TRY(prim_exclusive_sum_i64(x, x->run_scan, x->run_scan + neb, (size_t)neb));
@@ -1695,8 +1699,13 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (n_bound > seg_cap) n_bound = seg_cap;
     hipLaunchKernelGGL(k_seg_bounds, dim3(64), block, 0, so, x->bscal_s[set], n_bound, x->seg_k0, x->seg_vid,
                        x->seg_info_s[set], x->skey_a, x->sval_a);
-    if (n_bound > 0)
-        BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
+    if (n_bound > 0) {
+        if (x->radix_intree)
+            BSC_TRY(radix_sort_pairs_u32(x, side_order ? &x->rx_side : &x->rx_main, so, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid,
+                                         (size_t)n_bound, 0, 6));
+        else
+            BSC_TRY(prim_sort_pairs_u32(x, x->skey_a, (uint32_t *)x->seg_k0, x->sval_a, (uint32_t *)x->seg_vid, (size_t)n_bound, 0, 6));
+    }
     static const int long_log2 = getenv("BSC_LONG_LOG2") ? atoi(getenv("BSC_LONG_LOG2")) : LONG_MIN_LOG2;
     static const int hot_log2 = getenv("BSC_NO_HOT_SPLIT") ? 0 : (getenv("BSC_HOT_LOG2") ? atoi(getenv("BSC_HOT_LOG2")) : HOT_MIN_LOG2);
     hipLaunchKernelGGL(k_seg_order, dim3(64), block, 0, so, x->bscal_s[set], (const uint32_t *)x->seg_k0, (const uint32_t *)x->seg_vid,

@@ -149,6 +149,13 @@ class VoxelEngine:
                                          _hp(o["alpha"])))
         return o
 
+    def sort_pairs_u32(self, keys, vals, begin_bit=0, end_bit=32):
+        """The library's stable radix sort of (u32 key, u32 value) pairs on the key bits [begin_bit, end_bit): int32 CUDA tensors
+        (bit patterns) in, sorted copies out."""
+        ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+        _lib.check(self.lib.bsc_sort_pairs_u32(self.h, _dp(keys), _dp(vals), keys.numel(), begin_bit, end_bit, _dp(ko), _dp(vo)))
+        return ko, vo
+
     # ---- exports / imports -------------------------------------------------------------------
     def export_rgb(self):
         n = self.counters()["max_id"]

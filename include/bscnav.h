@@ -111,6 +111,12 @@ bsc_status bsc_geometry(bsc_ctx *ctx, const float *depth_dev, const double *tran
                         double *pg_host, int32_t *vox_host, int32_t *pix_host, int32_t *pat_host,
                         double *r2_host, double *alpha_host);
 
+/* the stable radix sort of (u32 key, u32 value) pairs on the key bits [begin_bit, end_bit) that orders a voxel's points and
+ * tokens inside bsc_ingest (memory_2.py:888-903: colour and mean of a voxel are defined by the order of its points) — exposed for
+ * the parity tests; device arrays, input preserved, at most max(max_points, voxel_capacity + 1) items, on the context's stream */
+bsc_status bsc_sort_pairs_u32(bsc_ctx *ctx, const uint32_t *keys_dev, const uint32_t *vals_dev, int64_t n, int32_t begin_bit,
+                              int32_t end_bit, uint32_t *keys_out_dev, uint32_t *vals_out_dev);
+
 /* on-disk layout exchange (memory_2.py:1136-1145 save, :189-200 load); host buffers sized from bsc_counters */
 bsc_status bsc_export_rgb(bsc_ctx *ctx, int32_t *pos_host, uint8_t *rgb_host, float *weight_host);
 bsc_status bsc_export_occupied(bsc_ctx *ctx, int32_t *occ_host /* (gs,gs,max_h-min_h) */);
