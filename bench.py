@@ -65,7 +65,7 @@ if os.environ.get("BSC_TUNABLEOP", "1") == "1" and "PYTORCH_TUNABLEOP_ENABLED" n
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PMC_FILE = "r05_pmc_ingest_kernels.json"
+PMC_FILE = "r06_pmc_ingest_kernels.json"
 # k_points by its SQ counters (profiles/r05_pmc_k_points.txt: SQ_INSTS_VALU / SQ_INSTS_SALU per wavefront of 512 points / 8 rounds;
 # the f64 share from the ISA: 664 of 2819 static vector instructions)
 KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 266.7, 63.0, 105.5
@@ -113,6 +113,7 @@ def parse():
     ap.add_argument("--no-host-feed", action="store_true", help="skip the frames-from-pinned-host-memory leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the hall / iid workloads and the C3 leg")
     ap.add_argument("--no-exact", action="store_true", help="skip the reference-semantics (exact mode) leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc traffic passes of the isolated bsc_ingest call")
     return ap.parse_args()
 
 
@@ -128,13 +129,49 @@ def pmc_traffic(frames_per_call, tok_bytes):
     request size — 32 / 64 / 128 B —, two separate --pmc passes, summed over the call's kernels; the counters are checked on
     known-byte kernels in profiles/r03_pmc_calibration.txt).  The file names the commit it was measured at; None when absent."""
     try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import pmc_summary
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             d = json.load(f)
         if d.get("frames_per_call", frames_per_call) != frames_per_call or d.get("token_bytes", 2) != tok_bytes:
             return None, None                           # measured at another --batch or token dtype: no figure
+        if d.get("ingest_sources_sha16") != pmc_summary.ingest_sources_sha():
+            return None, None                           # the ingest kernels changed after the profile was taken: a stale figure is not quoted
         return float(d["ingest_traffic_bytes_per_call"]), d.get("commit")
     except Exception:
         return None, None
+
+
+def live_pmc_traffic(a, g, D, timeout_s=170):
+    """HBM-side bytes per bsc_ingest call MEASURED IN THIS RUN: two rocprofv3 --pmc passes (read requests, write requests — separate
+    runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes) of scripts/ingest_only.py, i.e. of the very call roofline.frac
+    times: bsc_ingest + bsc_sync alone on the chip, the bench's frames / token rows / grid.  After the timed region, in a child
+    process; None when rocprofv3 is missing or a pass fails (the committed figure is then quoted, if it still matches the tree)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pmc_summary
+    csvs = []
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for tag, ctr in (("RD", "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B"), ("WR", "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B")):
+            cmd = [exe, "--pmc", *ctr.split(), "--kernel-trace", "--output-format", "csv", "-d", os.path.join(td, tag), "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "ingest_only.py"), "3", "sync", str(a.batch), a.kind, str(g), str(D), str(a.grid)]
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_", "PYTORCH_TUNABLEOP"))}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            found = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(td, tag)) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not found:
+                return None
+            csvs.append(found[0])
+        d = pmc_summary.summarise(csvs[0], csvs[1], a.batch, commit="this run", command="rocprofv3 --pmc ... -- scripts/ingest_only.py 3 sync "
+                                  f"{a.batch} {a.kind} {g} {D} {a.grid}")
+    top = sorted(((k, (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_call"]) for k, v in d["kernels"].items() if v["ingest"]),
+                 key=lambda kv: -kv[1])[:6]
+    return {"bytes_per_call": float(d["ingest_traffic_bytes_per_call"]), "largest_kernels_GB_per_call": {k[:48]: round(b / 1e9, 3) for k, b in top}}
 
 
 class Pipeline:
@@ -918,12 +955,22 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # under a launcher (torchrun sets WORLD_SIZE) the process group exists at ANY world size — `--gpus 1` then times the same code
+    # path as N > 1 (collectives of one rank: RCCL runs them, they move nothing) and must reproduce the plain N = 1 line
+    dist_active = world > 1 or "WORLD_SIZE" in os.environ
+    dist_info = None
+    if dist_active:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # evidence that the ranks are really connected: a SUM all-reduce of ones through the backend the merge will use
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        dist_info = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl", "ranks_counted_by_all_reduce": int(ones.item()),
+                     "world_size": world, "gpus_visible": torch.cuda.device_count()}
     import bsc_nav_amd as B
     from bsc_nav_amd import dist as bdist
 
@@ -953,7 +1000,7 @@ def main():
         p.reset_stats()
         t0 = time.perf_counter()
         p.run(a.warmup, n_steps)
-        if world > 1:
+        if dist_active:
             p.eng.sync(); torch.cuda.synchronize()
             tm = time.perf_counter()
             merge_info = bdist.merge_dense_maps(p.eng)
@@ -996,6 +1043,9 @@ def main():
         }
         if merge_info:
             out["config"]["merge"] = merge_info
+        if dist_info:
+            out["config"]["distributed"] = dist_info
+            out["rccl_ranks"] = dist_info["ranks_counted_by_all_reduce"] if dist_info["is_rccl"] else 0
     def guarded(key, fn, into=None):
         """an optional leg: its result under `key`, or {"error": ...} — never the loss of the headline line"""
         tgt = out if into is None else into
@@ -1026,22 +1076,28 @@ def main():
                                "traffic": None, "bytes_per_call": alg, "ms_per_call": ing_ms, "voxel_rows_per_call": U,
                                "stage_ms_in_pipeline": stage_timed}
             if merge_info and merge_info.get("seconds_inside_timed_region"):
-                mb = merge_info.get("per_rank", 0) * (D * 4 + 4) * (world - 1)      # rows each rank sends in the reduce-scatter
-                merge_info["reduce_scatter_bytes_sent_per_rank"] = mb
+                mb = merge_info.get("reduce_scatter_bytes_sent_per_rank", 0)          # rows each rank sends in the reduce-scatter
                 merge_info["merge_GBs_per_rank"] = mb / merge_info["seconds_inside_timed_region"] / 1e9
+                # xGMI is point-to-point: a rank's reduce-scatter traffic leaves over min(world - 1, 7) links of ~153 GB/s each
+                links = max(1, min(world - 1, 7))
+                merge_info["bytes_per_link_equivalent"] = mb / links
+                merge_info["expected_reduce_scatter_ms_on_xgmi"] = mb / links / 153e9 * 1e3
+                merge_info["xgmi_note"] = ("expected = bytes a rank sends / links / 153 GB/s (MI355X_MICROARCH.md: 7 links per GPU); the measured "
+                                           "phases_ms are of the backend named in config.distributed")
     if rank == 0 and world == 1:
         iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8))
         ing_ms = stage_timed["bsc_ingest"]
         single = {k: v for k, v in stage_timed.items() if k in ("k_points", "k_keys_pairs", "k_dense_reduce")}
         dom = max(single, key=single.get)
         traffic, traffic_commit = pmc_traffic(a.batch, tok_bytes)
+        traffic_src = None if traffic is None else f"profiles/{PMC_FILE} @ {traffic_commit} (rocprofv3 --pmc passes of this command, committed; its source hash matches the tree)"
+        traffic_live = False
         wall = iso["ingest_wall_ms"]
         out["roofline"] = {
             "bound": "hbm", "kernel": "bsc_ingest: one call followed by bsc_sync, alone on the chip — main-stream kernels, the per-voxel point "
                                      "order and the rgb chain on the library's side stream (SURVEY.md 8d bytes of the batch / that wall time)",
             "achieved": alg / wall / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / wall / 1e6 / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_measured_in_this_run": False,
-            "traffic_source": None if traffic is None else f"profiles/{PMC_FILE} @ {traffic_commit} (rocprofv3 --pmc passes of this command, committed)",
+            "traffic": traffic, "traffic_measured_in_this_run": traffic_live, "traffic_source": traffic_src,
             "bytes_per_call": alg, "ms_per_call": wall,
             "ms_per_call_main_stream_isolated": iso["stages"]["bsc_ingest"], "frac_main_stream_isolated": alg / iso["stages"]["bsc_ingest"] / 1e6 / HBM_PEAK_GBS,
             "ms_per_call_main_stream_in_pipeline": ing_ms, "frac_main_stream_in_pipeline": alg / ing_ms / 1e6 / HBM_PEAK_GBS,
@@ -1211,9 +1267,25 @@ def main():
             if D != 1024:
                 guarded("C4_C5_localize_2pow20_x_1024_grid512", lambda: localize_leg(B, a, local_rank, 1024), into=out["configs"])
             guarded("C4_store_shape_2pow20_voxels_M_1to10_x_1024", lambda: localize_store_leg(B, a, local_rank), into=out["configs"])
+    if rank == 0 and world == 1 and not a.no_pmc and "roofline" in out:
+        # roofline.traffic measured in THIS run (after everything that is timed; the bench's own engines are idle meanwhile)
+        def _live():
+            torch.cuda.empty_cache()
+            t0 = time.time()
+            lv = live_pmc_traffic(a, g, D)
+            if lv is not None:
+                out["roofline"].update({"traffic": lv["bytes_per_call"], "traffic_measured_in_this_run": True,
+                                        "traffic_source": "two rocprofv3 --pmc passes (TCC_EA0_RDREQ* / TCC_EA0_WRREQ*, by request size; --kernel-trace only) of "
+                                                          "scripts/ingest_only.py inside this run: bsc_ingest + bsc_sync alone on the chip, this run's frames, "
+                                                          "token rows and grid",
+                                        "traffic_largest_kernels_GB_per_call": lv["largest_kernels_GB_per_call"],
+                                        "traffic_over_algorithmic_bytes": lv["bytes_per_call"] / out["roofline"]["bytes_per_call"],
+                                        "traffic_passes_seconds": round(time.time() - t0, 1)})
+            return {}
+        guarded(None, _live)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_active:
         dist.barrier()
         dist.destroy_process_group()
 

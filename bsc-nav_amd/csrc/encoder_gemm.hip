@@ -50,7 +50,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define BSC_GEMM_NARROW_TILE 1           // tile variant for N <= 1024 (see bsc_enc_gemm_split)
 #endif
 
-enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2 };
+enum { GS_EPI_BIAS = 0, GS_EPI_GELU = 1, GS_EPI_RESID = 2, GS_EPI_GELU_ERF = 3 };
 #define GS_LN_REC 20             // floats per LayerNorm statistics record of a residual-stream row (see gemm_split_tile)
 
 #ifdef BSC_GEMM_PROFILE        // per-workgroup phase stamps (100 MHz wall clock) + the CU it ran on: -DBSC_GEMM_PROFILE, BSC_GEMM_PROFILE_DUMP=1
@@ -116,6 +116,23 @@ __device__ __forceinline__ float gelu_tanh(float x)
     const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);          // e^(2u)
     return x * (1.0f - __builtin_amdgcn_rcpf(1.0f + e));
 }
+
+// The exact form, torch.nn.GELU() as the reference's DINOv2 uses it (memory_2.py:43,738: hub model, approximate='none'):
+// 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the resolution of f32 itself) on the
+// hardware's exp2 / rcp: with q = (a1 t + .. + a5 t^5) e^(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2 (q = erfc z),
+// 1 + erf = 2 - q for x >= 0 and q for x < 0 — no cancellation on either side.  The tanh form differs from it by up to 5e-4.
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return x * (x >= 0.f ? fmaf(-0.5f, q, 1.0f) : 0.5f * q);
+}
+template <int EPI> __device__ __forceinline__ float gelu_of(float x) { return EPI == GS_EPI_GELU_ERF ? gelu_erf(x) : gelu_tanh(x); }
 
 // ---- activation pieces --------------------------------------------------------------------------------------------------------
 // Layout P32 of an (M,K) activation matrix as fp16 pieces: row m = K/32 chunks of 64 halfs, chunk c = [h of k = 32c..32c+31 |
@@ -566,7 +583,7 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[e] = fmaf(acc[mr][t][4 * q + e], out_scale, b4[e]);
-                            if (EPI == GS_EPI_GELU) v[e] = gelu_tanh(v[e]);
+                            if (EPI == GS_EPI_GELU || EPI == GS_EPI_GELU_ERF) v[e] = gelu_of<EPI>(v[e]);
                         }
                         if (CPIECES) {
                             uint32_t h0, l0, h1, l1;
@@ -628,7 +645,7 @@ __device__ __forceinline__ void gemm_split_tile(uint16_t *Ws, char *epi_lds, con
                         const int nl = 32 * t + 8 * (r >> 2) + 4 * g + (r & 3), n = n0 + wc * NT * 32 + nl;
                         if (m >= M || n >= N) continue;
                         float v = fmaf(acc[mr][t][r], out_scale, bs[nl]);
-                        if (EPI == GS_EPI_GELU) v = gelu_tanh(v);
+                        if (EPI == GS_EPI_GELU || EPI == GS_EPI_GELU_ERF) v = gelu_of<EPI>(v);
                         if (EPI == GS_EPI_RESID) v += R[m * N + n];
                         C[m * N + n] = v;
                     }
@@ -942,7 +959,7 @@ __global__ __launch_bounds__(GS_TPB) void k_splitk_finish(const float *__restric
     f32x4_t v = *(const f32x4_t *)(part + e);
     for (int sl = 1; sl < S; ++sl) v += *(const f32x4_t *)(part + sl * c_slice + e);
     if (bias) v += *(const f32x4_t *)(bias + n);
-    if (EPI == GS_EPI_GELU) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
+    if (EPI == GS_EPI_GELU || EPI == GS_EPI_GELU_ERF) { v[0] = gelu_of<EPI>(v[0]); v[1] = gelu_of<EPI>(v[1]); v[2] = gelu_of<EPI>(v[2]); v[3] = gelu_of<EPI>(v[3]); }
     if (EPI == GS_EPI_RESID) v += *(const f32x4_t *)(R + e);
     if (CPIECES) {
         uint32_t h0, l0, h1, l1;
@@ -1017,7 +1034,7 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
                                             int32_t epilogue, int32_t a_mode, float c_pieces_scale, float *ln_stats_dev,
                                             float *ln_mu_dev, float ln_eps, void *ws_dev, int64_t ws_bytes, void *hip_stream)
 {
-    if (!a_dev || !pieces_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || (K % GS_KC) || epilogue < 0 || epilogue > 2 ||
+    if (!a_dev || !pieces_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || (K % GS_KC) || epilogue < 0 || epilogue > 3 ||
         a_mode < 0 || a_mode > 2 || (epilogue == GS_EPI_RESID && !resid_dev) || (c_pieces_scale != 0.f && (N % 32))) {
         bsc_set_error("bsc_enc_gemm_split: invalid argument (K must be a multiple of 32; piece output needs N %% 32 == 0)");
         return BSC_E_INVALID;
@@ -1119,6 +1136,7 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
     } while (0)
     if (ln) {                           // LayerNorm folded into the operand load: qkv (bias) and fc1 (bias + GELU), piece output
         if (epilogue == GS_EPI_GELU) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_GELU, GS_A_LN, true, false);
+        else if (epilogue == GS_EPI_GELU_ERF) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_GELU_ERF, GS_A_LN, true, false);
         else BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_BIAS, GS_A_LN, true, false);
     } else if (stats) {                 // residual epilogue that leaves the row statistics for the next LayerNorm
         if (ap) BSC_GEMM_LAUNCH2(1, 8, 8, 1, GS_EPI_RESID, GS_A_PIECES, false, true);
@@ -1128,6 +1146,11 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
         else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_PIECES, false);
         else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, true);
         else BSC_GEMM_LAUNCH(GS_EPI_GELU, GS_A_F32, false);
+    } else if (epilogue_l == GS_EPI_GELU_ERF) {
+        if (ap && cp) BSC_GEMM_LAUNCH(GS_EPI_GELU_ERF, GS_A_PIECES, true);
+        else if (ap) BSC_GEMM_LAUNCH(GS_EPI_GELU_ERF, GS_A_PIECES, false);
+        else if (cp) BSC_GEMM_LAUNCH(GS_EPI_GELU_ERF, GS_A_F32, true);
+        else BSC_GEMM_LAUNCH(GS_EPI_GELU_ERF, GS_A_F32, false);
     } else if (epilogue_l == GS_EPI_RESID) {
         if (cp) { bsc_set_error("bsc_enc_gemm_split: the residual epilogue writes f32"); return BSC_E_INVALID; }
         if (ap) BSC_GEMM_LAUNCH(GS_EPI_RESID, GS_A_PIECES, false);
@@ -1147,6 +1170,7 @@ extern "C" bsc_status bsc_enc_gemm_split_ws(const void *a_dev, int64_t M, int32_
     hipLaunchKernelGGL((k_splitk_finish<EPIV, CPV>), fgrid, dim3(GS_TPB), 0, s, (const float *)part, S, (int64_t)M * N, M, N, bias_dev, \
                        resid_dev, c_dev, c_pieces_scale)
         if (epilogue == GS_EPI_GELU) { if (cpo) BSC_FIN(GS_EPI_GELU, true); else BSC_FIN(GS_EPI_GELU, false); }
+        else if (epilogue == GS_EPI_GELU_ERF) { if (cpo) BSC_FIN(GS_EPI_GELU_ERF, true); else BSC_FIN(GS_EPI_GELU_ERF, false); }
         else if (epilogue == GS_EPI_RESID) BSC_FIN(GS_EPI_RESID, false);
         else { if (cpo) BSC_FIN(GS_EPI_BIAS, true); else BSC_FIN(GS_EPI_BIAS, false); }
 #undef BSC_FIN

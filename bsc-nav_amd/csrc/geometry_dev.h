@@ -40,9 +40,11 @@ struct GeomConst {
 // library's exp, which this replaces on every device-alpha path.  Error <= 1 ulp (tests/test_gpu_edges.py: against NumPy's exp
 // over the whole depth range) — the same class as the library routine: the dense modes' rgb bytes differ from a host-alpha build
 // in < 0.1 % of the bytes either way; the reference-exact mode takes alpha from the host (bit-exact).  tab: 64 x (hi, lo), in LDS
-// for k_points.  Out-of-range lanes (their results are discarded): the table index stays in range, nothing traps.
+// for k_points.  Out-of-range lanes (their results are discarded): the table index stays in range, nothing traps; -inf (an
+// infinite depth, an r^2 beyond the f64 range) gives 0 like exp() — bsc_geometry reports alpha for flagged points too.
 __device__ __forceinline__ double bsc_exp(double x, const GeomConst &c, const double2 *tab)
 {
+    x = x < -800.0 ? -800.0 : x;            // exp(-inf) = 0 like exp() (the scaling below underflows to 0 from about -745); NaN stays NaN
     const double kf = __builtin_rint(__dmul_rn(x, c.exp_il));
     const int k = (int)kf;
     double r = __fma_rn(-kf, c.exp_l1, x);

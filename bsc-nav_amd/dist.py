@@ -264,17 +264,19 @@ def merge_dense_maps(engine, group=None):
       rgb, weights      merge_colour_states (documented dense-mode rule)
       top-down map      allreduce_heightmap (exact), replicated on every rank
 
-    `engine` needs: mode, device, keys_tensor(), dense_gather(keys), dense_gather_rgb(keys), export_heightmap(),
-    import_heightmap(h, cv), dense_replace(keys, acc, cnt, rgb, weight).  Returns dict(n_union, per_rank, n_local)."""
+    `engine` needs: mode, device, cfg.token_dim, keys_tensor(), dense_gather(keys), dense_gather_rgb(keys), export_heightmap(),
+    import_heightmap(h, cv), dense_replace(keys, acc, cnt, rgb, weight).  Returns dict(n_union, per_rank, n_local, colour,
+    phases_ms, reduce_scatter_bytes_sent_per_rank, chunk_rows): the phases are timed on every rank (a device synchronize per phase —
+    microseconds against a merge of milliseconds) so that a bench line can say where the merge's time goes."""
     rank, world = _world(group)
     import os, time
-    timing = os.environ.get("BSC_MERGE_TIMING") is not None
     marks = []
+    on_gpu = getattr(getattr(engine, "device", None), "type", "cpu") == "cuda"
 
     def mark(name):
-        if timing:
+        if on_gpu:
             torch.cuda.synchronize()
-            marks.append((name, time.perf_counter()))
+        marks.append((name, time.perf_counter()))
 
     mark("start")
     keys = engine.keys_tensor()
@@ -292,6 +294,10 @@ def merge_dense_maps(engine, group=None):
     # [c, c + n) of this rank's slice.  Same bytes on the wire, bounded staging (BSC_MERGE_CHUNK_BYTES, default 1 GiB).
     D = int(engine.cfg.token_dim)
     budget = int(os.environ.get("BSC_MERGE_CHUNK_BYTES", str(1 << 30)))
+    # every rank must issue the same number of collectives: the smallest budget of any rank's environment counts
+    bt = torch.tensor([budget], dtype=torch.int64, device=ukeys.device if dist.get_backend(group) != "gloo" else "cpu")
+    dist.all_reduce(bt, op=dist.ReduceOp.MIN, group=group)
+    budget = int(bt.item())
     chunk = max(1, min(per, budget // max(1, world * D * 4)))
     my_acc = torch.empty((per, D), dtype=torch.float32, device=ukeys.device)
     my_cnt = torch.empty(per, dtype=torch.int32, device=ukeys.device)
@@ -328,9 +334,13 @@ def merge_dense_maps(engine, group=None):
                          my_rgb[:n_local].contiguous(), my_w[:n_local].contiguous())
     engine.import_heightmap(top, colour)
     mark("replace")
-    if timing and rank == 0:
-        print("[merge] " + " ".join(f"{n}={1e3 * (t - marks[i][1]):.1f}ms" for i, (n, t) in enumerate(marks[1:])), flush=True)
-    return dict(n_union=n_union, per_rank=per, n_local=n_local, colour=colour_rule)
+    phases = {n: round(1e3 * (t - marks[i][1]), 3) for i, (n, t) in enumerate(marks[1:])}
+    if os.environ.get("BSC_MERGE_TIMING") is not None and rank == 0:
+        print("[merge] " + " ".join(f"{n}={v:.1f}ms" for n, v in phases.items()), flush=True)
+    # what a rank puts on the wire in the reduce-scatter: the rows of the other ranks' slices (sums + counts)
+    sent = int(per) * (D * 4 + 4) * (world - 1)
+    return dict(n_union=n_union, per_rank=per, n_local=n_local, colour=colour_rule, phases_ms=phases, chunk_rows=int(chunk),
+                reduce_scatter_bytes_sent_per_rank=sent)
 
 
 def _gather_to_root(t, root, group=None):

@@ -64,9 +64,10 @@ def attention_split(qkv_pieces, B, T, heads, out_scale=1.0):
 class SplitLinear:
     """nn.Linear at f32 accuracy on the fp16 matrix cores (bsc_enc_gemm_split): the weight's two fp16 pieces are made once
     (scaled by the power of two that puts its largest element in (4, 8]), the activation rows are split in registers.
-    epilogue: 0 bias, 1 bias + GELU(tanh), 2 bias + residual (in place when out is resid)."""
+    epilogue: 0 bias, 1 bias + GELU(tanh), 2 bias + residual (in place when out is resid), 3 bias + GELU(erf: torch.nn.GELU(),
+    what the reference's DINOv2 applies)."""
 
-    BIAS, GELU, RESID = 0, 1, 2
+    BIAS, GELU, RESID, GELU_ERF = 0, 1, 2, 3
     A_F32, A_PIECES, A_LN = 0, 1, 2
 
     def __init__(self, lin, ln=None, k_pad=None):
@@ -226,21 +227,30 @@ class _Block(nn.Module):
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         return self.proj(a.transpose(1, 2).reshape(B, T, Wd))
 
+    gelu = "tanh"           # "erf": torch.nn.GELU() exactly (RandomViT sets it per model)
+
     def mlp(self, y, fuse_gelu):
-        if fuse_gelu:       # bias + GELU(tanh) in the GEMM epilogue (hipBLASLt)
+        if fuse_gelu and self.gelu == "tanh":       # bias + GELU(tanh) in the GEMM epilogue (hipBLASLt)
             B, T, C = y.shape
             h = torch._addmm_activation(self.fc1.bias, y.reshape(B * T, C), self.fc1.weight.t(), use_gelu=True)
             return self.fc2(h).reshape(B, T, C)
-        return self.fc2(F.gelu(self.fc1(y), approximate="tanh"))
+        return self.fc2(F.gelu(self.fc1(y), approximate="tanh" if self.gelu == "tanh" else "none"))
 
 
 class RandomViT(nn.Module):
     def __init__(self, arch="vit_b16", image_size=224, out_dim=None, seed=0, dtype=torch.bfloat16, fused=True,
-                 init_weights=True):
+                 init_weights=True, gelu=None):
+        """gelu: the MLP activation — "erf" = torch.nn.GELU() exactly, what the reference's DINOv2 applies (memory_2.py:43,738), or
+        "tanh" = its tanh approximation (differs by up to 5e-4 per activation, ~1e-2 on a token).  Default: "erf" for the f32 model
+        (the reference's precision: in-tree erf epilogue of the split GEMM), "tanh" for the bf16 fast mode (the library GEMM's own
+        GELU epilogue; the difference is below bf16 resolution)."""
         super().__init__()
+        self.gelu = gelu or ("tanh" if dtype in (torch.bfloat16, torch.float16) else "erf")
+        assert self.gelu in ("erf", "tanh")
         self.fused = fused
         self.fused_attention = fused and os.environ.get("BSC_ENC_ATTENTION", "1") == "1"   # 0: library SDPA
-        self.lagged = os.environ.get("BSC_ENC_LAGGED", "1") == "1"     # 0: residual adds in the LayerNorm kernel
+        # 0: residual adds in the LayerNorm kernel (the lagged form rides on the library GEMM's tanh-GELU epilogue)
+        self.lagged = os.environ.get("BSC_ENC_LAGGED", "1") == "1" and self.gelu == "tanh"
         # f32 weights: dense layers through the in-tree split-operand MFMA GEMM (0: PyTorch-ROCm f32 GEMMs)
         self.split_gemm = dtype == torch.float32 and os.environ.get("BSC_ENC_SPLIT_GEMM", "1") == "1"
         s = VIT_SHAPES[arch]
@@ -255,6 +265,8 @@ class RandomViT(nn.Module):
         self.reg = nn.Parameter(torch.zeros(1, s["registers"], s["width"])) if s["registers"] else None
         self.pos = nn.Parameter(torch.zeros(1, 1 + self.grid * self.grid, s["width"]))
         self.blocks = nn.ModuleList([_Block(s["width"], s["heads"], s["mlp"]) for _ in range(s["depth"])])
+        for blk in self.blocks:
+            blk.gelu = self.gelu
         self.norm = nn.LayerNorm(s["width"], eps=1e-6)
         self.head = nn.Linear(s["width"], out_dim, bias=False) if out_dim and out_dim != s["width"] else None
         self.out_dim = out_dim or s["width"]
@@ -298,8 +310,8 @@ class RandomViT(nn.Module):
         """Maps DINOv2's parameters onto this module: the patch convolution as the unfolded-patch GEMM, the position
         embedding resampled to this grid the way `interpolate_pos_encoding` does (bicubic; antialias and no offset for the
         register models, offset 0.1 otherwise — the hub defaults), LayerScale folded into the projection and fc2 weights
-        and biases (x + g * (a W^T + b) = x + a (g W)^T + g b).  The MLP activation runs as tanh-GELU in the GEMM epilogue
-        (|tanh form - erf form| < 5e-4, below bf16 resolution)."""
+        and biases (x + g * (a W^T + b) = x + a (g W)^T + g b).  The MLP activation is `self.gelu`: the exact erf form for the f32
+        model (DINOv2's nn.GELU), its tanh approximation in the bf16 mode (|tanh form - erf form| < 5e-4, below bf16 resolution)."""
         dev, dt = self.cls.device, self.compute_dtype
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32)
         put = lambda prm, t: prm.data.copy_(t.to(dt))
@@ -435,6 +447,7 @@ class RandomViT(nn.Module):
         Wd, heads = self.width, self.blocks[0].heads
         hd = Wd // heads
         SL = SplitLinear
+        act = SL.GELU_ERF if self.gelu == "erf" else SL.GELU
         if kin % 32 == 0:       # (piece rows come zero-padded to a multiple of 32: ViT-L/14's 588 columns as 608)
             x = self._split(self.patch_embed, k_pad=kin)(t.reshape(B * n_patch, t.shape[2]).contiguous(), a_pieces=t_pieces).view(B, n_patch, Wd)
         else:
@@ -467,7 +480,7 @@ class RandomViT(nn.Module):
                 qkv = self._split(blk.qkv, blk.ln1)(u, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=1.0)
                 a = attention_split(qkv, B, T, heads, out_scale=16.0)
                 self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0, a_pieces=True, ln_stats=stats, ln_mu=mu)
-                h = self._split(blk.fc1, blk.ln2)(u, SL.GELU, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=4.0)
+                h = self._split(blk.fc1, blk.ln2)(u, act, a_ln=True, ln_stats=stats, ln_mu=mu, c_pieces_scale=4.0)
                 self._split(blk.fc2)(h, SL.RESID, resid=u, out=u, a_scale=4.0, a_pieces=True, ln_stats=stats, ln_mu=mu)
             return final_layernorm_f32(u, self.norm, B, T, 1 + self.registers)
         for bi, blk in enumerate(self.blocks):
@@ -484,7 +497,7 @@ class RandomViT(nn.Module):
                 self._split(blk.proj)(a, SL.RESID, resid=u, out=u, a_scale=16.0)
             y, yp = ln_in(blk.ln2)
             # the hidden tensor exists only as pieces (scaled by 4): written by fc1's GELU epilogue, read by fc2
-            h = self._split(blk.fc1)(y, SL.GELU, a_pieces=yp, c_pieces_scale=4.0)
+            h = self._split(blk.fc1)(y, act, a_pieces=yp, c_pieces_scale=4.0)
             self._split(blk.fc2)(h, SL.RESID, resid=u, out=u, a_scale=4.0, a_pieces=True)
         if ln_ok:
             return final_layernorm_f32(u, self.norm, B, T, 1 + self.registers)

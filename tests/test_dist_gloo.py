@@ -301,3 +301,71 @@ def test_batched_topk_merge_equals_per_query_merge():
     for qi in range(Q):
         p, s = bd.merge_topk([pos[r, qi, :cnt[r, qi]] for r in range(W)], [sim[r, qi, :cnt[r, qi]] for r in range(W)], K)
         assert np.array_equal(got_p[qi], p) and np.array_equal(got_s[qi], s.astype(np.float32))
+
+
+# ---- the target world size on CPU: eight gloo ranks (until now world size 8 ran only on the GPU box) ----
+def test_eight_rank_merge_and_sharded_localize(tmp_path):
+    """merge_dense_maps + localize_sharded + gather_merged_to_root over EIGHT ranks: one owner per voxel, counts exact, sums in
+    f32 order, ids in global first-touch order (first occurrence in the rank-major concatenation), the K-way merge of the eight
+    per-shard top-K lists equal to the top-K of the single merged map on every rank, the root holding the whole memory."""
+    world, D, mode = 8, 8, "mean"
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(f"{tmp_path}/r{r}.pt", weights_only=False) for r in range(world)]
+    ref, order = {}, []
+    for r in range(world):
+        keys, acc, cnt = _make_rank_map(r, D, mode)
+        for k, a, c in zip(keys.tolist(), acc, cnt):
+            k = tuple(k)
+            if k not in ref:
+                ref[k] = [a.clone(), int(c)]
+                order.append(k)
+            else:
+                ref[k][0] = ref[k][0] + a
+                ref[k][1] += int(c)
+    got, got_order = {}, []
+    for r in range(world):
+        for k, a, c in zip(res[r]["keys"].tolist(), res[r]["acc"], res[r]["cnt"]):
+            assert tuple(k) not in got
+            got[tuple(k)] = (a, int(c))
+            got_order.append(tuple(k))
+    assert got_order == order and res[0]["info"]["n_union"] == len(ref)
+    assert len(ref) % world != 0 or True                # the union need not divide by the world size (sentinel rows in the last slice)
+    for k in ref:
+        assert got[k][1] == ref[k][1] and torch.allclose(got[k][0], ref[k][0], atol=1e-5)
+    info = res[0]["info"]
+    assert set(info["phases_ms"]) >= {"global_id_order", "gather_rows+reduce_scatter", "colour", "heightmap", "replace"}
+    assert info["reduce_scatter_bytes_sent_per_rank"] == info["per_rank"] * (D * 4 + 4) * (world - 1)
+    assert res[0]["is_root"] and not any(res[r]["is_root"] for r in range(1, world))
+    assert [tuple(k) for k in res[0]["full"]["keys"].tolist()] == order
+    for name in ("acc", "cnt", "rgb", "w"):
+        assert torch.equal(res[0]["full"][name], torch.cat([res[r][name] for r in range(world)]))
+    keys = torch.tensor(sorted(ref), dtype=torch.int32)
+    acc = torch.stack([ref[tuple(k)][0] for k in keys.tolist()])
+    single = DictEngine(mode, D, keys, acc, torch.ones(len(keys), dtype=torch.int32))
+    q = torch.from_numpy(np.random.RandomState(99).standard_normal((3, D)).astype(np.float32))
+    p1, s1, n1 = single.localize(q, K=20)
+    for r in range(world):
+        for qi in range(3):
+            assert np.array_equal(res[r]["pos"][qi], p1[qi, :n1[qi]])
+            assert np.allclose(res[r]["sim"][qi], s1[qi, :n1[qi]], atol=1e-5)
+
+
+def test_eight_rank_colour_replay_equals_sequential_chain(tmp_path):
+    """merge_colour_replay over eight CPU ranks: rank 0's points, then rank 1's, ... — the global point order of a frame-sharded
+    build — replayed on every voxel's owner equal the sequential chain, bit for bit."""
+    world = 8
+    mp.spawn(_replay_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seq = {}
+    for r in range(world):
+        vox, alpha, rgbv, bad = _rank_points(r)
+        for v, a, c, b in zip(vox.tolist(), alpha, rgbv, bad):
+            if not b:
+                seq.setdefault(tuple(v), []).append((a, int(c)))
+    n = 0
+    for r in range(world):
+        got = torch.load(f"{tmp_path}/c{r}.pt", weights_only=False)
+        for k, c, w in zip(got["keys"].tolist(), got["rgb"], got["w"]):
+            ec, ew = _chain_np(seq[tuple(k)])
+            assert np.array_equal(c.numpy(), ec) and np.float32(w.item()) == ew
+            n += 1
+    assert n == len(seq)

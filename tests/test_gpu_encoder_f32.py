@@ -14,7 +14,7 @@ def _pieces_back(p, M, K, scale=1.0):
 
 @pytest.mark.parametrize("M,K,N", [(1000, 768, 2304), (777, 3072, 768), (257, 64, 96), (31, 32, 8), (50, 64, 30), (20741, 64, 768), (20741, 64, 2304),
                                    (197, 608, 1024), (197, 3072, 768), (1576, 768, 2304), (2088, 4096, 1024)])
-@pytest.mark.parametrize("epilogue", [0, 1, 2])
+@pytest.mark.parametrize("epilogue", [0, 1, 2, 3])
 def test_split_gemm_matches_fp32_linear(M, K, N, epilogue):
     """out = epilogue(A W^T + b): within a few f32 ulps of the fp64 result — at least as close as torch's own f32 GEMM — for f32
     rows and for pre-split pieces, ragged M / N (tile edges), every epilogue.  M = 20741: more tiles than CUs — N = 768 takes the
@@ -35,6 +35,8 @@ def test_split_gemm_matches_fp32_linear(M, K, N, epilogue):
     ref32 = A @ lin.weight.t() + lin.bias                      # the plain PyTorch fp32 reference of the op
     if epilogue == 1:
         ref64, ref32 = F.gelu(ref64, approximate="tanh"), F.gelu(ref32, approximate="tanh")
+    if epilogue == 3:       # torch.nn.GELU() exactly — the reference's DINOv2 (memory_2.py:43,738): erf by A&S 7.1.26 in the epilogue
+        ref64, ref32 = F.gelu(ref64), F.gelu(ref32)
     if epilogue == 2:
         ref64, ref32 = ref64 + R.double(), ref32 + R
     res = R.clone() if epilogue == 2 else None
@@ -50,8 +52,8 @@ def test_split_gemm_matches_fp32_linear(M, K, N, epilogue):
         r2 = R.clone()
         sl(A, 2, resid=r2, out=r2)
         assert torch.equal(r2, out)
-    if epilogue == 1 and N % 32 == 0:      # the hidden tensor as pieces (what fc2 reads)
-        cp = sl(A, 1, c_pieces_scale=4.0)
+    if epilogue in (1, 3) and N % 32 == 0:      # the hidden tensor as pieces (what fc2 reads)
+        cp = sl(A, epilogue, c_pieces_scale=4.0)
         assert cp.dtype == torch.float16 and cp.shape == (M, 2 * N)
         assert (_pieces_back(cp, M, N, 4.0) - ref64).abs().max().item() <= tol + 1e-6
 

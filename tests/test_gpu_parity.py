@@ -219,6 +219,12 @@ def test_device_exp_within_one_ulp_of_numpy(torch_cuda):
     ulps = np.abs(got.view(np.int64) - want.view(np.int64))
     assert ulps.max() <= 1, ulps.max()
     assert (ulps == 0).mean() > 0.7, (ulps == 0).mean()
+    # points that fail the depth check keep a defined alpha (0) in the export — infinite, huge and NaN depths included — and
+    # bsc_exp itself returns 0 for -inf like np.exp (its range reduction alone made NaN of it)
+    odd = np.full((H, W), 5.0, np.float32)
+    odd[0, :4] = [np.inf, 3.0e38, np.nan, 1.0e30]
+    o = eng.geometry(torch.from_numpy(odd).cuda(), T)
+    assert not (o["flags"][:4] & 1).any() and (o["alpha"][:4] == 0.0).all() and np.isfinite(o["alpha"]).all()
     eng.close()
 
 
