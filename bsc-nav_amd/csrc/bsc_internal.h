@@ -188,6 +188,8 @@ struct bsc_ctx {
     float2 *l_rscale;
     int64_t l_rscale_cap;
     bool row_scale_dirty;
+    bool rscale_from_reduce;        // the last ingest's dense reduce wrote the scale / inverse norm of every row it finished
+                                    // (k_dense_reduce_voxels): the scan's k_row_scale pass is then only needed after imports
     int last_nq, last_K;            // shape of the last bsc_localize call (its top-K stays resident for clustering)
     int32_t last_counts[1024];
     // frontier helpers (allocated on first use, gs*gs each)
@@ -205,6 +207,8 @@ struct bsc_ctx {
     hipEvent_t ev_ids, ev_runs;   // voxel ids assigned; side: k_runs has read the call's cells / block offsets
     hipEvent_t ev_tot;            // main: k_totals done (the call's run / new-voxel counts exist)
     hipStream_t copy;             // early readback of those counts while the main stream goes on with the pair tiles
+    void *h2d_pin[4];             // pinned staging of the pageable-host imports (capi.hip h2d_pipelined), allocated on first use
+    hipEvent_t h2d_ev[4];
     bool ev_runs_valid;
     int last_order_set;        // scratch set of the last order stage enqueued on the side stream (-1: none): its ev_ready marks it complete
     // bookkeeping
@@ -263,6 +267,19 @@ __device__ __forceinline__ float4 load_tok4(const bf16_t *row, int v)
     const uint2 raw = ((const uint2 *)row)[v];
     return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
                        __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u));
+}
+
+// (power-of-two operand scale, 1 / (norm scale 2^11)) of a token row from the sum of its squares: what the fp16-piece batched scan
+// (localize.hip k_cosine_f16x2) reads per row; computed by k_row_scale (one pass over the rows) and, row by row, by the dense reduce
+__device__ __forceinline__ float2 bsc_row_scale_of(float sumsq)
+{
+    const float nrm = sqrtf(sumsq);
+    int e = 0;
+    if (nrm > 0.f && nrm < INFINITY) (void)frexpf(nrm, &e);          // nrm = m 2^e, m in [0.5, 1)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float sc = (nrm > 0.f && nrm < INFINITY) ? ldexpf(1.0f, 12 - e) : 1.0f;     // norm * sc in [2^11, 2^12)
+    // the result leaves as acc * (1 / (sc 2^11)) / max(norm, 1e-8): the two powers of two are exact factors
+    return make_float2(sc, (1.0f / fmaxf(nrm, 1e-8f)) / sc * (1.0f / 2048.0f));
 }
 
 bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const uint8_t *rgb, int32_t rgb_ch,

@@ -7,6 +7,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#define BSC_H2D_NBUF 4                          // pinned staging buffers of h2d_pipelined (imports from pageable host memory)
+static const size_t BSC_H2D_CHUNK = (size_t)(getenv("BSC_H2D_CHUNK_MB") ? atoi(getenv("BSC_H2D_CHUNK_MB")) : 64) << 20;
+
 #define TPB 256
 
 static thread_local char g_err[512] = "";
@@ -94,7 +101,9 @@ static bsc_status reset_state(bsc_ctx *x)
     x->n_flush = 0;
     x->pool_n_host = 0;
     x->order_base = 0;
-    x->names_dirty = true; x->row_scale_dirty = true;
+    x->names_dirty = true;
+    // an empty dense map has no row whose scale could be stale: the reduce keeps the cache current from the first ingest on
+    x->row_scale_dirty = !(x->c.mode != BSC_MODE_EXACT && x->l_rscale && x->l_rscale_cap >= (int64_t)sizeof(float2) * (vcap + 1));
     x->log_n = 0;
     x->log_stale = false;
     return BSC_OK;
@@ -251,6 +260,8 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     } else {
         ALLOC(x->acc, vcap * D);
         ALLOC(x->acnt, vcap + 1);
+        ALLOC(x->l_rscale, vcap + 1);           // row scales of the batched scan, kept current by the dense reduce (8 B per voxel)
+        x->l_rscale_cap = (int64_t)sizeof(float2) * (vcap + 1);
     }
     ALLOC(x->p_cell, np); ALLOC(x->p_patf, np); ALLOC(x->p_r2f, np);
     ALLOC(x->skey_a, np); ALLOC(x->sval_a, np);
@@ -343,6 +354,9 @@ extern "C" void bsc_destroy(bsc_ctx *x)
                     x->run_bits_s[0], x->run_bits_s[1], x->ck_run_s[0], x->ck_run_s[1], x->ck_start_s[0], x->ck_start_s[1], x->run_val_s[0], x->run_val_s[1]};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    for (int b = 0; b < BSC_H2D_NBUF; ++b) {
+        if (x->h2d_pin[b]) { hipHostFree(x->h2d_pin[b]); hipEventDestroy(x->h2d_ev[b]); }
+    }
     radix_ws_destroy(&x->rx_main);
     radix_ws_destroy(&x->rx_side);
     if (x->hscal) hipHostFree(x->hscal);
@@ -400,9 +414,14 @@ extern "C" bsc_status bsc_ingest_typed(bsc_ctx *x, int32_t n_frames, const float
     BSC_HIP(hipSetDevice(x->device));
     BSC_HIP(hipMemcpyAsync(x->d_transforms, transforms_host, sizeof(double) * 16 * n_frames, hipMemcpyHostToDevice,
                            x->stream));
-    x->names_dirty = true; x->row_scale_dirty = true;
+    x->names_dirty = true;
+    const bool scales_were_current = !x->row_scale_dirty;
+    x->row_scale_dirty = true;
+    x->rscale_from_reduce = false;
     bsc_status st = ingest_batch(x, n_frames, depth_dev, rgb_dev, rgb_channels, tokens_dev, token_dtype, sample_idx_dev,
                                  offsets_host, alpha_dev, draw, user);
+    // the per-voxel dense reduce leaves the scale / inverse norm of every row it wrote: the cache stays current across ingests
+    if (st == BSC_OK && scales_were_current && x->rscale_from_reduce) x->row_scale_dirty = false;
     return st;
 }
 
@@ -744,6 +763,64 @@ extern "C" bsc_status bsc_import_rgb(bsc_ctx *x, int64_t max_id, const int32_t *
     return BSC_OK;
 }
 
+// ---- host -> device at link speed from PAGEABLE memory ---------------------------------------------------------------------------
+// load_memory hands over NumPy arrays (memory_2.py:189-200: np.load of a memory directory; a 512^3 scene's token store is 20+ GB).
+// hipMemcpy from pageable memory stages through one driver thread: 4.6 GB/s on this box against the 57 GB/s a pinned copy reaches.
+// Here a few host threads copy slices of a chunk into one of four pinned buffers while the DMA engine drains the previous ones
+// (hipMemcpyAsync + an event per buffer): the copy runs at what the host's memory and the link deliver together.
+static bsc_status h2d_pipelined(bsc_ctx *x, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return BSC_OK;
+    if (bytes < 4 * BSC_H2D_CHUNK) {            // small: not worth the threads
+        BSC_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+        return BSC_OK;
+    }
+    if (!x->h2d_pin[0]) {
+        for (int b = 0; b < BSC_H2D_NBUF; ++b) {
+            BSC_HIP(hipHostMalloc(&x->h2d_pin[b], BSC_H2D_CHUNK));
+            BSC_HIP(hipEventCreateWithFlags(&x->h2d_ev[b], hipEventDisableTiming));
+        }
+    }
+    int nthr = getenv("BSC_H2D_THREADS") ? atoi(getenv("BSC_H2D_THREADS")) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && nthr > hw) nthr = hw;
+    nthr = nthr < 1 ? 1 : (nthr > 32 ? 32 : nthr);
+    const size_t n_chunks = (bytes + BSC_H2D_CHUNK - 1) / BSC_H2D_CHUNK;
+    std::atomic<int> arrive{0};
+    std::atomic<int> failed{0};
+    // sense-reversing barrier over the nthr workers (spin + yield: the phases between barriers are a few milliseconds)
+    auto barrier = [&](int &phase) {
+        const int target = (++phase) * nthr;
+        arrive.fetch_add(1, std::memory_order_acq_rel);
+        while (arrive.load(std::memory_order_acquire) < target) std::this_thread::yield();
+    };
+    auto worker = [&](int t) {
+        (void)hipSetDevice(x->device);
+        int phase = 0;
+        for (size_t c = 0; c < n_chunks; ++c) {
+            const int b = (int)(c % BSC_H2D_NBUF);
+            const size_t off = c * BSC_H2D_CHUNK, n = bytes - off < BSC_H2D_CHUNK ? bytes - off : BSC_H2D_CHUNK;
+            if (t == 0 && c >= BSC_H2D_NBUF && hipEventSynchronize(x->h2d_ev[b]) != hipSuccess) failed.store(1);
+            barrier(phase);                                 // buffer b is free again
+            const size_t per = ((n + nthr - 1) / nthr + 63) & ~(size_t)63, lo = per * t < n ? per * t : n, hi = lo + per < n ? lo + per : n;
+            if (hi > lo) memcpy((char *)x->h2d_pin[b] + lo, (const char *)src_host + off + lo, hi - lo);
+            barrier(phase);                                 // chunk c is staged
+            if (t == 0) {
+                if (hipMemcpyAsync((char *)dst_dev + off, x->h2d_pin[b], n, hipMemcpyHostToDevice, x->copy) != hipSuccess ||
+                    hipEventRecord(x->h2d_ev[b], x->copy) != hipSuccess)
+                    failed.store(1);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthr; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool) th.join();
+    BSC_HIP(hipStreamSynchronize(x->copy));
+    if (failed.load()) { bsc_set_error("h2d_pipelined: a staged copy failed"); return BSC_E_HIP; }
+    return BSC_OK;
+}
+
 extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const int32_t *pos, const int32_t *cnt,
                                        const float *feats, const float *dists)
 {
@@ -777,8 +854,12 @@ extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const
     if (st == BSC_OK) {
         e = hipMemcpy(x->store_cnt, h_cnt, sizeof(int32_t) * (vcap + 1), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(x->store_rows, h_rows, sizeof(int32_t) * (vcap + 1) * cs, hipMemcpyHostToDevice);
-        if (e == hipSuccess && nt) e = hipMemcpy(x->pool, feats, sizeof(float) * nt * D, hipMemcpyHostToDevice);
-        if (e == hipSuccess && nt) e = hipMemcpy(x->pool_d, dists, sizeof(float) * nt, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nt) {
+            // the token rows: the large array (sum M x D x 4 bytes), staged through pinned buffers at link speed
+            e = hipStreamSynchronize(x->stream);
+            if (e == hipSuccess) st = h2d_pipelined(x, x->pool, feats, sizeof(float) * (size_t)nt * D);
+            if (e == hipSuccess && st == BSC_OK) st = h2d_pipelined(x, x->pool_d, dists, sizeof(float) * (size_t)nt);
+        }
         if (e == hipSuccess) e = hipMemcpy(x->dscal + DS_POOL_N, &nt, sizeof(int64_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) { bsc_set_error("bsc_import_store: %s", hipGetErrorString(e)); st = BSC_E_HIP; }
     }
@@ -795,7 +876,8 @@ extern "C" bsc_status bsc_import_dense(bsc_ctx *x, int64_t max_id, const float *
     BSC_TRY(read_scalars(x));
     if (max_id != x->hscal[DS_MAX_ID]) { bsc_set_error("bsc_import_dense: call bsc_import_rgb first (max_id mismatch)"); return BSC_E_INVALID; }
     if (max_id == 0) return BSC_OK;
-    BSC_HIP(hipMemcpy(x->acc, acc, sizeof(float) * max_id * x->c.token_dim, hipMemcpyHostToDevice));
+    BSC_HIP(hipStreamSynchronize(x->stream));
+    BSC_TRY(h2d_pipelined(x, x->acc, acc, sizeof(float) * (size_t)max_id * x->c.token_dim));
     BSC_HIP(hipMemcpy(x->acnt, cnt, sizeof(int32_t) * max_id, hipMemcpyHostToDevice));
     x->names_dirty = true; x->row_scale_dirty = true;
     return BSC_OK;

@@ -632,8 +632,12 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                                                              const TOK *__restrict__ tokens, int D,
                                                              float *__restrict__ acc_g, int32_t *__restrict__ acnt,
                                                              CellCode cc, const int32_t *__restrict__ occ,
-                                                             uint32_t row_lo, uint32_t row_hi, int later_pass)
+                                                             uint32_t row_lo, uint32_t row_hi, int later_pass,
+                                                             float2 *__restrict__ rscale)
 {
+    // rscale (may be null): per finished row the operand scale and inverse norm the batched localize scan reads (bsc_row_scale_of) —
+    // the wavefront holds the row in registers here, so the scan never needs its own pass over the map after an ingest (3.8 ms for
+    // 2^20 x 1024 rows, paid by the first query batch after every ingest until round 5).
     // [row_lo, row_hi): the token rows (frame * g^2 + patch) this launch reduces.  A call whose token tile is larger than the
     // 256 MB MALL is reduced in passes over slices of its frames (dense_reduce_batch): a voxel's pairs are in row order, so every
     // pass takes a contiguous stretch of its segment; passes after the first add to what the earlier ones stored.
@@ -760,6 +764,7 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
         const bool is_new = !later_pass && vid >= max_id_prev;
         if (total == 0 && !is_new) continue;                               // nothing of this voxel in this pass
         float4 *dst = (float4 *)(acc_g + vid * D);
+        float sq = 0.f;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int v = acc_slot<NV, PAIRED>(t, lane);
@@ -771,7 +776,12 @@ __global__ __launch_bounds__(TPB) void k_dense_reduce_voxels(const uint32_t *__r
                     else { o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
                 }
                 dst[v] = o;
+                sq = fmaf(o.x, o.x, sq); sq = fmaf(o.y, o.y, sq); sq = fmaf(o.z, o.z, sq); sq = fmaf(o.w, o.w, sq);
             }
+        }
+        if (rscale) {           // the same sum as k_row_scale forms (lane l: the columns 4 (l + 64 t) .., then the butterfly)
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            if (lane == 0) rscale[vid] = bsc_row_scale_of(sq);
         }
         if (lane == 0) acnt[vid] = (is_new ? 0 : acnt[vid]) + (int32_t)total;
     }
@@ -1142,10 +1152,17 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
         const int frames_per_pass = (n_frames + n_pass - 1) / n_pass;
         uint32_t row_lo = 0, row_hi = 0xffffffffu;
         int later_pass = 0;
+        // the rows' scale / inverse norm for the batched scan, while they are in registers (every voxel of the map was created by a
+        // point that left a pair: every row below max_id has been written by this kernel, unless an import / merge / reset wrote it)
+        float2 *rscale = nullptr;
+        if (x->l_rscale && x->l_rscale_cap >= (int64_t)sizeof(float2) * ((int64_t)x->c.voxel_capacity + 1) && !getenv("BSC_NO_RSCALE_IN_REDUCE")) {
+            rscale = x->l_rscale;
+            x->rscale_from_reduce = true;
+        }
 #define LVP(NVV, MODEV, TOKT, PAIR)                                                                                            \
     hipLaunchKernelGGL((k_dense_reduce_voxels<NVV, MODEV, TOKT, PAIR>), grid, block, 0, s, x->pair_cnt_b, idx_sorted, x->pair_key_a,  \
                        n_pairs, (const uint32_t *)x->pseg_start, x->dscal, (const TOKT *)tokens, D, x->acc, x->acnt, cc, x->occ,     \
-                       row_lo, row_hi, later_pass)
+                       row_lo, row_hi, later_pass, rscale)
 #define LV(NVV, MODEV, TOKT) LVP(NVV, MODEV, TOKT, false)
 #define LVM(NVV)                                                                                   \
     do {                                                                                           \

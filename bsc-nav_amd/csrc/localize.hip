@@ -459,15 +459,7 @@ __global__ __launch_bounds__(TPB) void k_row_scale(const float *__restrict__ X, 
         a = fmaf(v.x, v.x, a); a = fmaf(v.y, v.y, a); a = fmaf(v.z, v.z, a); a = fmaf(v.w, v.w, a);
     }
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) {
-        const float nrm = sqrtf(a);
-        int e = 0;
-        if (nrm > 0.f && nrm < INFINITY) (void)frexpf(nrm, &e);          // nrm = m 2^e, m in [0.5, 1)
-        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-        const float sc = (nrm > 0.f && nrm < INFINITY) ? ldexpf(1.0f, 12 - e) : 1.0f;     // norm * sc in [2^11, 2^12)
-        // the result leaves as acc * (1 / (sc 2^11)) / max(norm, 1e-8): the two powers of two are exact factors
-        rs[row] = make_float2(sc, (1.0f / fmaxf(nrm, 1e-8f)) / sc * (1.0f / FX_QSCALE));
-    }
+    if (lane == 0) rs[row] = bsc_row_scale_of(a);
 }
 
 // qn (Q, D) f32 unit rows -> qp (2, Q, D) fp16 pieces of 2^11 qn
