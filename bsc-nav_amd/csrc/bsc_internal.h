@@ -206,6 +206,8 @@ struct bsc_ctx {
     bool order_on_side;        // per-voxel point order (k_runs .. k_seg_order) on the side stream (BSC_ORDER_MAIN=1 keeps it on the main stream)
     hipEvent_t ev_ids, ev_runs;   // voxel ids assigned; side: k_runs has read the call's cells / block offsets
     hipEvent_t ev_tot;            // main: k_totals done (the call's run / new-voxel counts exist)
+    hipEvent_t ev_psort;          // main: the pair sort of the last call is done (the rgb chain starts behind it, launch_pending_chain)
+    bool ev_psort_valid;
     hipStream_t copy;             // early readback of those counts while the main stream goes on with the pair tiles
     void *h2d_pin[4];             // pinned staging of the pageable-host imports (capi.hip h2d_pipelined), allocated on first use
     hipEvent_t h2d_ev[4];

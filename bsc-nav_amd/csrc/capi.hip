@@ -322,6 +322,7 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     BSC_HIP(hipEventCreateWithFlags(&x->ev_ids, hipEventDisableTiming));
     BSC_HIP(hipEventCreateWithFlags(&x->ev_runs, hipEventDisableTiming));
     BSC_HIP(hipEventCreateWithFlags(&x->ev_tot, hipEventDisableTiming));
+    BSC_HIP(hipEventCreateWithFlags(&x->ev_psort, hipEventDisableTiming));
     BSC_HIP(hipStreamCreateWithFlags(&x->copy, hipStreamNonBlocking));
     for (int w = 0; w < BSC_STAT_SLOTS; ++w)
         for (int i = 0; i < 2 * BSC_EV_RING; ++i) BSC_HIP(hipEventCreate(&x->ev[w][i]));
@@ -364,6 +365,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     if (x->ev_ids) hipEventDestroy(x->ev_ids);
     if (x->ev_runs) hipEventDestroy(x->ev_runs);
     if (x->ev_tot) hipEventDestroy(x->ev_tot);
+    if (x->ev_psort) hipEventDestroy(x->ev_psort);
     if (x->copy) hipStreamDestroy(x->copy);
     for (int k = 0; k < 2; ++k) {
         if (x->ev_ready[k]) hipEventDestroy(x->ev_ready[k]);

@@ -1108,6 +1108,8 @@ bsc_status dense_reduce_batch(bsc_ctx *x, const void *tokens, int token_dtype, i
             BSC_TRY(prim_sort_pairs_u32_onesweep(x, x->pair_cnt_a, x->pair_cnt_b, pair_idx, idx_sorted, (size_t)n_pairs, 0, cell_code_bits(cc)));
         BSC_TRY(compact_heads_u32(x, x->pair_cnt_b, n_pairs, x->pseg_start, x->dscal + DS_B_NPSEG));
         stat_end(x, BSC_STAT_PAIRSORT, 0.0);
+        BSC_HIP(hipEventRecord(x->ev_psort, s));        // the rgb chain of this call starts behind the pair sort (launch_pending_chain)
+        x->ev_psort_valid = true;
         stat_begin(x, BSC_STAT_DENSE);
         const dim3 grid(256 * 8), block(TPB);
         {

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(const GeomConst gc, const ui
 // is the sequential one by construction.  A voxel that collects 2e5 points in a call takes ~3000 rounds of ~100
 // instructions instead of 2e5 dependent steps of ~28 (6 ms -> 0.5 ms), and the loads of a round are 64 independent
 // gathers instead of 4.
-#define LONG_WAVES 16384
+#define LONG_WAVES 32768
 #define HOT_RPT 8                                // rounds of 64 points per wavefront and tile of a hot segment (records held in registers)
 __device__ __forceinline__ float wave_incl_sum_f32(float x)
 {
@@ -867,6 +867,10 @@ __device__ __forceinline__ float wave_incl_sum_f32(float x)
 }
 
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int64_t rfl64(int64_t v)        // a wave-uniform 64-bit value into scalar registers
+{
+    return (int64_t)(((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)((u64)v >> 32)) << 32) | (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u64)v));
+}
 
 struct ChainState { float w; uint32_t c0, c1, c2; };
 
@@ -1033,8 +1037,12 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
                                                         float *__restrict__ weight, u64 *hmap, int32_t *__restrict__ seg_last,
                                                         int gs, int64_t order_base)
 {
-    __shared__ float s_sum[NWV];
-    __shared__ ChainState s_entry[NWV], s_exit[NWV];
+    __shared__ float s_sum[2][NWV];
+    __shared__ ChainState s_entry[2][NWV], s_exit[2][NWV];
+#ifndef BSC_CHAIN_TILES_V1
+    __shared__ double s_al[HOT_RPT][NWV * 64];           // the hot tile in flight: alpha and colour of every point (96 KB at 16 wavefronts)
+    __shared__ uint32_t s_rg[HOT_RPT][NWV * 64];
+#endif
     __shared__ double2 s_exp[REC8 ? 64 : 1];
     if (REC8) {
         if (threadIdx.x < 64) s_exp[threadIdx.x] = gc.exp_tab[threadIdx.x];
@@ -1070,10 +1078,122 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
         st.c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid]);
         st.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 1]);
         st.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb[3 * (int64_t)vid + 2]);
-        const int64_t klast = k1 - 1;
 #ifdef BSC_CHAIN_PROFILE
         ++n_hotseg;
 #endif
+#ifndef BSC_CHAIN_TILES_V1
+        // Tiles on the grid of the run order's 64-position WORDS (round 6).  A round of 64 lanes then lies in ONE word: its start
+        // bits and checkpoint are the same for all lanes — three scalar loads instead of three vector loads per lane (the look-up
+        // of a tile held 32 vector registers per wavefront) — and the phases of consecutive tiles overlap:
+        //   * the run gathers (j0) of tile t + 1 are issued before pass A of tile t and arrive under it and its barrier,
+        //   * the record gathers of tile t + 1 are issued behind that barrier and arrive under pass B of tile t,
+        //   * sums / entry / exit states alternate between two sets of shared arrays, so a tile needs TWO barriers (after the sums,
+        //     after the exits) instead of four: a wavefront that is through with its check goes on to the next tile's loads while
+        //     the others still step their rounds.
+        // Profile of the four-barrier form (wavefront 0, per tile of 8192 points, 33 k clocks): loads + alpha 6.5 k, pass A + barriers
+        // 10.4 k, pass B 6.3 k, barrier + check 10.2 k — two thirds of a tile were spent waiting.
+        k = rfl64(k);
+        const int64_t k1u = rfl64(k1);
+        const int64_t W0 = k >> 6, wlast = (k1u - 1) >> 6;
+        const int64_t n_tiles_seg = (wlast - W0 + (int64_t)NWV * HOT_RPT) / ((int64_t)NWV * HOT_RPT);
+        uint32_t posn[HOT_RPT];                 // tile in flight: run gathers, then record positions
+        uint32_t dn[HOT_RPT];
+        RecT<REC8> recn[HOT_RPT];
+        // word of round r of this wavefront in tile t; the lanes of the round are the positions 64 w + lane
+#define HOT_WORD(t, r) (W0 + ((t) * NWV + wv) * HOT_RPT + (r))
+#define HOT_VALID(t, r) (HOT_WORD(t, r) * 64 + lane >= k && HOT_WORD(t, r) * 64 + lane < k1u)
+#define HOT_ISSUE_RUNS(t)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < HOT_RPT; ++r) {                                                          \
+        const int64_t w_ = HOT_WORD(t, r), wc_ = w_ < wlast ? w_ : wlast;        /* wave-uniform: scalar loads */   \
+        RunLook l_;                                                                                                \
+        l_.b = o.bits[wc_]; l_.r = o.ck_run[wc_]; l_.s = o.ck_start[wc_];                                          \
+        uint32_t run_;                                                                                             \
+        run_of(l_, wc_ * 64 + lane, run_, dn[r]);                                                                  \
+        posn[r] = o.j0[run_];                                                                                      \
+    }
+#define HOT_ISSUE_RECS(t)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < HOT_RPT; ++r) rec_load(recn[r], p_rec, HOT_VALID(t, r) ? posn[r] + dn[r] : 0u);
+        HOT_ISSUE_RUNS((int64_t)0)
+        HOT_ISSUE_RECS((int64_t)0)
+        int par = 0;
+        for (int64_t t = 0; t < n_tiles_seg; ++t, par ^= 1) {
+            CP_T(4)
+            // the slice's weights and colours go to LDS (a private slot per thread and round): pass B reads them round by round, and
+            // the registers they would hold across it (24) carry the next tile's records in flight instead — with both in registers
+            // the 16-wavefront form spilled (it has 128 registers per lane)
+            float mine0 = 0.f;
+            {
+                const double wb = (double)st.w;
+#pragma unroll
+                for (int r = 0; r < HOT_RPT; ++r) {
+                    const double a = rec_alpha(recn[r], gc, s_exp);
+                    s_al[r][threadIdx.x] = a;
+                    s_rg[r][threadIdx.x] = rec_rgb(recn[r]);
+                    mine0 += HOT_VALID(t, r) ? (float)(wb + a) - st.w : 0.f;
+                }
+            }
+            const bool more = t + 1 < n_tiles_seg;
+            if (more) { HOT_ISSUE_RUNS(t + 1) }
+#ifdef BSC_CHAIN_PROFILE
+            ++n_tiles;
+#endif
+            CP_T(0)
+            // chunks < first are final; `st` is the true state at the start of chunk `first`
+            for (int first = 0, again = 0;; ++again) {
+                if (again) __syncthreads();                     // a repeated pass rewrites arrays the slower wavefronts may still be checking
+                if (wv >= first) {
+                    float mine = mine0;
+                    if (again) {                                // from the entry weight now known
+                        mine = 0.f;
+                        const double wb = (double)st.w;
+#pragma unroll
+                        for (int r = 0; r < HOT_RPT; ++r) mine += HOT_VALID(t, r) ? (float)(wb + s_al[r][threadIdx.x]) - st.w : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+                    if (lane == 0) s_sum[par][wv] = mine;
+                }
+                __syncthreads();
+                if (more && again == 0) { HOT_ISSUE_RECS(t + 1) }           // the runs have arrived under pass A and the barrier
+                CP_T(1)
+                if (wv >= first) {
+                    ChainState me = st;
+                    for (int i = first; i < wv; ++i) me.w += s_sum[par][i];
+                    if (lane == 0) s_entry[par][wv] = me;
+#pragma unroll
+                    for (int r = 0; r < HOT_RPT; ++r) {
+                        if (HOT_WORD(t, r) > wlast) break;      // (uniform) past the segment's end
+                        chain_round_step(s_al[r][threadIdx.x], s_rg[r][threadIdx.x], HOT_VALID(t, r), me.w, me.c0, me.c1, me.c2, lane);
+                    }
+                    if (lane == 0) s_exit[par][wv] = me;
+                }
+                CP_T(2)
+                __syncthreads();
+                // lane c compares the entry chunk c assumed with the exit of chunk c - 1
+                const int cl = lane < NWV ? lane : 0;
+                const ChainState have = s_entry[par][cl], real = s_exit[par][cl > 0 ? cl - 1 : 0];
+                const u64 bm = __ballot(lane > first && lane < NWV &&
+                                        !(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2));
+                const int bad = bm ? __ffsll((unsigned long long)bm) - 1 : NWV;
+                CP_T(3)
+                if (bad == NWV) break;
+                st = s_exit[par][bad - 1];                      // a binade crossing or a colour change upstream: predict again from here
+                st.w = readlane_f32(st.w, 0);
+                first = bad;
+#ifdef BSC_CHAIN_PROFILE
+                ++n_again;
+#endif
+            }
+            st = s_exit[par][NWV - 1];                          // the state after the tile (every thread reads the same entry)
+            st.w = readlane_f32(st.w, 0);
+        }
+        __syncthreads();                                        // the next segment starts on set 0 again
+#undef HOT_WORD
+#undef HOT_VALID
+#undef HOT_ISSUE_RUNS
+#undef HOT_ISSUE_RECS
+#else
+        const int64_t klast = k1 - 1;
         for (int64_t tile = k; tile < k1; tile += (int64_t)NWV * HOT_RPT * 64) {
             CP_T(4)
             const int64_t ka = tile + (int64_t)wv * HOT_RPT * 64;          // this wavefront's slice [ka, ka + HOT_RPT * 64) of the tile
@@ -1119,38 +1239,39 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
                     mine = readlane_f32(mine, 0);
                 }
                 __syncthreads();                                // the shared arrays are free (previous pass / tile / segment)
-                if (lane == 0) s_sum[wv] = mine;
+                if (lane == 0) s_sum[0][wv] = mine;
                 __syncthreads();
                 CP_T(1)
                 if (wv >= first) {
                     ChainState me = st;
-                    for (int i = first; i < wv; ++i) me.w += s_sum[i];
-                    if (lane == 0) s_entry[wv] = me;
+                    for (int i = first; i < wv; ++i) me.w += s_sum[0][i];
+                    if (lane == 0) s_entry[0][wv] = me;
 #pragma unroll
                     for (int r = 0; r < HOT_RPT; ++r) {
                         if (ka + r * 64 >= k1) break;           // (uniform) past the segment's end
                         chain_round_step(al[r], rg[r], ka + r * 64 + lane < k1, me.w, me.c0, me.c1, me.c2, lane);
                     }
-                    if (lane == 0) s_exit[wv] = me;
+                    if (lane == 0) s_exit[0][wv] = me;
                 }
                 CP_T(2)
                 __syncthreads();
                 int bad = NWV;
                 for (int c = NWV - 1; c > first; --c) {
-                    const ChainState have = s_entry[c], real = s_exit[c - 1];
+                    const ChainState have = s_entry[0][c], real = s_exit[0][c - 1];
                     if (!(have.w == real.w && have.c0 == real.c0 && have.c1 == real.c1 && have.c2 == real.c2)) bad = c;
                 }
                 CP_T(3)
                 if (bad == NWV) break;
-                st = s_exit[bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
+                st = s_exit[0][bad - 1];                           // a binade crossing or a colour change upstream: predict again from here
                 first = bad;
 #ifdef BSC_CHAIN_PROFILE
                 ++n_again;
 #endif
             }
-            st = s_exit[NWV - 1];                               // the state after the tile (every thread reads the same entry)
+            st = s_exit[0][NWV - 1];                               // the state after the tile (every thread reads the same entry)
             __syncthreads();                                    // before the next tile's pass overwrites the shared arrays
         }
+#endif
         if (threadIdx.x == 0) chain_finish(st, vid, s, k1 - 1, o, rgb_pos, rgb, weight, hmap, seg_last, gs, order_base);
     }
     // ---- the other long segments: one wavefront each, static schedule over the length-ordered list, back and forth (wave g
@@ -1465,6 +1586,12 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     x->chain_pending = false;
     const int set = x->chain_set;
     BSC_HIP(hipStreamWaitEvent(x->side, x->ev_ready[set], 0));
+    // A call followed at once by bsc_sync (the isolated call of the bench, a frame-by-frame user): the chain would start beside the
+    // pair sort of the same call, whose look-back tiles then wait for CUs the chain's resident workgroups hold (pair sort 0.3 ->
+    // 0.7 ms with two 8-wavefront chain workgroups per CU).  Behind the pair sort it overlaps the dense reduce alone.  In a pipeline
+    // the chain is launched at the next call and the event has long fired.
+    static const bool chain_after_psort = getenv("BSC_CHAIN_BESIDE_PAIRSORT") == nullptr;
+    if (chain_after_psort && x->ev_psort_valid) BSC_HIP(hipStreamWaitEvent(x->side, x->ev_psort, 0));
     // CHAIN_WAVES wavefronts x 16 quads pull segments from the queue, longest first, in workgroups of 4 (one wavefront per
     // SIMD of a CU): the queue hands the longest segments to the first workgroups, which keeps the chain's long tail on one
     // or two CUs — a CU with a resident chain wavefront (178 VGPRs) cannot take a 512-register GEMM wavefront of the
@@ -1487,7 +1614,9 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     // a wavefront per ~4096 points of the batch, at most long_waves (a frame-by-frame call launches a handful)
     int64_t nw = x->chain_points / 4096;
     nw = nw < 64 ? 64 : (nw > long_waves ? long_waves : nw);
-    static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 16;
+    // 8 wavefronts per hot segment since round 6 (two workgroups per CU: one steps its rounds while the other waits for records or
+    // at a barrier): chain 2.55 -> 1.95 ms per 768-frame call against the 16-wavefront form
+    static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 8;
     if (x->long_chain) {
         const RunOrder ro = {x->run_bits_s[set], x->ck_run_s[set], x->ck_start_s[set], x->run_val_s[set]};
 #define BSC_LAUNCH_LONG(NWVV, R8)                                                                                               \
