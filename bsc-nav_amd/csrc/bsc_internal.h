@@ -77,6 +77,7 @@ struct bsc_ctx {
     uint8_t *cv_map;   // (gs,gs,3)
     // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
     bool geom_fast;
+    bool pat_all_in;           // no pixel centre outside the patch grid: the every-pixel dense build needs no patch-table look-ups
     bool long_chain;           // segments of >= 64 points go to the wavefront-per-voxel chain (BSC_QUAD_CHAIN_ONLY unsets)
     // 8-byte point records for the every-pixel dense build (geometry_dev.h rec8_*): possible when float_as_uint over the valid
     // depth range (min_depth, max_depth) spans fewer than 2^28 values (BSC_REC12=1 keeps the 12-byte {alpha, rgb} records)
@@ -144,6 +145,8 @@ struct bsc_ctx {
     int64_t *bscal_s[2];       // per-set scalars: [0] voxel segments of the batch, [1] max_id before the batch
     int cur_set;
     hipStream_t side;          // rgb chain + top-down map run here, overlapped with the dense reduce / next encoder
+    hipStream_t side2;         // the one-wavefront segments of the long chain, beside the hot tiles on `side`
+    hipEvent_t ev_chain0, ev_mid;
     hipEvent_t ev_ready[2], ev_done[2];
     bool ev_done_valid[2];
     bool chain_pending;        // the last call's rgb chain / top-down map kernels are still to be launched (deferred)

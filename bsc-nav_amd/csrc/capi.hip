@@ -203,6 +203,9 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
                        patch_table(c.width, c.Kinv[0], c.Kinv[2], c.Kpatch[0], c.Kpatch[2], c.patch_grid, tx) &&
                        patch_table(c.height, c.Kinv[4], c.Kinv[5], c.Kpatch[4], c.Kpatch[5], c.patch_grid, ty);
         hipError_t e = hipSuccess;
+        x->pat_all_in = x->geom_fast;           // every pixel centre inside the patch grid (the usual case: K_patch is K scaled)
+        for (int px = 0; px < c.width && x->pat_all_in; ++px) x->pat_all_in = tx[px] != 255;
+        for (int py = 0; py < c.height && x->pat_all_in; ++py) x->pat_all_in = ty[py] != 255;
         if (x->geom_fast) {
             e = hipMemcpy(x->pat_x, tx, c.width, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(x->pat_y, ty, c.height, hipMemcpyHostToDevice);
@@ -287,6 +290,9 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
         int lo = 0, hi = 0;   // rgb chain: latency-bound, give it the highest priority the device offers
         BSC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         BSC_HIP(hipStreamCreateWithPriority(&x->side, hipStreamNonBlocking, hi));
+        BSC_HIP(hipStreamCreateWithPriority(&x->side2, hipStreamNonBlocking, hi));
+        BSC_HIP(hipEventCreateWithFlags(&x->ev_chain0, hipEventDisableTiming));
+        BSC_HIP(hipEventCreateWithFlags(&x->ev_mid, hipEventDisableTiming));
     }
     if (c.mode != BSC_MODE_EXACT) {
         x->pair_cap = np;
@@ -362,6 +368,9 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     radix_ws_destroy(&x->rx_side);
     if (x->hscal) hipHostFree(x->hscal);
     if (x->side) hipStreamDestroy(x->side);
+    if (x->side2) { hipStreamSynchronize(x->side2); hipStreamDestroy(x->side2); }
+    if (x->ev_chain0) hipEventDestroy(x->ev_chain0);
+    if (x->ev_mid) hipEventDestroy(x->ev_mid);
     if (x->ev_ids) hipEventDestroy(x->ev_ids);
     if (x->ev_runs) hipEventDestroy(x->ev_runs);
     if (x->ev_tot) hipEventDestroy(x->ev_tot);

@@ -190,9 +190,16 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
     uint32_t *s_rec = (uint32_t *)s_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef BSC_POINTS_PROFILE
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64();
+#define PT_T(k) { const long long now_ = clock64(); tph[k] += now_ - tq; tq = now_; }
+#else
+#define PT_T(k)
+#endif
     for (int i = tid; i < GROUP_HS; i += TPB) { s_key[i] = 0xffffffffu; s_first[i] = 0xffffffffu; }
     for (int i = tid; i < GW * (GROUP_HS + 1); i += TPB) { (&s_word[0][0])[i] = 0ull; (&s_cnt[0][0])[i] = 0u; }
     __syncthreads();
+    PT_T(6)
 
     const int32_t N = gc.H * gc.W;
     const int64_t blk_base = (int64_t)blockIdx.x * GB;
@@ -212,12 +219,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
     int32_t cells[RPW];
     uint32_t sr[RPW], ralo[RPW], rahi[RPW];
     int ovf_cnt = 0;
-#ifdef BSC_POINTS_PROFILE
-    long long tph[6] = {0, 0, 0, 0, 0, 0}, tq = clock64();
-#define PT_T(k) { const long long now_ = clock64(); tph[k] += now_ - tq; tq = now_; }
-#else
-#define PT_T(k)
-#endif
+    PT_T(7)
     // Frame, pixel and depth of the lane's point of EVERY round first: the rounds below then start from registers.  (Loaded round
     // by round, each round sat out three memory round trips in a row — its depth, the completion of its cell store ahead of the
     // colour gather, the gather itself: 4.7 k clocks per round for ~1 k clocks of instruction issue.)
@@ -227,10 +229,15 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
     uint32_t xy[RPW];                               // fast geometry: pixel (x | y << 16)
     uint32_t tpx[RPW], tpy[RPW];                    // patch column / row of the pixel (raw table bytes, one register each: combining or
                                                     // packing them here would wait for the loads)
+    // The "outside every patch" default of a lane past the last point comes out of an opaque register: with the literal 255 the
+    // compiler turns `phi(255, load) != 255` (the patch test of the geometry) into `phi(false, load != 255)` and evaluates the
+    // comparison right behind the load — a full memory round trip per round, eight in a row (12 k of a wavefront's 49 k clocks).
+    uint32_t pat_none = 255u;
+    asm volatile("" : "+v"(pat_none));
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int64_t j = blk_base + wv * RPW * 64 + r * 64 + lane;
-        fr[r] = 0; ir[r] = 0; zr[r] = 0.f; xy[r] = 0u; tpx[r] = 255; tpy[r] = 255;
+        fr[r] = 0; ir[r] = 0; zr[r] = 0.f; xy[r] = 0u; tpx[r] = pat_none; tpy[r] = pat_none;
         if (j < P) {
             int f;
             int32_t i;
@@ -259,8 +266,10 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
                 int32_t x = i - y * gc.W;
                 if (x < 0) { --y; x += gc.W; } else if (x >= gc.W) { ++y; x -= gc.W; }
                 xy[r] = (uint32_t)x | ((uint32_t)y << 16);
-                tpx[r] = gc.pat_x[x];
-                tpy[r] = gc.pat_y[y];
+                if (!PLAIN) {
+                    tpx[r] = gc.pat_x[x];
+                    tpy[r] = gc.pat_y[y];
+                }
             }
         }
     }
@@ -292,7 +301,9 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             cell = -1;
             if (FAST) {
                 GeomFastOut o;
-                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, !REC8 && alpha_in == nullptr, (uint32_t)tpx[r], (uint32_t)tpy[r], s_exp);
+                // PLAIN: the patch is not recorded and no pixel lies outside the patch grid (the host checked): no table look-ups
+                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, !REC8 && alpha_in == nullptr,
+                                  PLAIN ? 0u : (uint32_t)tpx[r], PLAIN ? 0u : (uint32_t)tpy[r], s_exp);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
             } else {
@@ -475,8 +486,8 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
     PT_T(5)
 #ifdef BSC_POINTS_PROFILE
     if (blockIdx.x == 1000 && lane == 0 && (wv == 0 || wv == 3))
-        printf("k_points wave %d: init %lld geometry %lld slot/rank %lld barrier %lld prefix/claims %lld records %lld (clocks, %d rounds)\n", wv,
-               tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], RPW);
+        printf("k_points wave %d: clear+barrier %lld transform %lld loads %lld geometry %lld slot/rank %lld barrier %lld prefix/claims %lld records %lld (clocks, %d rounds)\n", wv,
+               tph[6], tph[7], tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], RPW);
 #endif
 #undef PT_T
 }
@@ -1029,8 +1040,16 @@ __device__ __forceinline__ void chain_finish(const ChainState &st, const uint32_
 // settled); (C) chunk k+1's assumed entry must equal chunk k's exit: the first chunk that fails is run again from the true
 // state, and so on down the line.  A binade crossing or a colour change inside the segment costs the rest of it a second
 // run; otherwise a segment of n points takes n / (64 * wavefronts) rounds.
-template <int NWV, bool REC8>      // wavefronts per workgroup: the width of the hot-segment split; record format
-__global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, const RunOrder o, int64_t *bscal,
+// PART (round 6): 0 = hot segments, then the other long ones, in one launch; 1 = the hot segments only; 2 = the others only.  The
+// two halves want different launch shapes: a hot tile keeps 8 rounds of records in flight per wavefront (110 registers, 50 KB of
+// LDS per workgroup: four wavefronts per SIMD), a one-wavefront segment is a chain of dependent steps per round of 64 points whose
+// latency only other wavefronts on the SIMD can cover — alone (PART 2) it fits BSC_MID_MIN_BLOCKS workgroups of four wavefronts
+// per CU.  launch_pending_chain runs the halves side by side on two streams.
+#ifndef BSC_MID_MIN_BLOCKS
+#define BSC_MID_MIN_BLOCKS 6
+#endif
+template <int NWV, bool REC8, int PART>      // wavefronts per workgroup: the width of the hot-segment split; record format
+__global__ __launch_bounds__(NWV * 64, PART == 2 ? BSC_MID_MIN_BLOCKS : 1) void k_chain_long(const GeomConst gc, const RunOrder o, int64_t *bscal,
                                                         const int4 *__restrict__ seg_info,
                                                         const void *__restrict__ p_rec,
                                                         const int32_t *__restrict__ rgb_pos, uint8_t *__restrict__ rgb,
@@ -1040,8 +1059,8 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
     __shared__ float s_sum[2][NWV];
     __shared__ ChainState s_entry[2][NWV], s_exit[2][NWV];
 #ifndef BSC_CHAIN_TILES_V1
-    __shared__ double s_al[HOT_RPT][NWV * 64];           // the hot tile in flight: alpha and colour of every point (96 KB at 16 wavefronts)
-    __shared__ uint32_t s_rg[HOT_RPT][NWV * 64];
+    __shared__ double s_al[PART == 2 ? 1 : HOT_RPT][NWV * 64];      // the hot tile in flight: alpha and colour of every point (96 KB at 16 wavefronts)
+    __shared__ uint32_t s_rg[PART == 2 ? 1 : HOT_RPT][NWV * 64];
 #endif
     __shared__ double2 s_exp[REC8 ? 64 : 1];
     if (REC8) {
@@ -1050,6 +1069,12 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
     }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the hot tiles of one segment are a serial chain (the hottest voxel of a 768-frame call: 46 tiles): beside the 8192 resident
+    // wavefronts of the one-wavefront segments every phase of a tile waited for issue slots; at a raised wave priority they go first
+#ifndef BSC_HOT_PRIO
+#define BSC_HOT_PRIO 3
+#endif
+    if (PART == 1) __builtin_amdgcn_s_setprio(BSC_HOT_PRIO);
     const int64_t nlong = bscal[4], nhot = bscal[6];
     const int64_t max_id_prev = bscal[1];
 #ifdef BSC_CHAIN_PROFILE
@@ -1066,7 +1091,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
     // registers: (A) the increments of its slice summed from registers, (B) its rounds stepped from registers from the predicted
     // entry state, (C) the slices' entry / exit states compared; a slice whose entry was wrong runs (A, B) again from registers.
     // (Until round 4 the chunks spanned the whole segment and pass A re-read every record of it: +12 B per hot point.)
-    for (int64_t turn = blockIdx.x; turn < nhot; turn += gridDim.x) {
+    for (int64_t turn = blockIdx.x; PART != 2 && turn < nhot; turn += gridDim.x) {
         const int32_t s = seg_info[turn].w;
         const int4 info = seg_info[s];
         int64_t k = info.x;
@@ -1281,7 +1306,7 @@ __global__ __launch_bounds__(NWV * 64) void k_chain_long(const GeomConst gc, con
     const int64_t nwaves = (int64_t)gridDim.x * NWV;
     const int64_t wave = (int64_t)blockIdx.x * NWV + wv;
     const int64_t nrest = nlong - nhot;
-    for (int64_t pass = 0;; ++pass) {
+    for (int64_t pass = 0; PART != 1; ++pass) {
         const int64_t turn = nhot + pass * nwaves + ((pass & 1) ? nwaves - 1 - wave : wave);
         if (pass * nwaves >= nrest) break;
         if (turn >= nlong) continue;
@@ -1619,12 +1644,26 @@ bsc_status launch_pending_chain(bsc_ctx *x)
     static const int long_nwv = getenv("BSC_LONG_NWV") ? atoi(getenv("BSC_LONG_NWV")) : 8;
     if (x->long_chain) {
         const RunOrder ro = {x->run_bits_s[set], x->ck_run_s[set], x->ck_start_s[set], x->run_val_s[set]};
-#define BSC_LAUNCH_LONG(NWVV, R8)                                                                                               \
-    hipLaunchKernelGGL((k_chain_long<NWVV, R8>), dim3((unsigned)((nw + NWVV - 1) / NWVV)), dim3(NWVV * 64), 0, x->side, gc, ro,  \
+#define BSC_LAUNCH_LONG(NWVV, R8, PARTV, GRID, ST)                                                                              \
+    hipLaunchKernelGGL((k_chain_long<NWVV, R8, PARTV>), dim3((unsigned)(GRID)), dim3(NWVV * 64), 0, ST, gc, ro,                  \
                        x->bscal_s[set], x->seg_info_s[set], (const void *)x->p_rec_s[set], x->rgb_pos, x->rgb, x->weight,        \
                        x->hmap, x->seg_last_s[set], x->c.grid_size, x->chain_order_base)
-        if (long_nwv == 16) { if (rec8) BSC_LAUNCH_LONG(16, true); else BSC_LAUNCH_LONG(16, false); }
-        else { if (rec8) BSC_LAUNCH_LONG(8, true); else BSC_LAUNCH_LONG(8, false); }
+        // round 6: the one-wavefront segments (three quarters of the room scene's points) as a launch of their own, at the occupancy
+        // a chain of dependent steps needs, on a second side stream beside the hot tiles (BSC_CHAIN_SPLIT=0: one launch for both)
+        static const bool chain_split = getenv("BSC_CHAIN_SPLIT") == nullptr || atoi(getenv("BSC_CHAIN_SPLIT")) != 0;
+        if (chain_split && long_nwv != 16) {
+            BSC_HIP(hipEventRecord(x->ev_chain0, x->side));                 // behind k_chain: the first points of the new voxels
+            BSC_HIP(hipStreamWaitEvent(x->side2, x->ev_chain0, 0));
+            // a workgroup per hot segment (the device counts them; the host bounds them by the points of the call), launched first
+            int64_t ghot = x->chain_points >> HOT_MIN_LOG2;
+            ghot = ghot < 1 ? 1 : (ghot > 2048 ? 2048 : ghot);
+            if (rec8) BSC_LAUNCH_LONG(8, true, 1, ghot, x->side); else BSC_LAUNCH_LONG(8, false, 1, ghot, x->side);
+            const int64_t gmid = (nw + 3) / 4;
+            if (rec8) BSC_LAUNCH_LONG(4, true, 2, gmid, x->side2); else BSC_LAUNCH_LONG(4, false, 2, gmid, x->side2);
+            BSC_HIP(hipEventRecord(x->ev_mid, x->side2));
+            BSC_HIP(hipStreamWaitEvent(x->side, x->ev_mid, 0));
+        } else if (long_nwv == 16) { if (rec8) BSC_LAUNCH_LONG(16, true, 0, (nw + 15) / 16, x->side); else BSC_LAUNCH_LONG(16, false, 0, (nw + 15) / 16, x->side); }
+        else { if (rec8) BSC_LAUNCH_LONG(8, true, 0, (nw + 7) / 8, x->side); else BSC_LAUNCH_LONG(8, false, 0, (nw + 7) / 8, x->side); }
 #undef BSC_LAUNCH_LONG
     }
 #define BSC_LAUNCH_HWIN(R8)                                                                                                     \
@@ -1688,7 +1727,8 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     hipLaunchKernelGGL((k_points<FASTV, RPWV, PLAINV, R8>), fgrid, block, 0, s, gc, depth, rgb, rgb_ch, idx, x->d_offsets, n_frames, \
                        x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, (void *)p_rec, r2f, x->new_cells, x->dscal, \
                        x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
-    const bool plain = !idx && !patf && !r2f && !alpha && !g_cell;
+    // (PLAIN also takes for granted that every pixel lies inside the patch grid — bsc_create checked the tables — and reads none)
+    const bool plain = !idx && !patf && !r2f && !alpha && !g_cell && x->pat_all_in;
     // 8-byte records {rgb, index in block, depth offset} where the depth range allows (bsc_create), alpha left to the rgb chain
     const bool rec8 = gc.fast && plain && x->rec8_ok;
     x->rec8_s[set] = rec8;

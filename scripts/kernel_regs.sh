@@ -10,9 +10,11 @@ for line in open([f for f in __import__("glob").glob("*gfx950.s")][0]):
     if m: name = m.group(1)
     m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
     if m: scratch = m.group(1)
+    m = re.match(r"\s+\.group_segment_fixed_size:\s+(\d+)", line)
+    if m: lds = m.group(1)
     m = re.match(r"\s+\.sgpr_count:\s+(\d+)", line)
     if m: sg = m.group(1)
     m = re.match(r"\s+\.vgpr_count:\s+(\d+)", line)
-    if m and name and sys.argv[1] in name: print(f"{name[:90]:90s} vgpr {m.group(1):>4s} sgpr {sg:>4s} scratch {scratch}")
+    if m and name and sys.argv[1] in name: print(f"{name[:90]:90s} vgpr {m.group(1):>4s} sgpr {sg:>4s} scratch {scratch} lds {lds}")
 PY
 rm -rf $d
