@@ -154,8 +154,11 @@ __device__ __forceinline__ void claim_cells(bool want, int32_t cell, int64_t j, 
 #ifndef BSC_POINTS_MIN_BLOCKS
 #define BSC_POINTS_MIN_BLOCKS 4
 #endif
+#ifndef BSC_POINTS_MIN_BLOCKS_PLAIN8
+#define BSC_POINTS_MIN_BLOCKS_PLAIN8 4      // (6 — 80 registers, 24.6 KB of LDS — fits a CU but spills five registers and is slower: 5.05 against 4.91 ms per call)
+#endif
 template <bool FAST, int RPW, bool PLAIN, bool REC8>
-__global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_points(GeomConst gc, const float *__restrict__ depth,
+__global__ __launch_bounds__(TPB, RPW <= 8 ? (PLAIN && REC8 ? BSC_POINTS_MIN_BLOCKS_PLAIN8 : BSC_POINTS_MIN_BLOCKS) : 1) void k_points(GeomConst gc, const float *__restrict__ depth,
                                                 const uint8_t *__restrict__ rgb, int rgb_ch,
                                                 const int32_t *__restrict__ idx_, const int64_t *__restrict__ offsets,
                                                 int n_frames, const double *__restrict__ transforms,
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
     __shared__ uint32_t s_first[GROUP_HS + 1];           // first point (index inside the block) of the slot's cell
     // the per-wavefront ballot words live until the last round; the record staging starts after it: one buffer
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[WORD_BYTES > REC_BYTES ? WORD_BYTES : REC_BYTES];
-    __shared__ uint32_t s_cnt[GW][GROUP_HS + 1];          // + a spare entry for the lanes without a slot
+    __shared__ uint16_t s_cnt[GW][GROUP_HS + 1];          // + a spare entry for the lanes without a slot (16 bits: at most GB points;
+                                                          // with 32-bit counts six workgroups did not fit a CU's 160 KB)
     __shared__ uint32_t s_wsum[GW];
     __shared__ int32_t s_ovf[GW];
     __shared__ double2 s_exp[REC8 ? 1 : 64];              // 2^(j/64) as (hi, lo): bsc_exp's table (8-byte records: alpha is the chain's)
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
 #define PT_T(k)
 #endif
     for (int i = tid; i < GROUP_HS; i += TPB) { s_key[i] = 0xffffffffu; s_first[i] = 0xffffffffu; }
-    for (int i = tid; i < GW * (GROUP_HS + 1); i += TPB) { (&s_word[0][0])[i] = 0ull; (&s_cnt[0][0])[i] = 0u; }
+    for (int i = tid; i < GW * (GROUP_HS + 1); i += TPB) { (&s_word[0][0])[i] = 0ull; (&s_cnt[0][0])[i] = (uint16_t)0; }
     __syncthreads();
     PT_T(6)
 
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
                 // take the per-thread division)
                 int fb = fw;
                 int32_t ib = iw + r * 64 + lane;
-                if (N >= GB) {
+                if (PLAIN) {
+                    // (the host takes PLAIN only when a frame is a whole number of wavefront slices: no wavefront crosses a frame)
+                } else if (N >= GB) {
                     if (ib >= N) { ib -= N; ++fb; }
                 } else {
                     fb += ib / N;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             }
             fr[r] = f; ir[r] = i;
             zr[r] = depth[(int64_t)f * N + i];
-            if (FAST) {
+            if (FAST && !PLAIN) {
                 // y = i / W without an integer division: float estimate (exact operands below 2^24), corrected by one
                 int32_t y = (int32_t)((float)i * inv_w);
                 int32_t x = i - y * gc.W;
@@ -273,9 +279,22 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             }
         }
     }
-    uint32_t raw0[RPW], raw1[RPW];                  // colour gathers, consumed after the rounds
-    const bool rgb4 = rgb_ch == 4;
+    uint32_t raw0[RPW];                             // colour gathers, consumed after the rounds
+    // ONE 32-bit gather per point whatever the frame format: RGBA pixels are aligned words; the three bytes of an RGB pixel come
+    // with the byte behind them (an unaligned word: global memory takes it), except at the very end of the buffer, where the word
+    // starts one byte early.  With two gathers + a wait on the RGB path and one on the RGBA path the compiler could not count
+    // the loads in flight at the head of the next round and waited for all of them — the colour gather's round trip, every round.
+    const int64_t rgb_last = (int64_t)n_frames * gc.H * gc.W * rgb_ch - 4;
     PT_T(0)
+    // PLAIN: the pixel of the lane's point walks along with the rounds (64 pixels on, at most one row down: the host takes PLAIN only
+    // for frames at least 64 pixels wide) — two registers instead of one per round
+    int32_t run_x = 0, run_y = 0;
+    if (PLAIN) {
+        const int32_t i0 = iw + lane;
+        run_y = (int32_t)((float)i0 * inv_w);
+        run_x = i0 - run_y * gc.W;
+        if (run_x < 0) { --run_y; run_x += gc.W; } else if (run_x >= gc.W) { ++run_y; run_x -= gc.W; }
+    }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int p_local = wv * RPW * 64 + r * 64 + lane;
@@ -283,17 +302,21 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
         int32_t cell = -2;
         ralo[r] = rahi[r] = 0u;
         int64_t pix_off = 0;                        // byte offset of the colour the point samples (0: none — a harmless read)
+        uint32_t tail = 0u;
         if (j < P) {
             const int f = fr[r];
             const int32_t i = ir[r];
             const float z = zr[r];
-            if (__ballot(f != fT)) {                // wave-uniform: the transform is re-read only by a wavefront that crosses a frame
+            if (!PLAIN && __ballot(f != fT)) {      // wave-uniform: the transform is re-read only by a wavefront that crosses a frame
                 if (f != fT) {
                     const double *Tv = transforms + 16 * (int64_t)f;
 #pragma unroll
                     for (int k = 0; k < 12; ++k) T[k] = Tv[k];
                     fT = f;
                 }
+                // the reload completes HERE, in the rare block: left pending, the registers of T made the compiler wait for every
+                // load in flight (vmcnt(0)) at the head of the next round — the colour gather's round trip, once per round
+                __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0)
             }
             int32_t sx = 0, sy = 0;
             uint32_t patch = 0;
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             if (FAST) {
                 GeomFastOut o;
                 // PLAIN: the patch is not recorded and no pixel lies outside the patch grid (the host checked): no table look-ups
-                geom_point_fast_t(gc, (int32_t)(xy[r] & 0xffffu), (int32_t)(xy[r] >> 16), z, T, o, !REC8 && alpha_in == nullptr,
+                geom_point_fast_t(gc, PLAIN ? run_x : (int32_t)(xy[r] & 0xffffu), PLAIN ? run_y : (int32_t)(xy[r] >> 16), z, T, o, !REC8 && alpha_in == nullptr,
                                   PLAIN ? 0u : (uint32_t)tpx[r], PLAIN ? 0u : (uint32_t)tpy[r], s_exp);
                 cell = o.cell;
                 sx = o.sx; sy = o.sy; patch = o.patch; r2 = o.r2; alpha = o.alpha;
@@ -336,12 +359,19 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             }
         }
         // the colour gather of every lane, unconditionally and unprocessed: nothing below needs it before the records are written,
-        // so its round trip runs under the following rounds (RGBA frames: one aligned 32-bit gather; RGB: 16 + 8 bits)
-        // (raw1 stays unwritten for RGBA frames and is not read for them: a `= 0` here overwrites a register the hardware may still
-        //  owe an earlier load, and the wait for that also sat out the cell store just issued — a memory round trip per round)
-        if (rgb4) raw0[r] = *(const uint32_t *)(rgb + pix_off);
-        else { raw0[r] = (uint32_t)rgb[pix_off] | ((uint32_t)rgb[pix_off + 1] << 8); raw1[r] = (uint32_t)rgb[pix_off + 2]; }
+        // so its round trip runs under the following rounds
+        {
+            const int64_t off4 = pix_off < rgb_last ? pix_off : rgb_last;
+            tail = pix_off > off4 ? 1u : 0u;             // (rides in bit 30 of sr[r]: the word holds the colour one byte up)
+            uint32_t word;
+            __builtin_memcpy(&word, rgb + off4, 4);
+            raw0[r] = word;
+        }
         cells[r] = cell;
+        if (PLAIN) {
+            run_x += 64;
+            if (run_x >= gc.W) { run_x -= gc.W; ++run_y; }
+        }
         PT_T(1)
         // ---- slot of the cell, rank of the point among the wavefront's points of that cell --------------------------------
         uint32_t e = GROUP_OVF;
@@ -363,12 +393,12 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
         atomicOr((unsigned long long *)&s_word[wv][slot], grouped ? 1ull << lane : 0ull);
         wave_lds_order();
         const u64 word = __hip_atomic_load(&s_word[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const uint32_t before = __hip_atomic_load(&s_cnt[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t before = (uint32_t)__hip_atomic_load(&s_cnt[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         wave_lds_order();
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(word >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)word, 0u));
         uint32_t lr = before + rank;
         if (grouped && rank == 0u) {             // the cell's first lane of the round: count the round, clear the word
-            __hip_atomic_store(&s_cnt[wv][slot], before + (uint32_t)__popcll(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(&s_cnt[wv][slot], (uint16_t)(before + (uint32_t)__popcll(word)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __hip_atomic_store(&s_word[wv][slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (before == 0u) atomicMin(&s_first[slot], (uint32_t)p_local);     // the wavefront's first point of the cell
         }
@@ -376,7 +406,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
         const u64 om = __ballot(cell >= 0 && !grouped);
         if (!grouped) lr = (uint32_t)ovf_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
         ovf_cnt += __popcll(om);
-        sr[r] = cell >= 0 ? (e | (lr << 16)) : 0xffffffffu;
+        sr[r] = cell >= 0 ? (e | (lr << 16) | (tail << 30)) : 0xffffffffu;       // lr <= GB < 2^13
         PT_T(2)
     }
     // the cells of all rounds leave together: a store inside the rounds shares the vmcnt counter with the loads still in flight
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
         const uint32_t base = prefix & 0xffffu, rbase = prefix >> 16, nr = v[k] >> 16;
         uint32_t acc = base;
 #pragma unroll
-        for (int w = 0; w < GW; ++w) { const uint32_t c = s_cnt[w][e]; s_cnt[w][e] = acc; acc += c; }
+        for (int w = 0; w < GW; ++w) { const uint32_t c = s_cnt[w][e]; s_cnt[w][e] = (uint16_t)acc; acc += c; }
         for (uint32_t i = 0; i < nr; ++i) {
             stage_cell[stage_base + rbase + i] = s_key[e];
             stage_pos[stage_base + rbase + i] = (uint32_t)blk_base + base + (i << cap_log2);
@@ -448,7 +478,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const bool valid = sr[r] != 0xffffffffu;
-        const uint32_t e = sr[r] & 0xffffu, lr = sr[r] >> 16;
+        const uint32_t e = sr[r] & 0xffffu, lr = (sr[r] >> 16) & 0x3fffu;
         const bool ovf = valid && e == GROUP_OVF;
         uint32_t pos = 0;
         if (valid) pos = ovf ? ovf_base + lr : s_cnt[wv][e] + lr;
@@ -460,7 +490,7 @@ __global__ __launch_bounds__(TPB, RPW <= 8 ? BSC_POINTS_MIN_BLOCKS : 1) void k_p
             claim_cells(ovf, cells[r], blk_base + wv * RPW * 64 + r * 64 + lane, occ, new_cells, dscal, lane);
         }
         if (valid) {
-            const uint32_t rgbv = rgb4 ? (raw0[r] & 0xffffffu) : (raw0[r] | (raw1[r] << 16));
+            const uint32_t rgbv = (raw0[r] >> ((sr[r] >> 27) & 8u)) & 0xffffffu;
             if (REC8) {
                 uint32_t lo, hi;
                 rec8_pack(gc, rgbv, (uint32_t)(wv * RPW * 64 + r * 64 + lane), zr[r], lo, hi);
@@ -1728,7 +1758,10 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
                        x->d_transforms, alpha, P, inv_w, lb, x->occ, x->p_cell, patf, (void *)p_rec, r2f, x->new_cells, x->dscal, \
                        x->blk_cnt, x->blk_pass, x->stage_cell, x->stage_pos, g_cell)
     // (PLAIN also takes for granted that every pixel lies inside the patch grid — bsc_create checked the tables — and reads none)
-    const bool plain = !idx && !patf && !r2f && !alpha && !g_cell && x->pat_all_in;
+    // and that a frame is a whole number of wavefront slices (RPW x 64 points: 640x480 = 600 x 512), so that a wavefront never
+    // crosses into the next frame and its transform stays what it loaded at the start: with the conditional reload inside the
+    // rounds the compiler waited for EVERY load in flight at the head of each round — the previous round's colour gather included
+    const bool plain = !idx && !patf && !r2f && !alpha && !g_cell && x->pat_all_in && N % (x->group_rpw * 64) == 0 && x->c.width >= 64;
     // 8-byte records {rgb, index in block, depth offset} where the depth range allows (bsc_create), alpha left to the rgb chain
     const bool rec8 = gc.fast && plain && x->rec8_ok;
     x->rec8_s[set] = rec8;
