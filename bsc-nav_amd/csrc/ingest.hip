@@ -1041,6 +1041,11 @@ __device__ __forceinline__ void chain_rounds(const RunOrder &o, const void *__re
             const int64_t kc = k + 128 + lane < kend ? k + 128 + lane : klast, kd = k + 192 + lane < kend ? k + 192 + lane : klast;
             uint32_t rc;
             run_of(lk, kc, rc, d_nxt);
+            // the old word / checkpoint are used up before the next ones are requested: scheduled the other way round the two sets
+            // overlap, the new one lands in spare registers and is COPIED into the loop's registers at the end of the iteration —
+            // behind a wait for every load in flight, the newest included: one memory round trip per round of 64 points
+            asm volatile("" : "+v"(d_nxt), "+v"(rc));       // (both evaluated here, not sunk to their uses behind the new loads)
+            __builtin_amdgcn_sched_barrier(0);
             j0_nxt = o.j0[rc];
             lk = run_look(o, kd);
         }
