@@ -77,6 +77,7 @@ struct bsc_ctx {
     uint8_t *cv_map;   // (gs,gs,3)
     // fast geometry (geometry_dev.h geom_point_fast): pinhole intrinsics + per-pixel patch tables, verified at creation
     bool geom_fast;
+    bool proj_id;              // K Kinv p2d == p2d up to rounding and min_depth >= 0: source pixel without the division (GeomConst.proj_id)
     bool pat_all_in;           // no pixel centre outside the patch grid: the every-pixel dense build needs no patch-table look-ups
     bool long_chain;           // segments of >= 64 points go to the wavefront-per-voxel chain (BSC_QUAD_CHAIN_ONLY unsets)
     // 8-byte point records for the every-pixel dense build (geometry_dev.h rec8_*): possible when float_as_uint over the valid

@@ -131,6 +131,18 @@ static bool patch_table(int n, double kinv_a, double kinv_b, double kp_a, double
     return true;
 }
 
+// K (Kinv (i + 0.5)) == i + 0.5 up to rounding for every pixel column / row: the source pixel of a point is then its own pixel or
+// the one before it (geom_point_fast_t decides which without the division)
+static bool proj_identity(int n, double kinv_a, double kinv_b, double k_a, double k_b)
+{
+    for (int i = 0; i < n; ++i) {
+        const long double p = (long double)i + 0.5L;
+        const long double u = (long double)k_a * ((long double)kinv_a * p + (long double)kinv_b) + (long double)k_b;
+        if (!(fabsl(u - p) < 1e-9L * p)) return false;
+    }
+    return true;
+}
+
 extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hip_stream, bsc_ctx **out)
 {
     if (!cfg || !out) { bsc_set_error("bsc_create: null argument"); return BSC_E_INVALID; }
@@ -203,6 +215,9 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
                        patch_table(c.width, c.Kinv[0], c.Kinv[2], c.Kpatch[0], c.Kpatch[2], c.patch_grid, tx) &&
                        patch_table(c.height, c.Kinv[4], c.Kinv[5], c.Kpatch[4], c.Kpatch[5], c.patch_grid, ty);
         hipError_t e = hipSuccess;
+        x->proj_id = getenv("BSC_PROJ_DIVIDE") == nullptr && c.min_depth >= 0.0 &&
+                     proj_identity(c.width, c.Kinv[0], c.Kinv[2], c.K[0], c.K[2]) &&
+                     proj_identity(c.height, c.Kinv[4], c.Kinv[5], c.K[4], c.K[5]);
         x->pat_all_in = x->geom_fast;           // every pixel centre inside the patch grid (the usual case: K_patch is K scaled)
         for (int px = 0; px < c.width && x->pat_all_in; ++px) x->pat_all_in = tx[px] != 255;
         for (int py = 0; py < c.height && x->pat_all_in; ++py) x->pat_all_in = ty[py] != 255;

@@ -32,6 +32,10 @@ struct GeomConst {
     int32_t rec_lb;           // log2 of the points per k_points workgroup (the record carries the point's index inside its block)
     int32_t div_n_s, div_w_s;
     u64_t div_n_m, div_w_m;
+    // round 6: two shortcuts of the fast path, each with the form it replaces kept behind its flag
+    int32_t proj_id;          // K (Kinv p2d) is p2d up to rounding for every pixel centre and min_depth >= 0 (bsc_create checks): the
+                              // source pixel is x or x - 1 and the choice is made without the division (geom_point_fast_t)
+    int32_t gs_even;          // gs / 2 is an integer: row = gs / 2 - trunc(x / cs) in integer arithmetic
 };
 
 // exp(x) for the point weights alpha = exp(-r^2 / 1.2) (memory_2.py:873-875), x <= 0.  Table-driven (Tang): k = rint(x 64 / ln 2),
@@ -181,22 +185,46 @@ __device__ __forceinline__ void geom_point_fast_t(const GeomConst &c, int32_t x,
     const double g0 = dot4_fma(T + 0, p0, p1, z, 1.0);
     const double g1 = dot4_fma(T + 4, p0, p1, z, 1.0);
     const double g2 = dot4_fma(T + 8, p0, p1, z, 1.0);
-    const int32_t row = (int32_t)(c.half_gs - (double)(int32_t)div_by_const(g0, c.cs, c.rcs));
-    const int32_t col = (int32_t)(c.half_gs - (double)(int32_t)div_by_const(g1, c.cs, c.rcs));
+    const int32_t tr = (int32_t)div_by_const(g0, c.cs, c.rcs), tc = (int32_t)div_by_const(g1, c.cs, c.rcs);
+    int32_t row, col;
+    if (c.gs_even) {
+        // int(gs/2 - float(int(q))) with an integral gs/2: the difference of two integers below 2^32 is exact in f64, so the
+        // second truncation does nothing (a saturated first conversion lands outside the grid either way)
+        row = (int32_t)((uint32_t)(c.gs >> 1) - (uint32_t)tr);
+        col = (int32_t)((uint32_t)(c.gs >> 1) - (uint32_t)tc);
+    } else {
+        row = (int32_t)(c.half_gs - (double)tr);
+        col = (int32_t)(c.half_gs - (double)tc);
+    }
     const int32_t h = (int32_t)div_by_const(g2, c.cs, c.rcs);
     ok = ok && !(col >= c.gs || row >= c.gs || h >= c.max_h || col < 0 || row < 0 || h < c.min_h);
     // project_point(calib_mat): q0 / p2 - 0.5, q1 / p2 - 0.5 (mathematically integers: knife edge, evaluated exactly)
     const double q0 = __fma_rn(c.K[2], z, __dmul_rn(c.K[0], p0));
     const double q1 = __fma_rn(c.K[5], z, __dmul_rn(c.K[4], p1));
-    double rz = __builtin_amdgcn_rcp(z);
-    double e = __fma_rn(-z, rz, 1.0); rz = __fma_rn(rz, e, rz);
-    e = __fma_rn(-z, rz, 1.0); rz = __fma_rn(rz, e, rz);
-    const double u0 = __dmul_rn(q0, rz), u1 = __dmul_rn(q1, rz);
-    const double u = __fma_rn(__fma_rn(-z, u0, q0), rz, u0);
-    const double v = __fma_rn(__fma_rn(-z, u1, q1), rz, u1);
-    int sx = (int32_t)__dsub_rn(u, 0.5), sy = (int32_t)__dsub_rn(v, 0.5);
-    sx += sx < 0 ? c.W : 0;
-    sy += sy < 0 ? c.H : 0;
+    int sx, sy;
+    if (c.proj_id) {
+        // u = RN(q0 / z) is px = x + 0.5 up to a few ulps (K Kinv = 1), and int(u - 0.5) — the subtraction is exact — is x, or
+        // x - 1 when u < px (x >= 1; at x = 0 both signs of u - 0.5 truncate to 0).  px has a handful of significant bits: it is the
+        // even neighbour of the tie, so u < px  <=>  q0 / z < px - h with h half the spacing of the doubles below px (px = x + 0.5
+        // with x >= 1 is no power of two)  <=>  q0 - px z < -h z for z > 0.  px z is exact (<= 25 + 24 bits), q0 lies within a few
+        // ulps of it, so the fma returns the difference exactly; h z is a scaling by a power of two.  No reciprocal, no Newton
+        // steps, no quotients: 10 f64 instructions for both coordinates instead of 19.
+        const double rx = __fma_rn(-px, z, q0), ry = __fma_rn(-py, z, q1);
+        const double hx = __hiloint2double((__double2hiint(px) & 0x7ff00000) - (53 << 20), 0);
+        const double hy = __hiloint2double((__double2hiint(py) & 0x7ff00000) - (53 << 20), 0);
+        sx = x - ((x >= 1 && rx < -__dmul_rn(hx, z)) ? 1 : 0);
+        sy = y - ((y >= 1 && ry < -__dmul_rn(hy, z)) ? 1 : 0);
+    } else {
+        double rz = __builtin_amdgcn_rcp(z);
+        double e = __fma_rn(-z, rz, 1.0); rz = __fma_rn(rz, e, rz);
+        e = __fma_rn(-z, rz, 1.0); rz = __fma_rn(rz, e, rz);
+        const double u0 = __dmul_rn(q0, rz), u1 = __dmul_rn(q1, rz);
+        const double u = __fma_rn(__fma_rn(-z, u0, q0), rz, u0);
+        const double v = __fma_rn(__fma_rn(-z, u1, q1), rz, u1);
+        sx = (int32_t)__dsub_rn(u, 0.5); sy = (int32_t)__dsub_rn(v, 0.5);
+        sx += sx < 0 ? c.W : 0;
+        sy += sy < 0 ? c.H : 0;
+    }
     o.sx = min(max(sx, 0), c.W - 1);
     o.sy = min(max(sy, 0), c.H - 1);
     o.r2 = __dadd_rn(__dadd_rn(__dmul_rn(p0, p0), __dmul_rn(p1, p1)), __dmul_rn(z, z));

@@ -41,6 +41,8 @@ static GeomConst make_geom_const(const bsc_ctx *x)
     g.min_h = x->c.min_h; g.max_h = x->c.max_h; g.nh = x->nh; g.g = x->c.patch_grid;
     g.fast = x->geom_fast ? 1 : 0;
     g.rcs = 1.0 / x->c.cell_size;
+    g.proj_id = x->proj_id ? 1 : 0;
+    g.gs_even = (x->c.grid_size & 1) == 0 ? 1 : 0;
     g.pat_x = x->pat_x; g.pat_y = x->pat_y;
     // bsc_exp (geometry_dev.h): 64 / ln 2; ln 2 / 64 as a 40-bit head (k * head is exact for |k| < 2^13) and its tail; 1/2 .. 1/120
     const long double l64 = 0.693147180559945309417232121458176568L / 64.0L;

@@ -459,6 +459,12 @@ def test_fast_geometry_equals_generic_chain(hw, g):
     poses = synthetic.random_walk_poses(5, F)
     rgb, depth, _ = synthetic.make_frames(5, F, H, W, "room", poses=poses)
     depth[1] = synthetic.make_frames(6, 1, H, W, "iid")[1][0]          # one frame of worst-case depth
+    # one frame of depths on which a quotient q / z rounds most delicately: powers of two, short mantissas and their float
+    # neighbours (the division-free source-pixel test of the fast path decides on the sign of an exact residual there)
+    base = np.array([0.125, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 2.0, 2.5, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.5], np.float32)
+    special = np.concatenate([base, np.nextafter(base, np.float32(0)), np.nextafter(base, np.float32(100)),
+                              np.float32(1.0) / np.arange(1, 9, dtype=np.float32) * np.float32(3.0)])
+    depth[2] = torch.from_numpy(np.tile(special, H * W // len(special) + 1)[:H * W].reshape(H, W).copy()).to(depth.device)
     tok = torch.randn((F, g, g, D), device="cuda")
     chain = B.PoseChain()
     Ts = np.stack([chain.pc_transform(p) for p in poses])
