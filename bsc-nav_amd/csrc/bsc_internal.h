@@ -94,6 +94,8 @@ struct bsc_ctx {
     int pair_path;            // how the pairs of the batch in flight were built: 0 generic tiles, 1 patch tiles
     int64_t *dscal;    // DS_COUNT device scalars
     int64_t *hscal;    // pinned host mirror for readbacks
+    int64_t *mail, *mail_dev;  // DS_COUNT scalars + a sequence number, in coherent pinned host memory: written by k_block_totals, polled by
+    int64_t mail_seq;          // the host (ingest_batch) — no event / copy / synchronize between the front end and the order stage
     // exact mode
     float *cache_f;     // (iter_size,D)
     int32_t *cache_pos; // (iter_size,3)

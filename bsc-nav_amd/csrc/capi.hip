@@ -184,6 +184,14 @@ extern "C" bsc_status bsc_create(const bsc_config *cfg, int32_t device, void *hi
     ALLOC(x->cv_map, 3 * gs2);
     ALLOC(x->dscal, DS_COUNT);
     BSC_HIP(hipHostMalloc((void **)&x->hscal, sizeof(int64_t) * (DS_COUNT + 1)));      // + a slot for the pair count read on its own
+    if (getenv("BSC_NO_MAILBOX") == nullptr &&
+        hipHostMalloc((void **)&x->mail, sizeof(int64_t) * (DS_COUNT + 1), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        memset(x->mail, 0, sizeof(int64_t) * (DS_COUNT + 1));
+        if (hipHostGetDevicePointer((void **)&x->mail_dev, x->mail, 0) != hipSuccess) { hipHostFree(x->mail); x->mail = nullptr; }
+    } else {
+        x->mail = nullptr;
+        (void)hipGetLastError();
+    }
     ALLOC(x->exp_tab, 128);
     {
         double tab[128];
@@ -382,6 +390,7 @@ extern "C" void bsc_destroy(bsc_ctx *x)
     radix_ws_destroy(&x->rx_main);
     radix_ws_destroy(&x->rx_side);
     if (x->hscal) hipHostFree(x->hscal);
+    if (x->mail) hipHostFree(x->mail);
     if (x->side) hipStreamDestroy(x->side);
     if (x->side2) { hipStreamSynchronize(x->side2); hipStreamDestroy(x->side2); }
     if (x->ev_chain0) hipEventDestroy(x->ev_chain0);

@@ -551,6 +551,103 @@ __global__ void k_totals(int64_t P, int64_t nblk, const int32_t *blk_runs, const
 
 // ---- ids of the new voxels ---------------------------------------------------------------------------------------
 // new cell -> (winning point j, cell); sorted by j the list is in first-touch order
+// Round 6: the two block scans (runs, passing points) and k_totals as ONE launch of one workgroup — five launches in a row sat
+// between k_points and everything behind it (two rocPRIM look-back scans of 1.2e5 counts, each an init + a scan kernel, then a
+// one-thread kernel: 0.03 ms alone, 0.2-0.3 ms inside the encoder pipeline) — and the scalars the host sizes the back end from leave
+// through a mailbox in pinned host memory (system-scope stores + a sequence number the host polls) instead of an event, a copy
+// kernel on a third stream and a stream synchronize: the order stage used to start 0.2-0.3 ms behind k_totals.
+#define BT_THREADS 1024
+__global__ __launch_bounds__(BT_THREADS) void k_block_totals(int64_t P, int64_t nblk, const int32_t *__restrict__ blk_runs,
+                                                           int32_t *__restrict__ blk_run_off, const int32_t *__restrict__ blk_pass,
+                                                           int32_t *__restrict__ blk_pass_off, int64_t *dscal, int vcap, int64_t *bscal,
+                                                           int64_t *mail, int64_t seq)
+{
+    // an iteration takes BT_THREADS x 16 counts as FOUR rounds of BT_THREADS x 4: a thread's 16-byte loads and stores of a round
+    // are contiguous with its neighbours' (whole lines per instruction; with 16 consecutive counts per thread every instruction
+    // touched 64 lines and the one CU's address path made the launch 0.2 ms long)
+    __shared__ uint32_t s_w[2][4][BT_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t carry_r = 0, carry_p = 0;
+    const int64_t n4 = (nblk + 3) >> 2;                 // the arrays hold nblk_cap >= nblk + 3 entries (bsc_create pads them)
+    for (int64_t base4 = 0; base4 < n4; base4 += 4 * BT_THREADS) {
+        uint4 r[4], q[4];
+        uint32_t sr[4], sq[4], ir[4], iq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t v = base4 + k * BT_THREADS + tid, vc = v < n4 ? v : n4 - 1;
+            r[k] = ((const uint4 *)blk_runs)[vc];
+            q[k] = ((const uint4 *)blk_pass)[vc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t e0 = 4 * (base4 + k * BT_THREADS + tid);
+            r[k].x = e0 < nblk ? r[k].x : 0u; r[k].y = e0 + 1 < nblk ? r[k].y : 0u; r[k].z = e0 + 2 < nblk ? r[k].z : 0u; r[k].w = e0 + 3 < nblk ? r[k].w : 0u;
+            q[k].x = e0 < nblk ? q[k].x : 0u; q[k].y = e0 + 1 < nblk ? q[k].y : 0u; q[k].z = e0 + 2 < nblk ? q[k].z : 0u; q[k].w = e0 + 3 < nblk ? q[k].w : 0u;
+            sr[k] = r[k].x + r[k].y + r[k].z + r[k].w;
+            sq[k] = q[k].x + q[k].y + q[k].z + q[k].w;
+            ir[k] = wave_incl_sum_u32(sr[k]);
+            iq[k] = wave_incl_sum_u32(sq[k]);
+            if (lane == 63) { s_w[0][k][wv] = ir[k]; s_w[1][k][wv] = iq[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t br = carry_r + ir[k] - sr[k], bq = carry_p + iq[k] - sq[k], tr = 0, tq = 0;
+#pragma unroll
+            for (int w = 0; w < BT_THREADS / 64; ++w) {
+                const uint32_t a = s_w[0][k][w], b = s_w[1][k][w];
+                if (w < wv) { br += a; bq += b; }
+                tr += a; tq += b;
+            }
+            carry_r += tr; carry_p += tq;
+            const int64_t v = base4 + k * BT_THREADS + tid;
+            if (v < n4) {
+                uint4 o, u;
+                o.x = br; o.y = br + r[k].x; o.z = o.y + r[k].y; o.w = o.z + r[k].z;
+                u.x = bq; u.y = bq + q[k].x; u.z = u.y + q[k].y; u.w = u.z + q[k].z;
+                ((uint4 *)blk_run_off)[v] = o;
+                ((uint4 *)blk_pass_off)[v] = u;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    // what k_totals did (memory_2.py:888-894: the new voxels' id range), from the scan totals — on a register copy of the scalars:
+    // every value is read once, up front, and leaves twice (device array, host mailbox) without a load in between (interleaved,
+    // each mailbox store waited for the one before it to be acknowledged by the host: 18 x ~10 us)
+    int64_t d[DS_COUNT];
+#pragma unroll
+    for (int k = 0; k < DS_COUNT; ++k) d[k] = dscal[k];
+    const int64_t npass = carry_p;
+    int64_t nnew = d[DS_B_NNEW];
+    d[DS_B_NPASS] = npass;
+    d[DS_MAX_ID_PREV] = d[DS_MAX_ID];
+    if (d[DS_MAX_ID] + nnew > vcap) { nnew = vcap - d[DS_MAX_ID]; d[DS_ERROR] = 1; }
+    d[DS_B_NFIRST] = nnew;
+    d[DS_MAX_ID] += nnew;
+    d[DS_NPASS_TOTAL] += npass;
+    d[DS_NSEEN_TOTAL] += P;
+    d[DS_B_NRUN] = carry_r;
+    d[DS_B_NPSEG] = 0;
+#pragma unroll
+    for (int k = 0; k < DS_COUNT; ++k) dscal[k] = d[k];
+    bscal[0] = 0;                       // voxel segments of the point order (k_expand)
+    bscal[1] = d[DS_MAX_ID_PREV];
+    bscal[2] = 0;                       // points in the per-voxel order
+    bscal[3] = 0;                       // segment queue of the rgb chain (quads: short segments)
+    bscal[4] = 0;                       // long segments (k_seg_order): the first bscal[4] of the length-ordered list
+    bscal[5] = 0;                       // (unused)
+    bscal[6] = 0;                       // hot segments (k_seg_order): the first bscal[6] of the long ones, a workgroup each
+    if (mail) {
+        // write-through stores to the host, one wait for all their acknowledgements, then the sequence number: no release fence
+        // (at system scope it writes back the whole L2)
+#pragma unroll
+        for (int k = 0; k < DS_COUNT; ++k) __hip_atomic_store(&mail[k], d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(&mail[DS_COUNT], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(TPB) void k_new_keys(int64_t n, const int32_t *__restrict__ new_cells, const int32_t *__restrict__ occ,
                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ val)
 {
@@ -1787,15 +1884,23 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     stat_end(x, BSC_STAT_POINTS, 0.0);
     if (x->log_cap)             // the call's records, block-grouped like p_rec (every voxel's points still in order j)
         BSC_HIP(hipMemcpyAsync(x->log_rec + x->log_n, p_rec, sizeof(PointRec) * (size_t)P, hipMemcpyDeviceToDevice, s));
-    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
-    BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
-                       x->c.voxel_capacity, x->bscal_s[set]);
+    static const bool fused_totals = getenv("BSC_TOTALS_UNFUSED") == nullptr;
+    const bool early = x->order_on_side && !exact;
+    const bool mailbox = fused_totals && early && x->mail != nullptr;
+    if (fused_totals) {
+        x->mail_seq += 1;
+        hipLaunchKernelGGL(k_block_totals, dim3(1), dim3(BT_THREADS), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off,
+                           x->dscal, x->c.voxel_capacity, x->bscal_s[set], mailbox ? x->mail_dev : (int64_t *)nullptr, x->mail_seq);
+    } else {
+        BSC_TRY(prim_exclusive_sum_i32(x, x->blk_cnt, x->blk_off, (size_t)nblk));
+        BSC_TRY(prim_exclusive_sum_i32(x, x->blk_pass, x->blk_pass_off, (size_t)nblk));
+        hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, s, P, nblk, x->blk_cnt, x->blk_off, x->blk_pass, x->blk_pass_off, x->dscal,
+                           x->c.voxel_capacity, x->bscal_s[set]);
+    }
     // early: (dense modes, order stage on the side stream) the counts k_totals wrote come back over a copy stream WHILE the main
     // stream runs the pair tiles, and the new-voxel ids + order stage are enqueued on the side stream during that time; the pair
     // count follows with a second, short readback.  With ONE readback after the pair tiles the host came back to an empty main
     // stream and spent ~0.26 ms enqueueing before it had work again, and the order stage (hence the rgb chain) started 0.45 ms late.
-    const bool early = x->order_on_side && !exact;
     if (early) BSC_HIP(hipEventRecord(x->ev_tot, s));
     stat_begin(x, BSC_STAT_PAIRS);
     BSC_TRY(launch_keys_pairs(x, P, n_frames, idx == nullptr, patf));
@@ -1805,9 +1910,25 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
     if (early) {
         // the pair count: copied behind the pair tiles right away (its own pinned slot), waited for after the side stream's launches
         BSC_HIP(hipMemcpyAsync(x->hscal + DS_COUNT, x->dscal + DS_B_NPAIR, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        BSC_HIP(hipStreamWaitEvent(x->copy, x->ev_tot, 0));
-        BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->copy));
-        BSC_HIP(hipStreamSynchronize(x->copy));
+        bool got = false;
+        if (mailbox) {
+            // the scalars arrive in the mailbox behind k_block_totals; spin on its sequence number (bounded: a failed launch or a
+            // lost device never writes it — after ~2 s fall back to the copy, which reports the error)
+            volatile int64_t *const mb = x->mail;
+            for (int64_t spin = 0; spin < (1ll << 31); ++spin) {
+                if (__atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq) { got = true; break; }
+                if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s) != hipErrorNotReady) {
+                    got = __atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq;
+                    break;
+                }
+            }
+            if (got) for (int k = 0; k < DS_COUNT; ++k) x->hscal[k] = mb[k];
+        }
+        if (!got) {
+            BSC_HIP(hipStreamWaitEvent(x->copy, x->ev_tot, 0));
+            BSC_HIP(hipMemcpyAsync(x->hscal, x->dscal, sizeof(int64_t) * DS_COUNT, hipMemcpyDeviceToHost, x->copy));
+            BSC_HIP(hipStreamSynchronize(x->copy));
+        }
     } else {
         BSC_TRY(read_scalars(x));
     }
