@@ -66,14 +66,16 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PMC_FILE = "r06_pmc_ingest_kernels.json"
-# k_points by its SQ counters (profiles/r05_pmc_k_points.txt: SQ_INSTS_VALU / SQ_INSTS_SALU per wavefront of 512 points / 8 rounds;
-# the f64 share from the ISA: 664 of 2819 static vector instructions)
-KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 266.7, 63.0, 105.5
+# k_points by its SQ counters (profiles/r06_pmc_sq_ingest.txt, collected at 725086e: SQ_INSTS_VALU 797.2 M, of them
+# SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 136.4 M, SQ_INSTS_SALU 359.5 M per 460 800 wavefronts of 8 rounds of 64 points; round 5: 266.7 / 63 / 105.5)
+KP_VALU_PER_64, KP_VALU_F64_PER_64, KP_SALU_PER_64 = 216.3, 37.0, 97.5
 N_SIMD, CLOCK_GHZ = 1024, 2.4            # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), committed PMC pass (profiles/r05_pmc_mfma_counters.txt)
-MFMA_BUSY_COMMITTED = {"k_gemm_split qkv (LayerNorm in the load)": 0.435, "k_gemm_split fc1 + GELU (LayerNorm in the load)": 0.419,
-                       "k_gemm_split proj / fc2 (residual + statistics)": 0.430, "k_attention_split": 0.27, "k_cosine_f16x2 (Q = 256)": 0.378,
-                       "hipBLASLt bf16 (same shapes, round 4)": "0.43-0.47", "source": "profiles/r05_pmc_mfma_counters.txt"}
+# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), committed PMC pass (profiles/r06_pmc_mfma_counters.txt: the encoder's
+# kernels with the exact erf GELU epilogue; the batched scan from profiles/r05_pmc_mfma_counters.txt, its kernel unchanged since)
+MFMA_BUSY_COMMITTED = {"k_gemm_split qkv (LayerNorm in the load)": 0.438, "k_gemm_split fc1 + erf GELU (LayerNorm in the load)": 0.407,
+                       "k_gemm_split proj / fc2 (residual + statistics)": 0.432, "k_attention_split": 0.269, "k_cosine_f16x2 (Q = 256)": 0.378,
+                       "hipBLASLt bf16 (same shapes, round 4)": "0.43-0.47",
+                       "source": "profiles/r06_pmc_mfma_counters.txt (encoder), profiles/r05_pmc_mfma_counters.txt (k_cosine_f16x2)"}
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0
 MFMA_F32_PEAK_TF = 157.3
@@ -246,12 +248,26 @@ class Pipeline:
             out["encoder"] = sum(a.elapsed_time(b) for a, b in self.enc_events) / len(self.enc_events)
         return out
 
-    def isolated(self, lo, hi):
-        """Untimed extra pass: the encoder alone, then bsc_ingest alone (un-contended stage times)."""
+    def isolated(self, lo, hi, power=False):
+        """Untimed extra pass: the encoder alone, then bsc_ingest alone (un-contended stage times).  power: socket power sampled by
+        rocm-smi in a side thread while the encoder runs alone (joules per frame of the forward)."""
         torch.cuda.synchronize()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         enc = self.encs[0]
         tok = enc(self.rgbs[lo])
+        watts = None
+        if power:
+            # enough forwards for a dozen samples (a rocm-smi call takes ~50 ms); the sampler sees only fully loaded seconds
+            smp = PowerSampler()
+            for _ in range(3):
+                tok = enc(self.rgbs[lo])
+            torch.cuda.synchronize()
+            smp.start()
+            for _ in range(4):
+                for s in range(lo, hi):
+                    tok = enc(self.rgbs[s])
+            torch.cuda.synchronize()
+            watts = smp.stop()
         e0.record()
         for s in range(lo, hi):
             tok = enc(self.rgbs[s])
@@ -266,7 +282,7 @@ class Pipeline:
         torch.cuda.synchronize()
         k = hi - lo
         c1 = self.eng.counters()
-        return dict(encoder_ms=e0.elapsed_time(e1) / k, ingest_wall_ms=e1.elapsed_time(e2) / k, stages=self.stage_ms(),
+        return dict(encoder_ms=e0.elapsed_time(e1) / k, encoder_watts=watts, ingest_wall_ms=e1.elapsed_time(e2) / k, stages=self.stage_ms(),
                     U=(c1["voxel_rmw"] - c0["voxel_rmw"]) / k, U_new=(c1["max_id"] - c0["max_id"]) / k,
                     P=(c1["points_passed"] - c0["points_passed"]) / k, pairs=(c1["pairs"] - c0["pairs"]) / k)
 
@@ -274,6 +290,34 @@ class Pipeline:
         self.eng.close()
         self.rgbs, self.depths, self.encs = [], [], []
         torch.cuda.empty_cache()
+
+
+class PowerSampler:
+    """Socket power (W) from `rocm-smi --showpower --csv`, sampled by a side thread; stop() -> {"mean_W", "max_W", "samples"} or None."""
+
+    def __init__(self, period=0.05):
+        import threading
+        self.period, self.vals, self._stop = period, [], False
+        self.th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showpower", "--csv"], capture_output=True, text=True, timeout=5).stdout.strip().splitlines()
+                self.vals.append(float(o[-1].split(",")[-1]))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        self.th.start()
+
+    def stop(self):
+        self._stop = True
+        self.th.join(timeout=10)
+        v = self.vals[1:-1] if len(self.vals) > 4 else self.vals      # the first / last sample may straddle the loaded interval
+        return {"mean_W": sum(v) / len(v), "max_W": max(v), "samples": len(v)} if v else None
 
 
 def stage_rooflines(p, iso, tok_bytes):
@@ -287,7 +331,7 @@ def stage_rooflines(p, iso, tok_bytes):
         "pair_sort": 2 * 12.0 * pairs,                                         # pairs in / out once
         "k_dense_reduce": (2 * U - U_new) * D * 4 + 8 * U + F * g * g * D * tok_bytes + 12 * pairs,
         "ids+point_order": 0.25 * P,                                           # per-voxel point order out: a start bit per point + a checkpoint per 64 (runs in: not counted)
-        "k_chain": 12.0 * P + 19.0 * U,                                        # record per point, voxel state
+        "k_chain": 8.0 * P + 19.0 * U,                                         # 8-byte record per point (round 6; 12 before), voxel state
     }
     out = {}
     for name, b in byts.items():
@@ -1091,7 +1135,7 @@ def main():
                 merge_info["xgmi_note"] = ("expected = bytes a rank sends / links / 153 GB/s (MI355X_MICROARCH.md: 7 links per GPU); the measured "
                                            "phases_ms are of the backend named in config.distributed")
     if rank == 0 and world == 1:
-        iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8))
+        iso = p.isolated(a.warmup, min(n_steps, a.warmup + 8), power=rank == 0 and world == 1)
         ing_ms = stage_timed["bsc_ingest"]
         single = {k: v for k, v in stage_timed.items() if k in ("k_points", "k_keys_pairs", "k_dense_reduce")}
         dom = max(single, key=single.get)
@@ -1120,14 +1164,15 @@ def main():
         need = pts / 64.0 * cyc
         out["roofline"]["k_points_valu"] = {
             "bound": "vector instruction issue (CDNA4 SIMD-32: a wave64 instruction issues over 2 cycles, an f64 one over 4) — the kernel's "
-                     "largest single resource; by its phase clocks (profiles/README.md) the geometry phase runs at the issue rate of its four "
-                     "co-resident wavefronts, the grouping phases wait on LDS and the CU's one scalar unit (~100 scalar instructions per 64 points)",
+                     "largest single resource; by its phase clocks (profiles/README.md) the geometry phase runs at the issue rate of its five "
+                     "co-resident wavefronts, the grouping phases wait on LDS round trips (half of its LDS cycles are bank conflicts) and on the "
+                     "CU's one scalar unit (~100 scalar instructions per 64 points)",
             "kernel": "k_points", "ms_per_call": kp_ms,
             "valu_instructions_per_64_points": KP_VALU_PER_64, "of_them_f64": KP_VALU_F64_PER_64, "salu_instructions_per_64_points": KP_SALU_PER_64,
             "achieved": need / (kp_ms * 1e-3) / 1e12, "peak": N_SIMD * CLOCK_GHZ * 1e9 / 1e12, "unit": "T issue-cycles/s",
             "frac": need / (kp_ms * 1e-3) / (N_SIMD * CLOCK_GHZ * 1e9),
             "hbm_frac_of_own_bytes": 8.0 * pts / (kp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "source": "profiles/r05_pmc_k_points.txt (SQ_INSTS_VALU / SQ_INSTS_SALU per wavefront of 512 points) x points of this run / HIP-event time of this run"}
+            "source": "profiles/r06_pmc_sq_ingest.txt (SQ_INSTS_VALU / _F64 / SQ_INSTS_SALU per wavefront of 512 points) x points of this run / HIP-event time of this run"}
         out["roofline"]["kernels"] = {"note": "bsc_ingest running alone (no encoder beside it, a synchronize per call); own algorithmic bytes per stage",
                                       **stage_rooflines(p, iso, tok_bytes)}
         fl = p.vit.flops_per_frame() * a.batch
@@ -1144,6 +1189,13 @@ def main():
                                    "PFLOP/s (0.40-0.50 of the data-sheet peak); kernel-level gains measured alone (LayerNorm passes removed, "
                                    "-5 % kernel time) do not show in the sustained forward",
             "mfma_busy_committed": MFMA_BUSY_COMMITTED}
+        if iso.get("encoder_watts"):
+            # the forward is power-bound: what it costs is joules — socket power while it runs alone (rocm-smi, sampled in this run) x
+            # its time / frames of the step
+            w = iso["encoder_watts"]
+            enc_blk["socket_power_W_while_running_alone"] = w
+            enc_blk["joules_per_frame"] = w["mean_W"] * iso["encoder_ms"] * 1e-3 / a.batch
+            enc_blk["joules_per_forward"] = w["mean_W"] * iso["encoder_ms"] * 1e-3
         if f32 and p.vit.split_gemm:
             guarded("kernels", lambda: encoder_kernel_rates(p.vit, a.batch), into=enc_blk)
         out["roofline"]["encoder"] = enc_blk
