@@ -409,11 +409,14 @@ def test_long_chains_of_old_voxels_over_several_calls():
 
 
 @pytest.mark.parametrize("knob", ["BSC_ORDER_MAIN=1", "BSC_QUAD_CHAIN_ONLY=1", "BSC_CHAIN_EAGER=1", "BSC_NO_HOT_SPLIT=1",
-                                  "BSC_LONG_NWV=8", "BSC_HOT_LOG2=10", "BSC_LONG_LOG2=8", "BSC_GROUP_RPW=4"])
+                                  "BSC_LONG_NWV=8", "BSC_HOT_LOG2=10", "BSC_LONG_LOG2=8", "BSC_GROUP_RPW=4",
+                                  "BSC_CHAIN_SPLIT=0", "BSC_LONG_NWV=16", "BSC_TOTALS_UNFUSED=1", "BSC_NO_MAILBOX=1", "BSC_PROJ_DIVIDE=1",
+                                  "BSC_REC12=1", "BSC_SORT_ROCPRIM=1"])
 def test_chain_and_order_knobs_keep_the_result(knob):
     """The library's A/B switches move work between streams and kernels (order stage on the main stream, quad chain only, chain
-    right behind its order stage, no hot split, 8-wavefront hot tiles, other length classes, 1024-point blocks) — never the
-    result: the long-chain scene in three calls, bit-exact against the oracle, under each of them.  Most are read once per
+    right behind its order stage, no hot split, 8-wavefront hot tiles, other length classes, 1024-point blocks; round 6: the long
+    chain as one launch, 16-wavefront hot tiles, block scans + totals as separate launches, scalars by copy instead of the host
+    mailbox, source pixel by division, 12-byte records, rocPRIM sorts) — never the result: the long-chain scene in three calls, bit-exact against the oracle, under each of them.  Most are read once per
     process, so every case runs in its own interpreter."""
     import os, subprocess, sys
     name, val = knob.split("=")
