@@ -829,7 +829,8 @@ def localize_leg(B, a, local_rank, D, V=1 << 20, gL=512):
             np_ = 6.0 if os.environ.get("BSC_COSINE_BF16") else 3.0
             e.update({"cosine_f32_equivalent_TFLOPs": tf, "cosine_16bit_mfma_TFLOPs": np_ * tf, "piece_products": np_,
                       "cosine_frac_of_16bit_mfma_peak": np_ * tf / MFMA_BF16_PEAK_TF})
-            # the first query batch after the rows changed also rebuilds the per-row scales / inverse norms (one pass over the rows)
+            # the first query batch after the rows were replaced: since round 6 whoever changes the rows (ingest: in its reduce;
+            # imports / merges: at their end, bsc localize_prepare) leaves name ranks and row scales current — this should equal latency_ms
             engL.dense_replace(keys, rows, torch.ones(V, dtype=torch.int32, device="cuda"))
             engL.sync(); torch.cuda.synchronize()
             t = time.perf_counter()

@@ -311,6 +311,7 @@ bsc_status localize_impl(bsc_ctx *x, const float *q_dev, int32_t nq, int32_t K, 
 int64_t sims_row_stride(int64_t n_rows);
 bsc_status pool_query_impl(bsc_ctx *x, const float *tokens, int32_t B, int32_t T, int32_t D, float *out);
 bsc_status read_scalars(bsc_ctx *x); // dscal -> hscal (synchronises the main stream)
+void localize_prepare(bsc_ctx *x);   // name ranks + row scales of the batched scan, eagerly (localize.hip; the imports call it)
 bsc_status sync_all(bsc_ctx *x);     // main + side stream
 // record the start / stop event of launch number ev_n[which] (ring; older launches are overwritten)
 static inline void stat_begin(bsc_ctx *x, int which, hipStream_t s = nullptr)

@@ -900,7 +900,7 @@ extern "C" bsc_status bsc_import_store(bsc_ctx *x, int64_t nv, int64_t nt, const
     }
     free(occ); free(h_cnt); free(h_rows);
     x->names_dirty = true; x->row_scale_dirty = true;
-    if (st == BSC_OK) x->pool_n_host = nt;
+    if (st == BSC_OK) { x->pool_n_host = nt; localize_prepare(x); }
     return st;
 }
 
@@ -915,6 +915,7 @@ extern "C" bsc_status bsc_import_dense(bsc_ctx *x, int64_t max_id, const float *
     BSC_TRY(h2d_pipelined(x, x->acc, acc, sizeof(float) * (size_t)max_id * x->c.token_dim));
     BSC_HIP(hipMemcpy(x->acnt, cnt, sizeof(int32_t) * max_id, hipMemcpyHostToDevice));
     x->names_dirty = true; x->row_scale_dirty = true;
+    localize_prepare(x);
     return BSC_OK;
 }
 
@@ -1135,6 +1136,7 @@ extern "C" bsc_status bsc_dense_replace_full(bsc_ctx *x, int64_t n, const int32_
         bsc_set_error("bsc_dense_replace: a key lies outside the grid");
         return BSC_E_INVALID;
     }
+    localize_prepare(x);        // the merged / replaced memory is about to be queried: name ranks and row scales now
     return BSC_OK;
 }
 
