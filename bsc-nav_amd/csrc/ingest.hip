@@ -23,6 +23,7 @@
 #include "geometry_dev.h"
 
 #include <limits.h>
+#include <sched.h>
 #include <math.h>
 
 #define TPB 256
@@ -1917,6 +1918,7 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
             volatile int64_t *const mb = x->mail;
             for (int64_t spin = 0; spin < (1ll << 31); ++spin) {
                 if (__atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq) { got = true; break; }
+                if ((spin & 1023) == 1023) sched_yield();       // behind a caller's encoder pass the wait is long: let other threads run
                 if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s) != hipErrorNotReady) {
                     got = __atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq;
                     break;
