@@ -4,17 +4,21 @@
 // top-down map and the token cache are all defined by that order.  Here every point j of a batch
 // (frames in call order, points in the reference's shuffled order) carries its order implicitly:
 //
-//   k_points    1024 consecutive points per workgroup: geometry (fp64, bit-exact) -> cell / rgb / alpha; atomicMin
-//               claims the first toucher of every still-empty cell, the first claimer (in time) lists the cell as new;
-//               per-block counts of passing points and of RUNS (stretches of consecutive points in one cell)
-//   k_keys_pairs (dense.hip) LDS aggregation of (cell, frame, patch) pairs — independent of the ids
+//   k_points    2048 consecutive points per workgroup: geometry (fp64, bit-exact) -> cell / rgb (/ alpha); the block groups its
+//               records by cell (stable, in LDS), emits ONE run per (block, cell) and makes one first-touch claim per cell: the
+//               smallest point index wins a still-empty cell, the claimer that found it empty lists the cell as new
+//   k_block_totals   the block scans (runs, passing points) + the batch scalars in one launch; the scalars reach the host through
+//               a mailbox in pinned memory (round 6; k_totals + two rocPRIM scans + a copy before)
+//   k_patch_pairs / k_keys_pairs (dense.hip) LDS aggregation of (cell, frame, patch) pairs — independent of the ids
 //   k_new_keys + sort + k_new_assign   the new cells ranked by their winning point: id = max_id + rank, as the
 //               sequential max_id++ hands them out (a few thousand cells, not a pass over the points)
-//   k_runs      one pass over the cells: every run as key = voxel id | (length - 1) << id bits, value = first point
-//   radix sort  of the runs (stable, on the id bits only), one scan of (length, segment head) pairs, k_expand: every
-//               voxel's points in order j, at a fraction of the traffic of sorting the points themselves
-//   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on
-//               (h, order of the voxel's latest point)                        (1 quad of lanes / voxel)
+//   k_run_keys  every run as key = voxel id | (length - 1) << id bits, value = its first record
+//   radix sort  of the runs (radix.hip: stable, on the id bits only), k_run_blocksum + scan + k_expand: every voxel's points in
+//               order j as run start bits + a checkpoint per 64 positions — no index per point
+//   k_chain     per voxel: sequential truncating weighted rgb mean + top-down map atomicMax on (h, order of the voxel's latest
+//               point), a quad of lanes per voxel (short segments, the first points of new voxels)
+//   k_chain_long   long segments 64 points per round by checked prediction: hot segments in register tiles over a workgroup,
+//               the one-wavefront segments as a launch of their own beside them (round 6)
 //   k_hwin      the winning voxel of each map cell writes its colour
 //   dense.hip   pair sort + k_dense_reduce: multiplicity x token rows -> one RMW of the D-float
 //               accumulator row per voxel
