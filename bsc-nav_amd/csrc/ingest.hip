@@ -644,12 +644,12 @@ __global__ __launch_bounds__(BT_THREADS) void k_block_totals(int64_t P, int64_t 
     bscal[5] = 0;                       // (unused)
     bscal[6] = 0;                       // hot segments (k_seg_order): the first bscal[6] of the long ones, a workgroup each
     if (mail) {
-        // write-through stores to the host, one wait for all their acknowledgements, then the sequence number: no release fence
-        // (at system scope it writes back the whole L2)
+        // write-through 8-byte stores to the host, EVERY word tagged with the call's sequence number (value << 16 | seq: the scalars
+        // are counts below 2^47): the host takes the mailbox once all words carry the tag, whatever order the fabric delivered them
+        // in — no release fence (at system scope it writes back the whole L2), no ordering assumed between posted writes
 #pragma unroll
-        for (int k = 0; k < DS_COUNT; ++k) __hip_atomic_store(&mail[k], d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_s_waitcnt(0);
-        __hip_atomic_store(&mail[DS_COUNT], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int k = 0; k < DS_COUNT; ++k)
+            __hip_atomic_store(&mail[k], (int64_t)(((u64)d[k] << 16) | ((u64)seq & 0xffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1920,15 +1920,18 @@ bsc_status ingest_batch(bsc_ctx *x, int32_t n_frames, const float *depth, const 
             // the scalars arrive in the mailbox behind k_block_totals; spin on its sequence number (bounded: a failed launch or a
             // lost device never writes it — after ~2 s fall back to the copy, which reports the error)
             volatile int64_t *const mb = x->mail;
+            const u64 tag = (u64)x->mail_seq & 0xffffull;
+            const auto all_tagged = [&]() {
+                for (int k = 0; k < DS_COUNT; ++k)
+                    if (((u64)__atomic_load_n(&mb[k], __ATOMIC_ACQUIRE) & 0xffffull) != tag) return false;
+                return true;
+            };
             for (int64_t spin = 0; spin < (1ll << 31); ++spin) {
-                if (__atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq) { got = true; break; }
+                if (((u64)__atomic_load_n(&mb[DS_COUNT - 1], __ATOMIC_ACQUIRE) & 0xffffull) == tag && all_tagged()) { got = true; break; }
                 if ((spin & 1023) == 1023) sched_yield();       // behind a caller's encoder pass the wait is long: let other threads run
-                if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s) != hipErrorNotReady) {
-                    got = __atomic_load_n(&mb[DS_COUNT], __ATOMIC_ACQUIRE) == x->mail_seq;
-                    break;
-                }
+                if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s) != hipErrorNotReady) { got = all_tagged(); break; }
             }
-            if (got) for (int k = 0; k < DS_COUNT; ++k) x->hscal[k] = mb[k];
+            if (got) for (int k = 0; k < DS_COUNT; ++k) x->hscal[k] = (int64_t)mb[k] >> 16;       // (arithmetic: a value in +-2^47 survives)
         }
         if (!got) {
             BSC_HIP(hipStreamWaitEvent(x->copy, x->ev_tot, 0));
